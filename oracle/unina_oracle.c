@@ -1,0 +1,591 @@
+/*
+ * unina_oracle.c -- CPU ORACLE, forward graph (test infrastructure, NOT product code).
+ *
+ * fp32 NCHW restatement of the reference forward, module by module, taking the
+ * reference's UNFOLDED parameters (conv weight + BN gamma/beta/mean/var), so that the
+ * engine's BN folding is itself under test.
+ *
+ * Reference: /root/reference/unina_yolo_dla/model.py
+ *   ConvBlock      :23-50     Bottleneck :53-73    C3k2     :76-110
+ *   SPPF_DLA       :113-132   Upsample   :135-147  Backbone :152-219
+ *   Neck           :224-269   DetectionHead :274-303   UNINA_YOLO_DLA.forward :347-365
+ *
+ * Also used as bench.py's cpu_baseline ("port"): the convolution is a register-tiled
+ * 4x16 GEMM micro-kernel over a zero-padded copy of the input (AVX2/FMA through GCC
+ * vector extensions, OpenMP over output tiles) so that the denominator is a fair one.
+ */
+#define _GNU_SOURCE
+#include "unina_oracle.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ errors */
+static char g_err[512];
+const char *uo_last_error(void) { return g_err; }
+static void set_err(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+/* -------------------------------------------------------------- state dict */
+typedef struct {
+  char *name;
+  int ndim;
+  int dims[4];
+  float *data;
+} sd_entry;
+struct uo_statedict {
+  int count;
+  sd_entry *e;
+};
+
+uo_statedict *uo_sd_load(const char *path) {
+  FILE *f = fopen(path, "rb");
+  if (!f) {
+    set_err("cannot open %s", path);
+    return NULL;
+  }
+  char magic[8];
+  uint32_t count = 0;
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "UNSD0001", 8) || fread(&count, 4, 1, f) != 1) {
+    set_err("%s: bad UNSD header", path);
+    fclose(f);
+    return NULL;
+  }
+  uo_statedict *sd = calloc(1, sizeof *sd);
+  sd->count = (int)count;
+  sd->e = calloc(count, sizeof(sd_entry));
+  for (uint32_t i = 0; i < count; ++i) {
+    uint16_t nl;
+    uint32_t nd, dims[8];
+    if (fread(&nl, 2, 1, f) != 1) goto bad;
+    sd->e[i].name = calloc(nl + 1, 1);
+    if (fread(sd->e[i].name, 1, nl, f) != nl) goto bad;
+    if (fread(&nd, 4, 1, f) != 1 || nd > 4) goto bad;
+    if (nd && fread(dims, 4, nd, f) != nd) goto bad;
+    size_t n = 1;
+    sd->e[i].ndim = (int)nd;
+    for (uint32_t d = 0; d < nd; ++d) {
+      sd->e[i].dims[d] = (int)dims[d];
+      n *= dims[d];
+    }
+    sd->e[i].data = malloc(n * sizeof(float));
+    if (fread(sd->e[i].data, 4, n, f) != n) goto bad;
+  }
+  fclose(f);
+  return sd;
+bad:
+  set_err("%s: truncated UNSD file", path);
+  fclose(f);
+  uo_sd_free(sd);
+  return NULL;
+}
+
+void uo_sd_free(uo_statedict *sd) {
+  if (!sd) return;
+  for (int i = 0; i < sd->count; ++i) {
+    free(sd->e[i].name);
+    free(sd->e[i].data);
+  }
+  free(sd->e);
+  free(sd);
+}
+int uo_sd_count(const uo_statedict *sd) { return sd->count; }
+
+const float *uo_sd_get(const uo_statedict *sd, const char *name, int *ndim, int dims[4]) {
+  for (int i = 0; i < sd->count; ++i)
+    if (!strcmp(sd->e[i].name, name)) {
+      if (ndim) *ndim = sd->e[i].ndim;
+      if (dims) memcpy(dims, sd->e[i].dims, sizeof sd->e[i].dims);
+      return sd->e[i].data;
+    }
+  return NULL;
+}
+
+/* ------------------------------------------------------------------ tensors */
+typedef struct {
+  int c, h, w;
+  float *d; /* [c][h][w] */
+} ten;
+
+/* One persistent slab, bump-allocated per forward; pages stay mapped between calls so the
+ * cpu_baseline timing is not dominated by page faults. One live run at a time. */
+static char *g_slab;
+static size_t g_slab_cap, g_slab_used;
+static int g_slab_live;
+
+static float *slab_alloc(size_t nfloats) {
+  size_t bytes = (nfloats * sizeof(float) + 63) & ~(size_t)63;
+  if (g_slab_used + bytes > g_slab_cap) return NULL;
+  float *p = (float *)(g_slab + g_slab_used);
+  g_slab_used += bytes;
+  return p;
+}
+
+#define MAX_NAMED 256
+struct uo_run {
+  int n;
+  char *names[MAX_NAMED];
+  ten t[MAX_NAMED];
+  int keep_all;
+  int failed;
+};
+
+static ten new_ten(uo_run *r, int c, int h, int w) {
+  ten t = {c, h, w, slab_alloc((size_t)c * h * w)};
+  if (!t.d) {
+    r->failed = 1;
+    set_err("oracle slab exhausted");
+  }
+  return t;
+}
+static void keep(uo_run *r, const char *name, ten t, int always) {
+  if (!(r->keep_all || always) || r->n >= MAX_NAMED) return;
+  r->names[r->n] = strdup(name);
+  r->t[r->n++] = t;
+}
+
+/* ------------------------------------------------------------- convolution */
+typedef float v8f __attribute__((vector_size(32)));
+static inline v8f ld8(const float *p) {
+  v8f v;
+  memcpy(&v, p, 32);
+  return v;
+}
+static inline void st8(float *p, v8f v) { memcpy(p, &v, 32); }
+
+#define MR 4  /* output channels per register tile */
+#define NR 16 /* output pixels (one row segment) per register tile */
+#define KC 256
+
+/* acc[MR][NR] += sum_k wp[k][0..MR) * src[koff[k] + 0..NR)   (k-sequential fp32 accumulation) */
+static inline void micro_4x16(const float *restrict wp, const float *restrict base,
+                              const int64_t *restrict koff, int kn, float *restrict acc) {
+  v8f a00 = ld8(acc + 0), a01 = ld8(acc + 8), a10 = ld8(acc + 16), a11 = ld8(acc + 24);
+  v8f a20 = ld8(acc + 32), a21 = ld8(acc + 40), a30 = ld8(acc + 48), a31 = ld8(acc + 56);
+  for (int k = 0; k < kn; ++k) {
+    const float *bp = base + koff[k];
+    v8f b0 = ld8(bp), b1 = ld8(bp + 8);
+    const float *w = wp + (size_t)k * MR;
+    v8f w0 = {w[0], w[0], w[0], w[0], w[0], w[0], w[0], w[0]};
+    v8f w1 = {w[1], w[1], w[1], w[1], w[1], w[1], w[1], w[1]};
+    v8f w2 = {w[2], w[2], w[2], w[2], w[2], w[2], w[2], w[2]};
+    v8f w3 = {w[3], w[3], w[3], w[3], w[3], w[3], w[3], w[3]};
+    a00 += w0 * b0; a01 += w0 * b1;
+    a10 += w1 * b0; a11 += w1 * b1;
+    a20 += w2 * b0; a21 += w2 * b1;
+    a30 += w3 * b0; a31 += w3 * b1;
+  }
+  st8(acc + 0, a00); st8(acc + 8, a01); st8(acc + 16, a10); st8(acc + 24, a11);
+  st8(acc + 32, a20); st8(acc + 40, a21); st8(acc + 48, a30); st8(acc + 56, a31);
+}
+
+/* Conv2d, cross-correlation, zero padding k/2, stride s in {1,2}, k in {1,3}, optional bias
+ * (model.py:41-44 uses bias=False; the head output convs model.py:292,299 use bias=True).
+ * wgt is [O][C][k][k] exactly as in the reference state_dict. */
+static ten conv2d(uo_run *r, ten in, const float *wgt, const float *bias, int O, int k, int s) {
+  const int C = in.c, H = in.h, W = in.w, p = k / 2;
+  const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+  ten out = new_ten(r, O, Ho, Wo);
+  if (r->failed) return out;
+  const int K = C * k * k;
+
+  /* 1. source planes with contiguous x for every tap */
+  int64_t *koff = malloc(sizeof(int64_t) * (size_t)K);
+  float *src;
+  int64_t rs; /* row stride of the planes */
+  if (s == 1) {
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    rs = Wp;
+    src = calloc((size_t)C * Hp * Wp + 64, sizeof(float));
+    for (int c = 0; c < C; ++c)
+      for (int y = 0; y < H; ++y)
+        memcpy(src + ((size_t)c * Hp + y + p) * Wp + p, in.d + ((size_t)c * H + y) * W, sizeof(float) * W);
+    for (int c = 0, kk = 0; c < C; ++c)
+      for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw, ++kk) koff[kk] = ((int64_t)c * Hp + kh) * Wp + kw;
+  } else {
+    /* stride 2: split the padded input into 4 parity planes Q[a][b][c][yy][xx] = pad[c][2yy+a][2xx+b] */
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    const int Hh = (Hp + 1) / 2, Wh = (Wp + 1) / 2;
+    rs = Wh;
+    const size_t plane = (size_t)C * Hh * Wh;
+    src = calloc(4 * plane + 64, sizeof(float));
+    for (int c = 0; c < C; ++c)
+      for (int y = 0; y < H; ++y) {
+        const int py = y + p;
+        for (int x = 0; x < W; ++x) {
+          const int px = x + p;
+          src[(size_t)((py & 1) * 2 + (px & 1)) * plane + ((size_t)c * Hh + (py >> 1)) * Wh + (px >> 1)] =
+              in.d[((size_t)c * H + y) * W + x];
+        }
+      }
+    for (int c = 0, kk = 0; c < C; ++c)
+      for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw, ++kk)
+          koff[kk] = (int64_t)((kh & 1) * 2 + (kw & 1)) * (int64_t)plane + ((int64_t)c * Hh + (kh >> 1)) * Wh + (kw >> 1);
+  }
+
+  /* 2. weights packed per MR-panel: wp[panel][K][MR], zero-padded rows */
+  const int panels = (O + MR - 1) / MR;
+  float *wp = calloc((size_t)panels * K * MR, sizeof(float));
+  for (int o = 0; o < O; ++o)
+    for (int kk = 0; kk < K; ++kk) wp[((size_t)(o / MR) * K + kk) * MR + (o % MR)] = wgt[(size_t)o * K + kk];
+
+  /* 3. tiles */
+  const int xt = (Wo + NR - 1) / NR;
+#pragma omp parallel
+  {
+    float *tmp = malloc(sizeof(float) * (size_t)panels * MR * NR);
+#pragma omp for collapse(2) schedule(dynamic, 1)
+    for (int y = 0; y < Ho; ++y)
+      for (int xi = 0; xi < xt; ++xi) {
+        const int x0 = xi * NR;
+        const float *base = src + (int64_t)y * rs + x0;
+        memset(tmp, 0, sizeof(float) * (size_t)panels * MR * NR);
+        for (int k0 = 0; k0 < K; k0 += KC) {
+          const int kn = K - k0 < KC ? K - k0 : KC;
+          for (int pn = 0; pn < panels; ++pn)
+            micro_4x16(wp + ((size_t)pn * K + k0) * MR, base, koff + k0, kn, tmp + (size_t)pn * MR * NR);
+        }
+        const int nx = Wo - x0 < NR ? Wo - x0 : NR;
+        for (int o = 0; o < O; ++o) {
+          const float b = bias ? bias[o] : 0.0f;
+          float *dst = out.d + ((size_t)o * Ho + y) * Wo + x0;
+          const float *t = tmp + (size_t)o * NR;
+          for (int j = 0; j < nx; ++j) dst[j] = t[j] + b;
+        }
+      }
+    free(tmp);
+  }
+  free(wp);
+  free(src);
+  free(koff);
+  return out;
+}
+
+/* BatchNorm2d (eval) + ReLU, in place: y = (x-mean)/sqrt(var+eps)*gamma+beta  (model.py:46-50) */
+static void bn_relu(ten t, const float *gamma, const float *beta, const float *mean, const float *var) {
+  const size_t hw = (size_t)t.h * t.w;
+#pragma omp parallel for schedule(static)
+  for (int c = 0; c < t.c; ++c) {
+    const float invstd = 1.0f / sqrtf(var[c] + 1e-5f);
+    float *d = t.d + (size_t)c * hw;
+    for (size_t i = 0; i < hw; ++i) {
+      float v = (d[i] - mean[c]) * invstd * gamma[c] + beta[c];
+      d[i] = v > 0.0f ? v : 0.0f;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ modules */
+typedef struct {
+  uo_run *r;
+  const uo_statedict *sd;
+} net;
+
+static const float *param(net *n, const char *mod, const char *suffix, int expect) {
+  char key[256];
+  snprintf(key, sizeof key, "%s.%s", mod, suffix);
+  int nd, dims[4];
+  const float *p = uo_sd_get(n->sd, key, &nd, dims);
+  if (!p) {
+    n->r->failed = 1;
+    set_err("missing parameter %s", key);
+    return NULL;
+  }
+  size_t cnt = 1;
+  for (int i = 0; i < nd; ++i) cnt *= (size_t)dims[i];
+  if ((int)cnt != expect) {
+    n->r->failed = 1;
+    set_err("parameter %s has %zu elements, expected %d", key, cnt, expect);
+    return NULL;
+  }
+  return p;
+}
+
+/* ConvBlock (model.py:23-50) */
+static ten conv_block(net *n, const char *name, ten x, int cout, int k, int s) {
+  ten bad = {0, 0, 0, NULL};
+  const float *w = param(n, name, "conv.weight", cout * x.c * k * k);
+  const float *g = param(n, name, "bn.weight", cout), *b = param(n, name, "bn.bias", cout);
+  const float *m = param(n, name, "bn.running_mean", cout), *v = param(n, name, "bn.running_var", cout);
+  if (n->r->failed) return bad;
+  ten y = conv2d(n->r, x, w, NULL, cout, k, s);
+  if (n->r->failed) return bad;
+  bn_relu(y, g, b, m, v);
+  keep(n->r, name, y, 0);
+  return y;
+}
+
+static ten add(net *n, const char *name, ten a, ten b) {
+  ten y = new_ten(n->r, a.c, a.h, a.w);
+  if (n->r->failed) return y;
+  const size_t cnt = (size_t)a.c * a.h * a.w;
+  for (size_t i = 0; i < cnt; ++i) y.d[i] = a.d[i] + b.d[i];
+  keep(n->r, name, y, 0);
+  return y;
+}
+
+static ten cat(net *n, const char *name, const ten *ts, int cnt) {
+  int c = 0;
+  for (int i = 0; i < cnt; ++i) c += ts[i].c;
+  ten y = new_ten(n->r, c, ts[0].h, ts[0].w);
+  if (n->r->failed) return y;
+  size_t off = 0;
+  for (int i = 0; i < cnt; ++i) {
+    size_t sz = (size_t)ts[i].c * ts[i].h * ts[i].w;
+    memcpy(y.d + off, ts[i].d, sz * sizeof(float));
+    off += sz;
+  }
+  keep(n->r, name, y, 0);
+  return y;
+}
+
+/* Bottleneck inside C3k2: expansion=1.0, shortcut=True (model.py:71-73, 99): x + cv2(cv1(x)) */
+static ten bottleneck(net *n, const char *name, ten x) {
+  char s[256];
+  snprintf(s, sizeof s, "%s.cv1", name);
+  ten t = conv_block(n, s, x, x.c, 1, 1);
+  if (n->r->failed) return t;
+  snprintf(s, sizeof s, "%s.cv2", name);
+  t = conv_block(n, s, t, x.c, 3, 1);
+  if (n->r->failed) return t;
+  snprintf(s, sizeof s, "%s.add", name);
+  return add(n, s, x, t);
+}
+
+/* C3k2 (model.py:76-110): cv3(cat[bottlenecks(cv1(x)), cv2(x)]) */
+static ten c3k2(net *n, const char *name, ten x, int cout, int nb) {
+  char s[256];
+  const int hid = cout / 2;
+  snprintf(s, sizeof s, "%s.cv1", name);
+  ten p1 = conv_block(n, s, x, hid, 1, 1);
+  if (n->r->failed) return p1;
+  snprintf(s, sizeof s, "%s.cv2", name);
+  ten p2 = conv_block(n, s, x, hid, 1, 1);
+  if (n->r->failed) return p2;
+  for (int i = 0; i < nb; ++i) {
+    snprintf(s, sizeof s, "%s.bottlenecks.%d", name, i);
+    p1 = bottleneck(n, s, p1);
+    if (n->r->failed) return p1;
+  }
+  ten pair[2] = {p1, p2};
+  snprintf(s, sizeof s, "%s.cat", name);
+  ten c = cat(n, s, pair, 2);
+  if (n->r->failed) return c;
+  snprintf(s, sizeof s, "%s.cv3", name);
+  return conv_block(n, s, c, cout, 1, 1);
+}
+
+/* MaxPool2d(5,1,2): window clipped at the border == -inf padding (model.py:125) */
+static ten maxpool5(net *n, const char *name, ten x) {
+  ten y = new_ten(n->r, x.c, x.h, x.w);
+  if (n->r->failed) return y;
+#pragma omp parallel for schedule(static)
+  for (int c = 0; c < x.c; ++c)
+    for (int i = 0; i < x.h; ++i)
+      for (int j = 0; j < x.w; ++j) {
+        float m = -INFINITY;
+        for (int di = -2; di <= 2; ++di) {
+          int ii = i + di;
+          if (ii < 0 || ii >= x.h) continue;
+          for (int dj = -2; dj <= 2; ++dj) {
+            int jj = j + dj;
+            if (jj < 0 || jj >= x.w) continue;
+            float v = x.d[((size_t)c * x.h + ii) * x.w + jj];
+            if (v > m) m = v;
+          }
+        }
+        y.d[((size_t)c * x.h + i) * x.w + j] = m;
+      }
+  keep(n->r, name, y, 0);
+  return y;
+}
+
+/* SPPF_DLA (model.py:113-132) */
+static ten sppf(net *n, const char *name, ten x, int cout) {
+  char s[256];
+  snprintf(s, sizeof s, "%s.cv1", name);
+  ten t[4];
+  t[0] = conv_block(n, s, x, x.c / 2, 1, 1);
+  if (n->r->failed) return t[0];
+  for (int i = 1; i < 4; ++i) {
+    snprintf(s, sizeof s, "%s.pool%d", name, i);
+    t[i] = maxpool5(n, s, t[i - 1]);
+    if (n->r->failed) return t[i];
+  }
+  snprintf(s, sizeof s, "%s.cat", name);
+  ten c = cat(n, s, t, 4);
+  if (n->r->failed) return c;
+  snprintf(s, sizeof s, "%s.cv2", name);
+  return conv_block(n, s, c, cout, 1, 1);
+}
+
+/* Upsample nearest x2 (model.py:145-147): out[y][x] = in[y/2][x/2] */
+static ten up2(net *n, const char *name, ten x) {
+  ten y = new_ten(n->r, x.c, 2 * x.h, 2 * x.w);
+  if (n->r->failed) return y;
+  for (int c = 0; c < x.c; ++c)
+    for (int i = 0; i < y.h; ++i)
+      for (int j = 0; j < y.w; ++j)
+        y.d[((size_t)c * y.h + i) * y.w + j] = x.d[((size_t)c * x.h + i / 2) * x.w + j / 2];
+  keep(n->r, name, y, 0);
+  return y;
+}
+
+/* DetectionHead branch (model.py:289-303): ConvBlock3x3 -> ConvBlock3x3 -> Conv2d 1x1 (+bias) */
+static ten head_branch(net *n, const char *head, const char *branch, ten x, int nout, const char *out_name) {
+  char s[256];
+  snprintf(s, sizeof s, "%s.%s.0", head, branch);
+  ten t = conv_block(n, s, x, x.c, 3, 1);
+  if (n->r->failed) return t;
+  snprintf(s, sizeof s, "%s.%s.1", head, branch);
+  t = conv_block(n, s, t, x.c, 3, 1);
+  if (n->r->failed) return t;
+  snprintf(s, sizeof s, "%s.%s.2", head, branch);
+  const float *w = param(n, s, "weight", nout * x.c), *b = param(n, s, "bias", nout);
+  if (n->r->failed) return t;
+  ten y = conv2d(n->r, t, w, b, nout, 1, 1);
+  keep(n->r, out_name, y, 1);
+  return y;
+}
+
+uo_run *uo_forward(const uo_statedict *sd, const float *x, int H, int W, int num_classes, int base_channels,
+                   int lite_p2, int keep_all, int nthreads) {
+  if (g_slab_live) {
+    set_err("uo_forward: previous run not freed (one live run at a time)");
+    return NULL;
+  }
+  if (H % 16 || W % 16) {
+    set_err("H and W must be multiples of 16");
+    return NULL;
+  }
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+  (void)nthreads;
+#endif
+  /* activation volume: ~263 floats per input pixel for base_channels=32; be generous */
+  size_t need = (size_t)H * W * 420 * (size_t)(base_channels > 32 ? base_channels / 32 : 1) * sizeof(float) + (64u << 20);
+  if (need > g_slab_cap) {
+    free(g_slab);
+    g_slab = NULL;
+    if (posix_memalign((void **)&g_slab, 64, need)) {
+      g_slab_cap = 0;
+      set_err("oracle: cannot allocate %zu bytes", need);
+      return NULL;
+    }
+    memset(g_slab, 0, need);
+    g_slab_cap = need;
+  }
+  g_slab_used = 0;
+  g_slab_live = 1;
+
+  uo_run *r = calloc(1, sizeof *r);
+  r->keep_all = keep_all;
+  net n = {r, sd};
+  const int c1 = base_channels, c2 = c1 * 2, c3 = c1 * 4, c4 = c1 * 8;
+
+  ten in = new_ten(r, 3, H, W);
+  if (r->failed) return r;
+  memcpy(in.d, x, sizeof(float) * 3 * (size_t)H * W);
+
+  /* Backbone.forward (model.py:205-219) */
+  ten t = conv_block(&n, "backbone.stem", in, c1, 3, 2);
+  if (r->failed) return r;
+  t = conv_block(&n, "backbone.stage1_conv", t, c2, 3, 2);
+  if (r->failed) return r;
+  ten p2 = lite_p2 ? conv_block(&n, "backbone.stage1_block", t, c2, 3, 1) : c3k2(&n, "backbone.stage1_block", t, c2, 1);
+  if (r->failed) return r;
+  t = conv_block(&n, "backbone.stage2_conv", p2, c3, 3, 2);
+  if (r->failed) return r;
+  ten p3 = c3k2(&n, "backbone.stage2_c3k2", t, c3, 2);
+  if (r->failed) return r;
+  t = conv_block(&n, "backbone.stage3_conv", p3, c4, 3, 2);
+  if (r->failed) return r;
+  ten p4 = c3k2(&n, "backbone.stage3_c3k2", t, c4, 2);
+  if (r->failed) return r;
+  ten p4s = sppf(&n, "backbone.sppf", p4, c4);
+  if (r->failed) return r;
+
+  /* Neck.forward (model.py:252-269) */
+  t = conv_block(&n, "neck.lateral_p3", p4s, c3, 1, 1);
+  if (r->failed) return r;
+  ten pr[2];
+  pr[0] = up2(&n, "neck.up1", t);
+  pr[1] = p3;
+  if (r->failed) return r;
+  t = cat(&n, "neck.cat_fpn1", pr, 2);
+  if (r->failed) return r;
+  ten p3f = c3k2(&n, "neck.fpn_c3k2_1", t, c3, 1);
+  if (r->failed) return r;
+  t = conv_block(&n, "neck.lateral_p2", p3f, c2, 1, 1);
+  if (r->failed) return r;
+  pr[0] = up2(&n, "neck.up2", t);
+  pr[1] = p2;
+  if (r->failed) return r;
+  t = cat(&n, "neck.cat_fpn2", pr, 2);
+  if (r->failed) return r;
+  ten p2f = c3k2(&n, "neck.fpn_c3k2_2", t, c2, 1);
+  if (r->failed) return r;
+  pr[0] = conv_block(&n, "neck.down1", p2f, c2, 3, 2);
+  pr[1] = p3f;
+  if (r->failed) return r;
+  t = cat(&n, "neck.cat_pan1", pr, 2);
+  if (r->failed) return r;
+  ten p3o = c3k2(&n, "neck.pan_c3k2_1", t, c3, 1);
+  if (r->failed) return r;
+  pr[0] = conv_block(&n, "neck.down2", p3o, c3, 3, 2);
+  pr[1] = p4; /* PRE-SPPF p4 (model.py:254,267) */
+  if (r->failed) return r;
+  t = cat(&n, "neck.cat_pan2", pr, 2);
+  if (r->failed) return r;
+  ten p4o = c3k2(&n, "neck.pan_c3k2_2", t, c4, 1);
+  if (r->failed) return r;
+
+  /* heads (model.py:361-365) */
+  head_branch(&n, "head_p2", "cls_branch", p2f, num_classes, "p2_cls");
+  if (r->failed) return r;
+  head_branch(&n, "head_p2", "reg_branch", p2f, 4, "p2_reg");
+  if (r->failed) return r;
+  head_branch(&n, "head_p3", "cls_branch", p3o, num_classes, "p3_cls");
+  if (r->failed) return r;
+  head_branch(&n, "head_p3", "reg_branch", p3o, 4, "p3_reg");
+  if (r->failed) return r;
+  head_branch(&n, "head_p4", "cls_branch", p4o, num_classes, "p4_cls");
+  if (r->failed) return r;
+  head_branch(&n, "head_p4", "reg_branch", p4o, 4, "p4_reg");
+  return r;
+}
+
+const float *uo_run_get(const uo_run *r, const char *name, int *c, int *h, int *w) {
+  if (!r || r->failed) return NULL;
+  for (int i = 0; i < r->n; ++i)
+    if (!strcmp(r->names[i], name)) {
+      if (c) *c = r->t[i].c;
+      if (h) *h = r->t[i].h;
+      if (w) *w = r->t[i].w;
+      return r->t[i].d;
+    }
+  return NULL;
+}
+int uo_run_count(const uo_run *r) { return r && !r->failed ? r->n : -1; }
+const char *uo_run_name(const uo_run *r, int i) { return r->names[i]; }
+void uo_run_free(uo_run *r) {
+  if (!r) return;
+  for (int i = 0; i < r->n; ++i) free(r->names[i]);
+  free(r);
+  g_slab_live = 0;
+  g_slab_used = 0;
+}
