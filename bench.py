@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec (+ p50/p99 latency) of the fused detector path, 640x640 batch-1, on N MI355X.
+
+    python bench.py --gpus 1 --steps 2000 --warmup 200
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE frame through the whole hot path on one GPU: stem (reads the fp32 NCHW frame already resident
+in HBM) -> 50 fused implicit-GEMM conv launches + SPPF pool (one hipGraph replay) -> fused decode/sort/NMS
+kernel -> detections left in HBM. Weak scaling: every rank processes K frames of its own (frames shard
+embarrassingly); the only collective is the RCCL all-gather of the fixed-size detection
+slots, issued every GATHER_EVERY frames on the rank's stream. value = N*K / max-over-ranks(time).
+
+Workload = BASELINE.json configs[1]: unina-yolo-dla-m (graph A), fp16, batch 1, 640x640, NMS on GPU; synthetic
+frames (N(0,1), seeds 1234..), seeded synthetic weights (no checkpoints exist for the reference).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+FLOPS_PER_FRAME = {640: 35_664_691_200, 1280: 142_658_764_800}   # SURVEY.md section 8d (2 x MACs, conv only)
+PEAK_TFLOPS = {"f16": 2500.0}                                     # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+N_FRAMES = 16            # distinct synthetic frames cycled through
+IN_FLIGHT = 2            # engine handles per GPU = frames in flight
+GATHER_EVERY = 16        # frames per RCCL all-gather of detection slots
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--latency-frames", type=int, default=300)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import unina_yolo_dla_amd as u
+    from unina_yolo_dla_amd import export
+    from unina_yolo_dla_amd.engine import Engine, MAX_DETECTIONS
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    S = args.size
+
+    # ---- engine(s): seeded synthetic weights -> engine file -> IN_FLIGHT handles on this GPU ----
+    g = u.graph.Graph(in_h=S, in_w=S)
+    sd = u.synth.make_state_dict(7, g)
+    fd, path = tempfile.mkstemp(suffix=f".rank{rank}.une")
+    os.close(fd)
+    export.export_engine(sd, path, g)
+    engines = [Engine(path, device=local) for _ in range(IN_FLIGHT)]
+    os.unlink(path)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(IN_FLIGHT)]
+    frames = [torch.from_numpy(u.rng.frame(1234 + i + 100 * rank, S, S)).to(dev) for i in range(N_FRAMES)]
+    slot_words = 8 + 8 * MAX_DETECTIONS
+    results = torch.zeros((GATHER_EVERY, slot_words), dtype=torch.int32, device=dev)
+    gathered = torch.zeros((world, GATHER_EVERY, slot_words), dtype=torch.int32, device=dev) if world > 1 else None
+    conf = 0.5 if S == 640 else 0.6
+    torch.cuda.synchronize()
+
+    def run(n_frames):
+        """n_frames frames, IN_FLIGHT of them overlapping on separate streams; detections gathered with RCCL."""
+        for i in range(n_frames):
+            k = i % IN_FLIGHT
+            slot = i % GATHER_EVERY
+            with torch.cuda.stream(streams[k]):
+                engines[k].infer_async(frames[i % N_FRAMES], conf, 0.45, 0.1, out=results[slot], stream=streams[k])
+            if world > 1 and slot == GATHER_EVERY - 1:
+                cur = torch.cuda.current_stream()
+                for s in streams:
+                    cur.wait_stream(s)
+                dist.all_gather_into_tensor(gathered.view(world, -1), results.view(-1))
+                for s in streams:
+                    s.wait_stream(cur)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fps = world * args.steps / dt
+    n_det = int(results[0, 0].item())
+
+    line = None
+    if rank == 0:
+        # ---- per-frame latency: submit -> detections on the host, one frame at a time (no overlap) ----
+        lat = []
+        e0 = engines[0]
+        for i in range(20 + args.latency_frames):
+            f = frames[i % N_FRAMES]
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            e0.infer(f, conf, 0.45, 0.1)
+            if i >= 20:
+                lat.append((time.perf_counter() - a) * 1e3)
+        lat = np.array(lat)
+
+        # ---- roofline of the dominant kernel: live HIP-event timing of every op on the launch stream ----
+        ops = e0.profile_ops(iters=20)
+        by_kernel = {}
+        for o in ops:
+            k = by_kernel.setdefault(o["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            k["ms"] += o["ms"]; k["flops"] += o["flops"]; k["bytes"] += o["bytes"]; k["launches"] += 1
+        dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
+        achieved_tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        total_ms = sum(o["ms"] for o in ops)
+        roofline = {
+            "bound": "mfma", "kernel": dom_name, "launches_per_frame": dom["launches"],
+            "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 3),
+            "flops_per_launch": dom["flops"] / dom["launches"],
+            "achieved": round(achieved_tf, 2), "peak": PEAK_TFLOPS["f16"], "unit": "TFLOP/s",
+            "frac": round(achieved_tf / PEAK_TFLOPS["f16"], 4), "traffic": None,
+            "algorithmic_gbs": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
+            "sum_of_ops_ms": round(total_ms, 4),
+            "whole_frame_tflops": round(fps / world * FLOPS_PER_FRAME.get(S, 0) / 1e12, 2),
+        }
+
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(u, sd, S, conf, args.cpu_seconds)
+
+        line = {
+            "metric": "frames/sec, 640x640 batch-1 (p99 latency alongside)" if S == 640 else f"frames/sec, {S}x{S} batch-1",
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"unina-yolo-dla-m graph A fp16, batch=1, {S}x{S}, NMS on-GPU (BASELINE configs[1])",
+                       "frames_in_flight_per_gpu": IN_FLIGHT, "parallelism": f"replica x{world}, RCCL all-gather of detection slots every {GATHER_EVERY} frames" if world > 1 else "1 GPU",
+                       "thresholds": {"conf": conf, "iou": 0.45, "conformal_q": 0.1}, "detections_last_frame": n_det},
+            "latency_ms": {"p50": round(float(np.percentile(lat, 50)), 4), "p99": round(float(np.percentile(lat, 99)), 4),
+                           "mean": round(float(lat.mean()), 4), "frames": len(lat), "mode": "serial, submit->detections on host"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if cpu:
+            line["gpu_over_cpu"] = round(fps / world / cpu["value"], 1)
+    for e in engines:
+        e.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if line is not None:
+        print(json.dumps(line))
+
+
+def cpu_baseline(u, sd, S, conf, budget_s):
+    """The CPU oracle (a port of the reference's fp32 forward + greedy NMS) timed on this box's host cores, on a
+    bounded sample of the same workload. Checker code, timed here only as the reported baseline."""
+    from oracle import oracle
+    oracle.build()
+    osd = oracle.StateDict(sd)
+    cores = min(os.cpu_count() or 1, 64)
+    x = u.rng.frame(1234, S, S)
+
+    def one():
+        o = oracle.forward(osd, x, nthreads=cores)
+        oracle.postprocess([o[n] for n in u.graph.OUTPUT_NAMES], conf, 0.45, 0.1)
+
+    one(); one()                                       # warm-up (slab allocation, thread pool)
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end and len(times) < 50:
+        a = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - a)
+    osd.close()
+    times = np.array(times)
+    return {"value": round(1.0 / float(times.mean()), 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} frames of {S}x{S} (same weights/frame), fp32 forward + decode/NMS, after 2 warm-ups",
+            "ms_per_frame": round(1e3 * float(times.mean()), 2), "p99_ms": round(1e3 * float(np.percentile(times, 99)), 2)}
+
+
+if __name__ == "__main__":
+    main()

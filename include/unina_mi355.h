@@ -1,0 +1,163 @@
+/*
+ * unina_mi355.h -- C ABI of libunina_mi355.so, the MI355X (gfx950) engine for the
+ * UNINA-YOLO-DLA detector hot path: forward graph + decode/NMS.
+ *
+ * This is the drop-in boundary. Every entry point names the reference interface it
+ * replaces (paths relative to /root/reference/unina_yolo_dla/):
+ *
+ *   engine object ......... class TensorRTEngine          ros2_ws/src/perception/src/perception_node.cpp:223-351
+ *   post-process C API .... extern "C" block              ros2_ws/src/perception/include/gpu_postprocess.h:36-84
+ *   detection record ...... struct GpuDetection           ros2_ws/src/perception/include/gpu_postprocess.h:27-33
+ *   tensor names .......... "images", "p2_cls".."p4_reg"  perception_node.cpp:612-618, model.py:382-383
+ *
+ * Conventions: plain C, no exceptions cross the boundary, 0 == success everywhere.
+ * Device pointers are ordinary HIP device pointers; streams are hipStream_t.
+ * A handle may be used by one thread at a time; distinct handles (e.g. one per GPU,
+ * or two on one GPU to keep two frames in flight) are fully independent.
+ */
+#ifndef UNINA_MI355_H
+#define UNINA_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef UNINA_NO_HIP_HEADERS /* for pure-C consumers / ctypes documentation builds */
+typedef struct ihipStream_t *hipStream_t;
+typedef int hipError_t;
+#else
+#include <hip/hip_runtime_api.h>
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAX_DETECTIONS 1024 /* gpu_postprocess.h:24 */
+
+/* 32-byte record, identical layout to the reference (gpu_postprocess.h:27-33).
+ * Coordinates are xyxy in input-tensor pixels. */
+#if defined(__cplusplus)
+struct alignas(32) GpuDetection {
+#else
+struct GpuDetection {
+#endif
+  float x1, y1, x2, y2;
+  float confidence;
+  int class_id;
+  int valid; /* 1 = kept */
+  int _pad;
+};
+typedef struct GpuDetection GpuDetection;
+
+/* ------------------------------------------------------------------ error codes */
+enum {
+  UNINA_OK = 0,
+  UNINA_ERR_IO = 1,          /* engine file unreadable                    */
+  UNINA_ERR_FORMAT = 2,      /* bad magic / version / table               */
+  UNINA_ERR_HIP = 3,         /* a HIP call failed (see unina_last_error)  */
+  UNINA_ERR_ARG = 4,         /* null / misaligned / unknown tensor name   */
+  UNINA_ERR_STATE = 5,       /* e.g. "images" not bound before enqueue    */
+  UNINA_ERR_UNSUPPORTED = 6  /* layer shape the kernels do not cover      */
+};
+
+typedef struct unina_engine unina_engine_t;
+
+/* ------------------------------------------------------------------ engine (TensorRTEngine role) */
+
+/* Replaces TensorRTEngine::load(engine_path, logger, dla_core) (perception_node.cpp:228-259).
+ * `path` is an engine file written by unina-yolo-dla_amd/export.py (folded weights + op table);
+ * `device_id` plays the role of dla_core: which accelerator the handle lives on. */
+int unina_load_engine(const char *path, int device_id, unina_engine_t **out);
+
+/* Replaces TensorRTEngine::unload() / the destructor (perception_node.cpp:226,261-266). NULL is a no-op. */
+void unina_unload_engine(unina_engine_t *e);
+
+/* Replaces TensorRTEngine::getInputDimensions(w,h) (perception_node.cpp:297-325); also reports num_classes,
+ * which the node hard-codes to 4 (perception_node.cpp:630-639). Any out pointer may be NULL. */
+int unina_engine_input_dims(const unina_engine_t *e, int *width, int *height, int *num_classes);
+
+/* Replaces setInputTensorAddress / setOutputTensorAddress (perception_node.cpp:268-276).
+ * Names: "images" fp32 [1,3,H,W]; "p2_cls","p2_reg","p3_cls","p3_reg","p4_cls","p4_reg" fp32 planar
+ * [1,C,H/s,W/s], s = 4/8/16. Pointers must be 16-byte aligned device pointers owned by the caller.
+ * Outputs left unbound are written to engine-owned buffers (see unina_tensor_address). */
+int unina_set_tensor_address(unina_engine_t *e, const char *name, void *device_ptr);
+
+/* Current device address + element count of a named tensor (engine-owned default or the bound one). */
+int unina_tensor_address(const unina_engine_t *e, const char *name, void **device_ptr, size_t *num_floats);
+
+/* Replaces TensorRTEngine::enqueueV3(stream) (perception_node.cpp:278-282, call site :621):
+ * runs the forward graph asynchronously on `stream`, producing the six raw head tensors. */
+int unina_enqueue(unina_engine_t *e, hipStream_t stream);
+
+/* The fused path the north star names: forward + sigmoid/argmax/threshold + TLBR decode + conformal dilation
+ * + sort + class-aware NMS + compaction, all on the GPU, no host round-trip in between. It replaces
+ * perception_node.cpp:612-656 (bind, enqueueV3, reset_detection_counter, 3 x decode_yolo_head,
+ * get_detection_count, run_gpu_nms, copy_valid_detections_to_host).
+ *
+ *   d_images_nchw : device, fp32 [1,3,H,W] (same as binding "images"); NULL = keep the current binding
+ *   out           : HOST buffer for up to MAX_DETECTIONS records (sorted by confidence, valid=1)
+ *   out_count     : HOST int
+ * Synchronous: returns after the records are in `out` (one stream sync, one D2H of <= 32 KiB). */
+int unina_infer(unina_engine_t *e, const float *d_images_nchw, float conf_threshold, float iou_threshold,
+                float conformal_q, GpuDetection *out, int *out_count, hipStream_t stream);
+
+/* Asynchronous variant: results stay on the device (d_out: MAX_DETECTIONS records, d_out_count: one int);
+ * nothing is synchronised. Used to pipeline frames and to feed the RCCL gather without touching the host. */
+int unina_infer_async(unina_engine_t *e, const float *d_images_nchw, float conf_threshold, float iou_threshold,
+                      float conformal_q, GpuDetection *d_out, int *d_out_count, hipStream_t stream);
+
+/* Decode + NMS only, on head tensors already on the device (the six bound/owned outputs). */
+int unina_postprocess_async(unina_engine_t *e, float conf_threshold, float iou_threshold, float conformal_q,
+                            GpuDetection *d_out, int *d_out_count, hipStream_t stream);
+
+/* Error text of the last failing call on this handle (never NULL). With e == NULL: last load failure. */
+const char *unina_last_error(const unina_engine_t *e);
+
+/* ------------------------------------------------------------------ introspection / measurement */
+
+typedef struct unina_op_info {
+  char name[96];      /* reference module path(s), e.g. "head_p3.cls_branch.0+head_p3.reg_branch.0" */
+  char kernel[64];    /* device kernel (template instantiation) that executes it */
+  int kind;           /* 1 conv, 2 stem, 3 sppf pool, 4 upsample */
+  int m, n, k;        /* implicit-GEMM shape (pixels, out channels, taps*in channels); 0 for non-conv */
+  double flops;       /* 2*m*n*k */
+  double bytes;       /* algorithmic bytes: inputs once + weights once + outputs once */
+  int grid, block;    /* launch geometry */
+} unina_op_info;
+
+int unina_op_count(const unina_engine_t *e);
+int unina_get_op_info(const unina_engine_t *e, int index, unina_op_info *info);
+
+/* Times every op of the forward with HIP events on `stream` (eager launches, `iters` repetitions each
+ * after one warm-up); ms_per_op[i] = mean milliseconds of op i. Used by bench.py's roofline leg. */
+int unina_profile_ops(unina_engine_t *e, int iters, float *ms_per_op, hipStream_t stream);
+
+/* Copies an internal activation buffer to the host as fp32 NCHW ([C,H,W]) -- parity tests only.
+ * `name` is a buffer name from the engine file (e.g. "p3_fused"); returns UNINA_ERR_ARG if unknown. */
+int unina_debug_read_buffer(unina_engine_t *e, const char *name, float *host_out, size_t capacity_floats,
+                            int *c, int *h, int *w);
+
+/* Library/build identification: "unina_mi355 <version> gfx950". */
+const char *unina_version(void);
+
+/* ------------------------------------------------------------------ post-process C API (gpu_postprocess.h:42-80)
+ * Same seven symbols, same argument meaning, hipError_t/hipStream_t in place of cudaError_t/cudaStream_t
+ * (ABI-identical: int + pointer), so perception_node.cpp:627-656 recompiles unchanged under HIP.
+ * Semantics are the deterministic ones of SURVEY.md App. D (the reference kernel's atomic append order and
+ * racy NMS are not reproducible by construction). One process-global workspace, like the reference
+ * (gpu_postprocess.cu:56-57); the engine handles above each own a private one instead. */
+hipError_t init_postprocess_resources(void);
+hipError_t cleanup_postprocess_resources(void);
+hipError_t reset_detection_counter(hipStream_t stream);
+hipError_t get_detection_count(int *count, hipStream_t stream);
+hipError_t decode_yolo_head(const float *d_cls, const float *d_reg, GpuDetection *d_detections, int grid_w,
+                            int grid_h, int stride, int num_classes, float conf_threshold, float conformal_q,
+                            hipStream_t stream);
+hipError_t run_gpu_nms(GpuDetection *d_detections, int num_detections, float iou_threshold, hipStream_t stream);
+hipError_t copy_valid_detections_to_host(const GpuDetection *d_detections, GpuDetection *h_detections,
+                                         int num_detections, int *out_valid_count, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNINA_MI355_H */

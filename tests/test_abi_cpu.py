@@ -1,0 +1,107 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every symbol the header declares,
+fails loudly without a GPU, and the exporter writes what the loader expects. No compute on the device."""
+import ctypes as C
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    from unina_yolo_dla_amd import build, engine
+    build.build_native()
+    return engine.load_library()
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "unina_mi355.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{]*\)\s*;", text)
+    return sorted(set(n for n in names if n.startswith("unina_") or n in (
+        "init_postprocess_resources", "cleanup_postprocess_resources", "reset_detection_counter",
+        "get_detection_count", "decode_yolo_head", "run_gpu_nms", "copy_valid_detections_to_host")))
+
+
+def test_header_and_library_agree(lib):
+    from unina_yolo_dla_amd import engine
+    declared = _declared_functions()
+    assert len(declared) >= 22
+    assert sorted(engine.ABI_SYMBOLS) == declared          # the Python binding list mirrors the header
+    for name in declared:
+        assert hasattr(lib, name), f"libunina_mi355.so does not export {name}"
+    assert b"gfx950" in lib.unina_version()
+
+
+def test_reference_postprocess_symbols_present(lib):
+    # the seven entry points of gpu_postprocess.h:42-80, by the reference's exact names
+    for name in ("init_postprocess_resources", "cleanup_postprocess_resources", "reset_detection_counter",
+                 "get_detection_count", "decode_yolo_head", "run_gpu_nms", "copy_valid_detections_to_host"):
+        assert hasattr(lib, name)
+
+
+def test_detection_record_layout(pkg):
+    from unina_yolo_dla_amd import engine
+    d = engine.DET_DTYPE
+    assert d.itemsize == 32                                  # gpu_postprocess.h:27-33, __align__(32)
+    assert [d.fields[n][1] for n in ("x1", "y1", "x2", "y2", "confidence", "class_id", "valid", "_pad")] == \
+        [0, 4, 8, 12, 16, 20, 24, 28]
+
+
+def test_load_errors_are_loud_not_fatal(lib, tmp_path):
+    h = C.c_void_p()
+    assert lib.unina_load_engine(b"/nonexistent/engine.une", 0, C.byref(h)) == 1          # UNINA_ERR_IO
+    assert b"cannot open" in lib.unina_last_error(None)
+    bad = tmp_path / "bad.une"
+    bad.write_bytes(b"NOTANENG" + b"\0" * 200)
+    assert lib.unina_load_engine(str(bad).encode(), 0, C.byref(h)) == 2                     # UNINA_ERR_FORMAT
+    assert b"magic" in lib.unina_last_error(None)
+    assert not h.value
+    lib.unina_unload_engine(None)                                                            # NULL is a no-op
+
+
+def test_engine_wrapper_refuses_without_gpu(pkg, sd7, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from unina_yolo_dla_amd import engine, export
+    path = str(tmp_path / "a.une")
+    export.export_engine(sd7, path)
+    with pytest.raises(engine.EngineError):
+        engine.Engine(path)
+
+
+def test_export_tables(pkg, sd7, tmp_path):
+    from unina_yolo_dla_amd import export
+    b = export.EngineBuilder(sd7)
+    assert len(b.ops) == 52                                   # 67 reference convs -> 50 conv launches + stem + pool
+    convs = [s.module for o in b.ops for s in o.segs if o.kind in (export.OP_CONV, export.OP_STEM)]
+    assert sorted(convs) == sorted(n.name for n in pkg.graph.Graph().convs())   # every conv exactly once
+    path = str(tmp_path / "a.une")
+    b.save(path)
+    h = export.read_engine_header(path)
+    assert (h["in_h"], h["in_w"], h["num_classes"], h["n_ops"]) == (640, 640, 4, 52)
+    assert h["macs"] == 17_832_345_600
+    assert os.path.getsize(path) == 128 + 64 * h["n_buffers"] + 256 * h["n_ops"] + h["blob_bytes"]
+
+
+def test_bn_folding_matches_unfolded_math(pkg, sd7):
+    from unina_yolo_dla_amd import export
+    w, b = export.fold_bn(sd7, "backbone.stage1_conv")
+    x = np.random.default_rng(0).standard_normal((64,)).astype(np.float64)        # conv output for one pixel
+    g, beta = sd7["backbone.stage1_conv.bn.weight"], sd7["backbone.stage1_conv.bn.bias"]
+    mu, var = sd7["backbone.stage1_conv.bn.running_mean"], sd7["backbone.stage1_conv.bn.running_var"]
+    unfolded = (x - mu) / np.sqrt(var.astype(np.float64) + 1e-5) * g + beta                # model.py:46-50
+    scale = w[:, 0, 0, 0] / sd7["backbone.stage1_conv.conv.weight"][:, 0, 0, 0].astype(np.float64)
+    np.testing.assert_allclose(x * scale + b, unfolded, rtol=1e-12, atol=1e-12)
+
+
+def test_export_rejects_unsupported_width(pkg):
+    from unina_yolo_dla_amd import export
+    g = pkg.graph.Graph(base_channels=16)
+    with pytest.raises(NotImplementedError):
+        export.EngineBuilder(pkg.synth.make_state_dict(7, g), g)

@@ -1,0 +1,248 @@
+"""GPU parity tests proper (-m gpu): the HIP engine, called through the C ABI, against the CPU oracle and the
+committed reference fixtures. Tolerances are BASELINE.json's: fp16 path, matched boxes IoU >= 0.999 and
+|score delta| < 1e-3 against the fp32 oracle; post-process on identical inputs is exact."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from detcmp import compare
+
+pytestmark = pytest.mark.gpu
+
+# head-tensor tolerance of the fp16-activation path against fp32 (logits have std 2.0, regs std 0.5):
+HEAD_ATOL = 2e-2
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def eng640(pkg, sd7, torch_cuda):
+    from unina_yolo_dla_amd.engine import Engine
+    e = Engine.from_state_dict(sd7)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng64(pkg, sd7, torch_cuda):
+    from unina_yolo_dla_amd.engine import Engine
+    e = Engine.from_state_dict(sd7, pkg.graph.Graph(in_h=64, in_w=64))
+    yield e
+    e.close()
+
+
+def _frame(pkg, torch, seed, s):
+    return torch.from_numpy(pkg.rng.frame(seed, s, s)).cuda()
+
+
+def test_library_is_the_hip_engine(eng64):
+    assert b"gfx950" in eng64.L.unina_version()
+    assert len(eng64.op_infos()) == 52
+
+
+def test_mini64_every_buffer_vs_oracle(pkg, eng64, oracle_mod, oracle_sd7, torch_cuda):
+    x = pkg.rng.frame(1234, 64, 64)
+    heads = eng64.forward(torch_cuda.from_numpy(x).cuda())
+    ref = oracle_mod.forward(oracle_sd7, x, keep_all=True)
+    for name in pkg.graph.OUTPUT_NAMES:
+        np.testing.assert_allclose(heads[name], ref[name], atol=HEAD_ATOL, rtol=0, err_msg=name)
+    # intermediate buffers (engine buffer name -> oracle tensor; concat buffers compare against the oracle's cat)
+    pairs = {
+        "backbone.stem": "backbone.stem", "backbone.stage1_conv": "backbone.stage1_conv",
+        "backbone.stage1_block.cat": "backbone.stage1_block.cat", "backbone.stage2_conv": "backbone.stage2_conv",
+        "backbone.stage3_conv": "backbone.stage3_conv", "backbone.sppf.cat": "backbone.sppf.cat",
+        "backbone.sppf": "backbone.sppf.cv2", "neck.cat_fpn1": "neck.cat_fpn1", "neck.cat_fpn2": "neck.cat_fpn2",
+        "neck.cat_pan1": "neck.cat_pan1", "neck.cat_pan2": "neck.cat_pan2", "p2_fused": "neck.fpn_c3k2_2.cv3",
+        "p3_out": "neck.pan_c3k2_1.cv3", "p4_out": "neck.pan_c3k2_2.cv3",
+    }
+    for bname, oname in pairs.items():
+        got = eng64.read_buffer(bname)
+        want = ref[oname]
+        assert got.shape == want.shape, (bname, got.shape, want.shape)
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(got, want, atol=1e-2 * scale, rtol=0, err_msg=bname)
+
+
+def test_sppf_pool_is_exact(pkg, eng64):
+    """max is exact in any precision: y1,y2,y3 must equal the 5/9/13 clipped-window maxima of the fp16 x bit for bit."""
+    cat = eng64.read_buffer("backbone.sppf.cat")          # [4*hid, h, w] = [x | y1 | y2 | y3]
+    hid = cat.shape[0] // 4
+    x = cat[:hid]
+    def pool(t, r):
+        out = np.full_like(t, -np.inf)
+        h, w = t.shape[1:]
+        for dy in range(-r, r + 1):
+            for dx in range(-r, r + 1):
+                ys, ye = max(0, -dy), min(h, h - dy)
+                xs, xe = max(0, -dx), min(w, w - dx)
+                out[:, ys:ye, xs:xe] = np.maximum(out[:, ys:ye, xs:xe], t[:, ys + dy:ye + dy, xs + dx:xe + dx])
+        return out
+    for i, r in enumerate((2, 4, 6), start=1):
+        assert np.array_equal(cat[i * hid:(i + 1) * hid], pool(x, r)), f"y{i}"
+
+
+def test_640_heads_vs_reference_fixture(pkg, eng640, torch_cuda):
+    gold = load_golden("frame640_seed1234.npz")
+    heads = eng640.forward(_frame(pkg, torch_cuda, 1234, 640))
+    for name in pkg.graph.OUTPUT_NAMES:
+        ref = gold[f"head/{name}"]
+        err = np.abs(heads[name] - ref)
+        assert err.max() < HEAD_ATOL, (name, float(err.max()))
+        assert err.mean() < HEAD_ATOL / 10, (name, float(err.mean()))
+
+
+@pytest.mark.parametrize("conf,iou,q", [(0.5, 0.45, 0.1), (0.5, 0.45, 0.0), (0.3, 0.2, 0.0), (0.2, 0.6, 0.25),
+                                        (0.0, 0.45, 0.1), (0.9999999, 0.45, 0.1)])
+def test_postprocess_exact_on_reference_heads(pkg, eng640, oracle_mod, torch_cuda, conf, iou, q):
+    """Identical inputs (the reference's own head tensors) -> the fused kernel must reproduce the oracle
+    (engine semantics) record for record: same count, same order, bit-identical boxes and classes."""
+    gold = load_golden("frame640_seed1234.npz")
+    heads = [gold[f"head/{n}"] for n in pkg.graph.OUTPUT_NAMES]
+    for n, h in zip(pkg.graph.OUTPUT_NAMES, heads):
+        eng640.outputs[n].copy_(torch_cuda.from_numpy(h)[None])
+    got = eng640.postprocess(conf, iou, q)
+    want, ncand = oracle_mod.postprocess(heads, conf, iou, q)
+    assert len(got) == len(want), (len(got), len(want), ncand)
+    if len(want) == 0:
+        return
+    # GPU expf vs glibc expf may differ by an ulp: confidences within 2e-7; order ties can then swap neighbours,
+    # so compare as sets keyed by the (exact) box
+    np.testing.assert_allclose(np.sort(got["confidence"]), np.sort(want["confidence"]), atol=2e-7, rtol=0)
+    ka = np.lexsort((got["y2"], got["x2"], got["y1"], got["x1"], got["class_id"]))
+    kb = np.lexsort((want["y2"], want["x2"], want["y1"], want["x1"], want["class_id"]))
+    for f in ("x1", "y1", "x2", "y2", "class_id"):
+        assert np.array_equal(got[f][ka], want[f][kb]), f
+    assert np.all(np.diff(got["confidence"]) <= 0)
+    assert np.all(got["valid"] == 1) and np.all(got["_pad"] == 0)
+
+
+def test_postprocess_heavy_overlap_nms(pkg, eng640, oracle_mod, torch_cuda):
+    """Synthetic heads where most candidates overlap (big boxes, two classes): exercises the suppression masks."""
+    rng = np.random.default_rng(5)
+    heads = []
+    for s in (160, 80, 40):
+        cls = rng.normal(-4.0, 1.0, (4, s, s)).astype(np.float32)
+        hot = rng.random((s, s)) < (300.0 / (3 * s * s))
+        cls[rng.integers(0, 2, (s, s)), np.arange(s)[:, None], np.arange(s)[None, :]] += np.where(hot, 7.0, 0.0).astype(np.float32)
+        reg = rng.uniform(4.0, 9.0, (4, s, s)).astype(np.float32)
+        heads += [cls, reg]
+    for n, h in zip(pkg.graph.OUTPUT_NAMES, heads):
+        eng640.outputs[n].copy_(torch_cuda.from_numpy(h)[None])
+    got = eng640.postprocess(0.5, 0.45, 0.1)
+    want, ncand = oracle_mod.postprocess(heads, 0.5, 0.45, 0.1)
+    assert ncand > 150 and len(want) < ncand * 0.8           # the NMS really suppresses
+    assert len(got) == len(want)
+    ka = np.lexsort((got["y2"], got["x2"], got["y1"], got["x1"], got["class_id"]))
+    kb = np.lexsort((want["y2"], want["x2"], want["y1"], want["x1"], want["class_id"]))
+    for f in ("x1", "y1", "x2", "y2", "class_id"):
+        assert np.array_equal(got[f][ka], want[f][kb]), f
+
+
+@pytest.mark.parametrize("q", [0.1, 0.0])
+def test_infer_end_to_end_vs_oracle(pkg, eng640, oracle_mod, oracle_sd7, torch_cuda, q):
+    """The north-star check: fused forward+decode+NMS vs the fp32 oracle on the same frame."""
+    for seed in (1234, 1235):
+        x = pkg.rng.frame(seed, 640, 640)
+        got = eng640.infer(torch_cuda.from_numpy(x).cuda(), 0.5, 0.45, q)
+        o = oracle_mod.forward(oracle_sd7, x)
+        want, _ = oracle_mod.postprocess([o[n] for n in pkg.graph.OUTPUT_NAMES], 0.5, 0.45, q)
+        stats = compare(got, want, 0.5, min_iou=0.999, score_tol=1e-3)
+        assert stats["matched"] >= 0.97 * len(want), stats
+
+
+def test_infer_matches_reference_fixture_detections(pkg, eng640, torch_cuda):
+    """Against detections produced by the reference's own model.py + postprocess.hpp (committed fixture)."""
+    gold = load_golden("frame640_seed1234.npz")
+    x = _frame(pkg, torch_cuda, 1234, 640)
+    for q in (0.1, 0.0):
+        got = eng640.infer(x, 0.5, 0.45, q)
+        ref = gold[f"ref_dets_q{q}"]
+        want = np.zeros(len(ref), dtype=got.dtype)
+        for f in ref.dtype.names:
+            want[f] = ref[f]
+        stats = compare(got, want, 0.5, min_iou=0.999, score_tol=1e-3)
+        assert stats["matched"] >= 0.97 * len(want), stats
+
+
+def test_determinism_and_rebinding(pkg, eng640, torch_cuda):
+    xs = [_frame(pkg, torch_cuda, s, 640) for s in (1, 2)]
+    first = [eng640.infer(x).tobytes() for x in xs]
+    for _ in range(5):
+        for x, f in zip(xs, first):
+            assert eng640.infer(x).tobytes() == f            # bit-identical across replays and input re-binding
+    assert first[0] != first[1]
+
+
+def test_async_result_layout(pkg, eng640, torch_cuda):
+    x = _frame(pkg, torch_cuda, 1234, 640)
+    sync = eng640.infer(x)
+    buf = eng640.infer_async(x)
+    torch_cuda.cuda.synchronize()
+    assert eng640.unpack(buf).tobytes() == sync.tobytes()
+
+
+def test_stepwise_reference_api(pkg, eng640, oracle_mod, torch_cuda):
+    """perception_node.cpp:627-656 call sequence through the seven gpu_postprocess.h symbols."""
+    import ctypes as C
+    L = eng640.L
+    gold = load_golden("frame640_seed1234.npz")
+    heads = [gold[f"head/{n}"] for n in pkg.graph.OUTPUT_NAMES]
+    dev = [torch_cuda.from_numpy(h).cuda() for h in heads]
+    dets = torch_cuda.zeros(1024 * 8, dtype=torch_cuda.int32, device="cuda")
+    assert L.init_postprocess_resources() == 0
+    try:
+        stream = torch_cuda.cuda.current_stream().cuda_stream
+        assert L.reset_detection_counter(stream) == 0
+        for i, s in enumerate((4, 8, 16)):
+            c, r = dev[2 * i], dev[2 * i + 1]
+            assert L.decode_yolo_head(c.data_ptr(), r.data_ptr(), dets.data_ptr(), c.shape[2], c.shape[1], s, 4,
+                                      0.5, 0.1, stream) == 0
+        n = C.c_int(-1)
+        assert L.get_detection_count(C.byref(n), stream) == 0
+        torch_cuda.cuda.synchronize()
+        want, ncand = oracle_mod.postprocess(heads, 0.5, 0.45, 0.1)
+        assert n.value == ncand
+        n = min(n.value, 1024)
+        assert L.run_gpu_nms(dets.data_ptr(), n, 0.45, stream) == 0
+        from unina_yolo_dla_amd.engine import DET_DTYPE
+        host = np.zeros(1024, dtype=DET_DTYPE)
+        valid = C.c_int(-1)
+        assert L.copy_valid_detections_to_host(dets.data_ptr(), host.ctypes.data, n, C.byref(valid), stream) == 0
+        got = host[:valid.value]
+        assert len(got) == len(want)
+        ka = np.lexsort((got["y2"], got["x2"], got["y1"], got["x1"], got["class_id"]))
+        kb = np.lexsort((want["y2"], want["x2"], want["y1"], want["x1"], want["class_id"]))
+        for f in ("x1", "y1", "x2", "y2", "class_id"):
+            assert np.array_equal(got[f][ka], want[f][kb]), f
+    finally:
+        L.cleanup_postprocess_resources()
+
+
+def test_1280_p2_head_config(pkg, sd7, torch_cuda):
+    """BASELINE config 5: 1280x1280 (P2 grid 320x320). Checked against the reference's sampled head values."""
+    from unina_yolo_dla_amd.engine import Engine
+    gold = load_golden("frame1280_seed1234.npz")
+    e = Engine.from_state_dict(sd7, pkg.graph.Graph(in_h=1280, in_w=1280))
+    try:
+        x = _frame(pkg, torch_cuda, 1234, 1280)
+        heads = e.forward(x)
+        for name in pkg.graph.OUTPUT_NAMES:
+            flat = heads[name].reshape(-1)
+            np.testing.assert_allclose(flat[gold[f"idx/{name}"]], gold[f"vals/{name}"], atol=HEAD_ATOL, rtol=0, err_msg=name)
+            assert abs(float(flat.astype(np.float64).mean()) - gold[f"stats/{name}"][0]) < 2e-3
+        np.testing.assert_allclose(heads["p4_cls"], gold["head/p4_cls"], atol=HEAD_ATOL, rtol=0)
+        got = e.infer(x, 0.6, 0.45, 0.1)
+        ref = gold["ref_dets_conf0.6_q0.1"]
+        want = np.zeros(len(ref), dtype=got.dtype)
+        for f in ref.dtype.names:
+            want[f] = ref[f]
+        stats = compare(got, want, 0.6, min_iou=0.999, score_tol=1e-3)
+        assert stats["matched"] >= 0.97 * len(want), stats
+    finally:
+        e.close()

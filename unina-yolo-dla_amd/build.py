@@ -1,0 +1,70 @@
+"""Builds libunina_mi355.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the dev container; the .so travels to the GPU box
+with the repo snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from typing import List
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(PKG, "libunina_mi355.so")
+ARCH = "gfx950"
+
+# translation unit -> extra flags
+UNITS = {
+    "conv_igemm.hip": [],
+    "stem_pool.hip": [],
+    "postprocess.hip": ["-ffp-contract=off"],   # box arithmetic must round like the reference's scalar code
+    "engine.hip": [],
+}
+COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result"]
+
+
+def hipcc() -> str:
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need the ROCm toolchain to build the MI355X engine)")
+
+
+def _deps() -> List[str]:
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(PKG), "include", "unina_mi355.h"))
+    return hdrs
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    dep_mtime = max(os.path.getmtime(h) for h in _deps())
+    objs = []
+    rebuilt = False
+    for unit, extra in UNITS.items():
+        src = os.path.join(CSRC, unit)
+        obj = os.path.join(OBJ, unit + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), dep_mtime):
+            cmd = [cc, *COMMON, *extra, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode:
+                raise RuntimeError(f"hipcc failed on {unit}:\n{r.stderr}")
+            rebuilt = True
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_native(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,571 @@
+// engine.hip -- engine handle behind the C ABI of include/unina_mi355.h.
+//
+// Role in the reference: class TensorRTEngine (ros2_ws/src/perception/src/perception_node.cpp:223-351) plus
+// the per-frame body of processGpuBuffer (perception_node.cpp:612-656). Here the "plan" is an explicit op
+// table (engine_format.h) executed as hand-written HIP kernels; the whole forward is captured once into a
+// hipGraph and replayed per frame (52 launches -> one graph launch), the post-process is one more launch.
+//
+// Memory: one HBM blob for all folded weights (10 MB fp16), one arena for the NHWC fp16 activation buffers
+// (86 MB at 640^2 -- every tensor keeps its own slot; with 288 GB there is nothing to gain from aliasing and
+// distinct slots keep two handles = two frames in flight trivially independent).
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "engine_format.h"
+#include "kernels.h"
+
+using namespace unina;
+
+namespace {
+
+thread_local std::string g_load_error = "";
+
+struct Buffer {
+  BufferDesc d;
+  void* ptr = nullptr;    // current device address (engine-owned or caller-bound)
+  void* owned = nullptr;  // engine-owned allocation (inside the arena), if any
+  size_t bytes = 0;
+};
+
+struct PlannedOp {
+  OpDesc d;
+  ConvParams cp;
+  ConvLaunch cl;
+  StemParams sp;
+  PoolParams pp;
+  unina_op_info info;
+};
+
+struct DeviceResult {  // what the fused post-process writes; one D2H brings count + records
+  int count;
+  int candidates;
+  int pad[6];
+  GpuDetection det[MAX_DETECTIONS];
+};
+
+}  // namespace
+
+struct unina_engine {
+  int device = 0;
+  FileHeader h;
+  std::vector<Buffer> bufs;
+  std::vector<PlannedOp> ops;
+  void* d_blob = nullptr;
+  void* d_arena = nullptr;
+  int images_buf = -1;
+  int out_buf[6] = {-1, -1, -1, -1, -1, -1};
+  // post-process workspace
+  GpuDetection* d_cand = nullptr;
+  int* d_block_count = nullptr;
+  unsigned int* d_ticket = nullptr;
+  DeviceResult* d_result = nullptr;
+  DeviceResult* h_result = nullptr;  // pinned
+  int post_blocks = 0;
+  // graph
+  bool use_graph = true;
+  bool plan_dirty = true;
+  hipStream_t capture_stream = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  std::string err;
+};
+
+namespace {
+
+int fail(unina_engine* e, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf; else g_load_error = buf;
+  return code;
+}
+
+#define HIPCHK(e, call)                                                                          \
+  do {                                                                                           \
+    hipError_t _err = (call);                                                                    \
+    if (_err != hipSuccess) return fail((e), UNINA_ERR_HIP, "%s: %s", #call, hipGetErrorString(_err)); \
+  } while (0)
+
+size_t buffer_bytes(const BufferDesc& d) {
+  const size_t n = (size_t)d.h * d.w * d.c;
+  return d.dtype == kBufF16Nhwc ? n * 2 : n * 4;
+}
+
+void drop_graph(unina_engine* e) {
+  if (e->exec) (void)hipGraphExecDestroy(e->exec);
+  if (e->graph) (void)hipGraphDestroy(e->graph);
+  e->exec = nullptr;
+  e->graph = nullptr;
+}
+
+// (Re)computes kernel parameters from the current buffer addresses.
+int plan(unina_engine* e) {
+  const char* blob = static_cast<const char*>(e->d_blob);
+  for (size_t i = 0; i < e->ops.size(); ++i) {
+    PlannedOp& op = e->ops[i];
+    const OpDesc& d = op.d;
+    const Buffer& src = e->bufs[d.src_buf];
+    unina_op_info& info = op.info;
+    memset(&info, 0, sizeof info);
+    snprintf(info.name, sizeof info.name, "%s", d.name);
+    info.kind = (int)d.kind;
+    if (d.kind == kOpConv) {
+      ConvParams& p = op.cp;
+      memset(&p, 0, sizeof p);
+      p.src = static_cast<const half_t*>(src.ptr);
+      p.src_ld = (int)src.d.c;
+      p.H = (int)d.in_h; p.W = (int)d.in_w; p.Cin = (int)d.cin;
+      p.Ho = (int)d.out_h; p.Wo = (int)d.out_w; p.M = p.Ho * p.Wo;
+      p.ksize = (int)d.ksize; p.stride = (int)d.stride; p.pad = (int)d.ksize / 2;
+      p.relu = (int)d.relu;
+      if (d.res_buf >= 0) {
+        const Buffer& rb = e->bufs[d.res_buf];
+        p.res = static_cast<const half_t*>(rb.ptr) + d.res_coff;
+        p.res_ld = (int)rb.d.c;
+      }
+      p.nseg = (int)d.nseg;
+      int ntot = 0;
+      double out_bytes = 0;
+      for (int s = 0; s < p.nseg; ++s) {
+        const SegDesc& sd = d.seg[s];
+        const Buffer& db = e->bufs[sd.dst_buf];
+        ConvSeg& cs = p.seg[s];
+        cs.w = reinterpret_cast<const half_t*>(blob + sd.w_off);
+        cs.bias = reinterpret_cast<const float*>(blob + sd.b_off);
+        cs.src_coff = (int)sd.src_coff;
+        cs.n_count = (int)sd.n_count;
+        cs.up2 = (sd.flags & kSegUp2) ? 1 : 0;
+        if (sd.flags & kSegPlanarF32) {
+          if (db.d.dtype != kBufF32Planar) return fail(e, UNINA_ERR_FORMAT, "op %zu: planar slice into non-planar buffer", i);
+          cs.dst_planar = static_cast<float*>(db.ptr);
+          cs.dst = nullptr;
+          cs.dst_ld = 0;
+          out_bytes += 4.0 * sd.n_count * p.M;
+        } else {
+          if (db.d.dtype != kBufF16Nhwc || sd.n_count % 4) return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: NHWC slice needs n %% 4 == 0", i);
+          cs.dst = static_cast<half_t*>(db.ptr) + sd.dst_coff;
+          cs.dst_planar = nullptr;
+          cs.dst_ld = (int)db.d.c;
+          out_bytes += 2.0 * sd.n_count * p.M * (cs.up2 ? 4 : 1);
+        }
+        ntot += (int)sd.n_count;
+      }
+      if (p.Cin % 32 || p.src_ld % 8) return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu (%s): Cin %% 32 != 0", i, d.name);
+      op.cl = conv_plan(p);
+      const int K = p.ksize * p.ksize * p.Cin;
+      info.m = p.M; info.n = ntot; info.k = K;
+      info.flops = 2.0 * p.M * (double)ntot * K;
+      // algorithmic bytes: each distinct input element once, weights once, outputs once, residual once
+      const bool shared_src = p.nseg == 1 || d.seg[0].src_coff == d.seg[1].src_coff;
+      info.bytes = 2.0 * p.H * p.W * p.Cin * (shared_src ? 1 : p.nseg) + 2.0 * ntot * K + 4.0 * ntot + out_bytes +
+                   (p.res ? 2.0 * p.M * ntot : 0.0);
+      snprintf(info.kernel, sizeof info.kernel, "%s", op.cl.kernel_name);
+      info.grid = (int)(op.cl.grid.x * op.cl.grid.y);
+      info.block = (int)op.cl.block.x;
+    } else if (d.kind == kOpStem) {
+      const SegDesc& sd = d.seg[0];
+      const Buffer& db = e->bufs[sd.dst_buf];
+      StemParams& p = op.sp;
+      p.src = static_cast<const float*>(src.ptr);
+      p.w = reinterpret_cast<const float*>(blob + sd.w_off);
+      p.bias = reinterpret_cast<const float*>(blob + sd.b_off);
+      p.dst = static_cast<half_t*>(db.ptr) + sd.dst_coff;
+      p.H = (int)d.in_h; p.W = (int)d.in_w; p.Ho = (int)d.out_h; p.Wo = (int)d.out_w;
+      p.Co = (int)sd.n_count; p.dst_ld = (int)db.d.c;
+      info.m = p.Ho * p.Wo; info.n = p.Co; info.k = 27;
+      info.flops = 2.0 * info.m * info.n * 27;
+      info.bytes = 4.0 * 3 * p.H * p.W + 2.0 * info.m * p.Co;
+      snprintf(info.kernel, sizeof info.kernel, "stem_conv_kernel");
+      info.grid = (info.m + (256 / (p.Co / 8)) - 1) / (256 / (p.Co / 8));
+      info.block = 256;
+    } else if (d.kind == kOpSppfPool) {
+      PoolParams& p = op.pp;
+      p.buf = static_cast<half_t*>(src.ptr);
+      p.H = (int)d.in_h; p.W = (int)d.in_w; p.C = (int)d.cin; p.ld = (int)src.d.c; p.coff = (int)d.seg[0].src_coff;
+      info.bytes = 2.0 * p.H * p.W * p.C * 4;
+      snprintf(info.kernel, sizeof info.kernel, "sppf_pool_kernel<32>");
+      info.grid = p.H * (p.C / 32);
+      info.block = 256;
+    } else {
+      return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: kind %u not executable", i, d.kind);
+    }
+  }
+  e->plan_dirty = false;
+  drop_graph(e);
+  return UNINA_OK;
+}
+
+hipError_t launch_op(unina_engine* e, size_t i, hipStream_t s) {
+  PlannedOp& op = e->ops[i];
+  switch (op.d.kind) {
+    case kOpConv: return conv_launch(op.cp, op.cl, s);
+    case kOpStem: return stem_launch(op.sp, s);
+    case kOpSppfPool: return sppf_pool_launch(op.pp, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// Ops that read the caller's "images" tensor (the stem) stay OUTSIDE the captured graph: a camera pipeline hands
+// over a different input buffer every frame, and re-binding must not cost a re-capture.
+bool is_eager(const unina_engine* e, size_t i) { return (int)e->ops[i].d.src_buf == e->images_buf; }
+
+int launch_all(unina_engine* e, hipStream_t s, int which = 0 /*0 all, 1 eager only, 2 graph part only*/) {
+  for (size_t i = 0; i < e->ops.size(); ++i) {
+    if ((which == 1 && !is_eager(e, i)) || (which == 2 && is_eager(e, i))) continue;
+    hipError_t err = launch_op(e, i, s);
+    if (err != hipSuccess) return fail(e, UNINA_ERR_HIP, "op %zu (%s): %s", i, e->ops[i].d.name, hipGetErrorString(err));
+  }
+  return UNINA_OK;
+}
+
+int capture(unina_engine* e) {
+  drop_graph(e);
+  HIPCHK(e, hipStreamBeginCapture(e->capture_stream, hipStreamCaptureModeThreadLocal));
+  int rc = launch_all(e, e->capture_stream, 2);
+  hipError_t end = hipStreamEndCapture(e->capture_stream, &e->graph);
+  if (rc != UNINA_OK) return rc;
+  if (end != hipSuccess) return fail(e, UNINA_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(end));
+  HIPCHK(e, hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0));
+  return UNINA_OK;
+}
+
+int find_buffer(const unina_engine* e, const char* name) {
+  for (size_t i = 0; i < e->bufs.size(); ++i)
+    if (!strncmp(e->bufs[i].d.name, name, sizeof e->bufs[i].d.name)) return (int)i;
+  return -1;
+}
+
+float half_bits_to_float(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000) << 16;
+  uint32_t exp = (h >> 10) & 0x1F, man = h & 0x3FF, bits;
+  if (exp == 0) {
+    if (man == 0) bits = sign;
+    else {
+      int sh = 0;
+      while (!(man & 0x400)) { man <<= 1; ++sh; }
+      man &= 0x3FF;
+      bits = sign | ((uint32_t)(127 - 15 - sh + 1) << 23) | (man << 13);
+    }
+  } else if (exp == 31) bits = sign | 0x7F800000u | (man << 13);
+  else bits = sign | ((exp + 112) << 23) | (man << 13);
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+
+int fill_post_params(unina_engine* e, PostParams* pp, float conf, float iou, float q, GpuDetection* d_out, int* d_count,
+                     int* d_cand_count) {
+  memset(pp, 0, sizeof *pp);
+  for (int i = 0; i < 3; ++i) {
+    const Buffer& c = e->bufs[e->out_buf[2 * i]];
+    const Buffer& r = e->bufs[e->out_buf[2 * i + 1]];
+    pp->cls[i] = static_cast<const float*>(c.ptr);
+    pp->reg[i] = static_cast<const float*>(r.ptr);
+    pp->gw[i] = (int)c.d.w;
+    pp->gh[i] = (int)c.d.h;
+    pp->stride[i] = (int)e->h.strides[i];
+  }
+  pp->num_classes = (int)e->h.num_classes;
+  pp->conf_thr = conf;
+  pp->iou_thr = iou;
+  pp->conformal_q = q;
+  pp->cand = e->d_cand;
+  pp->block_count = e->d_block_count;
+  pp->ticket = e->d_ticket;
+  pp->out = d_out;
+  pp->out_count = d_count;
+  pp->out_candidates = d_cand_count;
+  return UNINA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* unina_version(void) { return "unina_mi355 0.1.0 gfx950"; }
+
+const char* unina_last_error(const unina_engine_t* e) { return e ? e->err.c_str() : g_load_error.c_str(); }
+
+int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
+  if (!path || !out) return fail(nullptr, UNINA_ERR_ARG, "unina_load_engine: null argument");
+  *out = nullptr;
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(nullptr, UNINA_ERR_IO, "cannot open %s", path);
+  unina_engine* e = new unina_engine();
+  e->device = device_id;
+  auto bail = [&](int code, const char* msg) {
+    g_load_error = msg;
+    if (f) fclose(f);
+    unina_unload_engine(e);
+    return code;
+  };
+  if (fread(&e->h, sizeof e->h, 1, f) != 1) return bail(UNINA_ERR_FORMAT, "truncated header");
+  if (memcmp(e->h.magic, kMagic, 8)) return bail(UNINA_ERR_FORMAT, "bad magic (not a UNINAENG file)");
+  if (e->h.version != kVersion) return bail(UNINA_ERR_FORMAT, "unsupported engine file version");
+  if (e->h.precision != kFp16) return bail(UNINA_ERR_UNSUPPORTED, "this build executes fp16 engines only");
+  if (e->h.n_heads != 3 || e->h.n_buffers == 0 || e->h.n_buffers > 4096 || e->h.n_ops == 0 || e->h.n_ops > 4096)
+    return bail(UNINA_ERR_FORMAT, "implausible table sizes");
+  e->bufs.resize(e->h.n_buffers);
+  for (auto& b : e->bufs)
+    if (fread(&b.d, sizeof b.d, 1, f) != 1) return bail(UNINA_ERR_FORMAT, "truncated buffer table");
+  e->ops.resize(e->h.n_ops);
+  for (auto& o : e->ops)
+    if (fread(&o.d, sizeof o.d, 1, f) != 1) return bail(UNINA_ERR_FORMAT, "truncated op table");
+  std::vector<char> blob(e->h.blob_bytes);
+  if (e->h.blob_bytes && fread(blob.data(), 1, blob.size(), f) != blob.size()) return bail(UNINA_ERR_FORMAT, "truncated weight blob");
+  fclose(f);
+  f = nullptr;
+
+  // table validation (indices, offsets) before anything touches the GPU
+  for (auto& o : e->ops) {
+    o.d.name[sizeof o.d.name - 1] = 0;
+    if (o.d.src_buf >= e->h.n_buffers || o.d.nseg < 1 || o.d.nseg > 2 || (o.d.res_buf >= (int)e->h.n_buffers))
+      return bail(UNINA_ERR_FORMAT, "op table: bad buffer index");
+    for (uint32_t s = 0; s < o.d.nseg; ++s) {
+      const SegDesc& sd = o.d.seg[s];
+      if (sd.dst_buf >= e->h.n_buffers) return bail(UNINA_ERR_FORMAT, "op table: bad destination buffer");
+      if (o.d.kind == kOpConv) {
+        const uint64_t wbytes = (uint64_t)sd.n_pad * o.d.ksize * o.d.ksize * o.d.cin * 2;
+        if (sd.w_off + wbytes > e->h.blob_bytes || sd.b_off + (uint64_t)sd.n_pad * 4 > e->h.blob_bytes || sd.w_off % 16 || sd.b_off % 16)
+          return bail(UNINA_ERR_FORMAT, "op table: weight offset outside blob");
+        const BufferDesc& sb = e->bufs[o.d.src_buf].d;
+        const BufferDesc& db = e->bufs[sd.dst_buf].d;
+        if (sd.src_coff + o.d.cin > sb.c || sb.h != o.d.in_h || sb.w != o.d.in_w) return bail(UNINA_ERR_FORMAT, "op table: source slice outside buffer");
+        const uint32_t mul = (sd.flags & kSegUp2) ? 2 : 1;
+        if (sd.dst_coff + sd.n_count > db.c || db.h != o.d.out_h * mul || db.w != o.d.out_w * mul) return bail(UNINA_ERR_FORMAT, "op table: destination slice outside buffer");
+      }
+    }
+  }
+  for (size_t i = 0; i < e->bufs.size(); ++i) {
+    e->bufs[i].d.name[sizeof e->bufs[i].d.name - 1] = 0;
+    e->bufs[i].bytes = buffer_bytes(e->bufs[i].d);
+    if (e->bufs[i].d.flags & kBufInput) e->images_buf = (int)i;
+  }
+  static const char* kOut[6] = {"p2_cls", "p2_reg", "p3_cls", "p3_reg", "p4_cls", "p4_reg"};
+  for (int i = 0; i < 6; ++i) {
+    e->out_buf[i] = find_buffer(e, kOut[i]);
+    if (e->out_buf[i] < 0) return bail(UNINA_ERR_FORMAT, "engine file lacks a head output buffer");
+  }
+  if (e->images_buf < 0) return bail(UNINA_ERR_FORMAT, "engine file lacks the images input buffer");
+
+  // ---- device side ----
+  hipError_t err;
+#define LOADCHK(call)                                                            \
+  if ((err = (call)) != hipSuccess) {                                            \
+    std::string m = std::string(#call) + ": " + hipGetErrorString(err);          \
+    return bail(UNINA_ERR_HIP, m.c_str());                                       \
+  }
+  LOADCHK(hipSetDevice(device_id));
+  LOADCHK(hipMalloc(&e->d_blob, blob.size() ? blob.size() : 16));
+  LOADCHK(hipMemcpy(e->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+  size_t arena = 0;
+  for (auto& b : e->bufs)
+    if (!(b.d.flags & kBufInput)) arena += (b.bytes + 255) & ~(size_t)255;
+  LOADCHK(hipMalloc(&e->d_arena, arena ? arena : 256));
+  LOADCHK(hipMemset(e->d_arena, 0, arena ? arena : 256));
+  size_t off = 0;
+  for (auto& b : e->bufs) {
+    if (b.d.flags & kBufInput) continue;
+    b.owned = static_cast<char*>(e->d_arena) + off;
+    b.ptr = b.owned;
+    off += (b.bytes + 255) & ~(size_t)255;
+  }
+  int gw[3], gh[3];
+  for (int i = 0; i < 3; ++i) {
+    gw[i] = (int)e->bufs[e->out_buf[2 * i]].d.w;
+    gh[i] = (int)e->bufs[e->out_buf[2 * i]].d.h;
+  }
+  e->post_blocks = post_num_blocks(gw, gh);
+  if (e->post_blocks > kPostBlock) return bail(UNINA_ERR_UNSUPPORTED, "input too large for the post-process workspace");
+  LOADCHK(hipMalloc(&e->d_cand, sizeof(GpuDetection) * (size_t)e->post_blocks * kPostBlock));
+  LOADCHK(hipMalloc(&e->d_block_count, sizeof(int) * (size_t)e->post_blocks));
+  LOADCHK(hipMalloc(&e->d_ticket, sizeof(unsigned int)));
+  LOADCHK(hipMemset(e->d_ticket, 0, sizeof(unsigned int)));
+  LOADCHK(hipMalloc(&e->d_result, sizeof(DeviceResult)));
+  LOADCHK(hipMemset(e->d_result, 0, sizeof(DeviceResult)));
+  LOADCHK(hipHostMalloc(&e->h_result, sizeof(DeviceResult), hipHostMallocDefault));
+  LOADCHK(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
+  LOADCHK(hipDeviceSynchronize());
+#undef LOADCHK
+  const char* ng = getenv("UNINA_NO_GRAPH");
+  e->use_graph = !(ng && ng[0] == '1');
+  e->plan_dirty = true;
+  *out = e;
+  return UNINA_OK;
+}
+
+void unina_unload_engine(unina_engine_t* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  drop_graph(e);
+  if (e->capture_stream) (void)hipStreamDestroy(e->capture_stream);
+  void* dev[] = {e->d_blob, e->d_arena, e->d_cand, e->d_block_count, e->d_ticket, e->d_result};
+  for (void* p : dev)
+    if (p) (void)hipFree(p);
+  if (e->h_result) (void)hipHostFree(e->h_result);
+  delete e;
+}
+
+int unina_engine_input_dims(const unina_engine_t* e, int* width, int* height, int* num_classes) {
+  if (!e) return UNINA_ERR_ARG;
+  if (width) *width = (int)e->h.in_w;
+  if (height) *height = (int)e->h.in_h;
+  if (num_classes) *num_classes = (int)e->h.num_classes;
+  return UNINA_OK;
+}
+
+int unina_set_tensor_address(unina_engine_t* e, const char* name, void* device_ptr) {
+  if (!e || !name) return UNINA_ERR_ARG;
+  const int i = find_buffer(e, name);
+  if (i < 0 || !(e->bufs[i].d.flags & (kBufInput | kBufOutput))) return fail(e, UNINA_ERR_ARG, "unknown I/O tensor '%s'", name);
+  if (!device_ptr && (e->bufs[i].d.flags & kBufOutput)) device_ptr = e->bufs[i].owned;  // NULL = back to the engine-owned buffer
+  if (((uintptr_t)device_ptr) & 15) return fail(e, UNINA_ERR_ARG, "tensor '%s': address must be 16-byte aligned", name);
+  if (e->bufs[i].ptr != device_ptr) {
+    e->bufs[i].ptr = device_ptr;
+    if (i == e->images_buf && !e->plan_dirty) {
+      for (size_t k = 0; k < e->ops.size(); ++k)  // only the eager (stem) ops read it: patch them, keep the graph
+        if (is_eager(e, k)) e->ops[k].sp.src = static_cast<const float*>(device_ptr);
+    } else {
+      e->plan_dirty = true;
+    }
+  }
+  return UNINA_OK;
+}
+
+int unina_tensor_address(const unina_engine_t* e, const char* name, void** device_ptr, size_t* num_floats) {
+  if (!e || !name) return UNINA_ERR_ARG;
+  const int i = find_buffer(e, name);
+  if (i < 0 || !(e->bufs[i].d.flags & (kBufInput | kBufOutput))) return UNINA_ERR_ARG;
+  if (device_ptr) *device_ptr = e->bufs[i].ptr;
+  if (num_floats) *num_floats = (size_t)e->bufs[i].d.h * e->bufs[i].d.w * e->bufs[i].d.c;
+  return UNINA_OK;
+}
+
+int unina_enqueue(unina_engine_t* e, hipStream_t stream) {
+  if (!e) return UNINA_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->bufs[e->images_buf].ptr) return fail(e, UNINA_ERR_STATE, "tensor 'images' is not bound");
+  if (e->plan_dirty) {
+    int rc = plan(e);
+    if (rc != UNINA_OK) return rc;
+  }
+  if (!e->use_graph) return launch_all(e, stream);
+  if (!e->exec) {
+    int rc = capture(e);
+    if (rc != UNINA_OK) return rc;
+  }
+  int rc = launch_all(e, stream, 1);
+  if (rc != UNINA_OK) return rc;
+  HIPCHK(e, hipGraphLaunch(e->exec, stream));
+  return UNINA_OK;
+}
+
+int unina_postprocess_async(unina_engine_t* e, float conf, float iou, float q, GpuDetection* d_out, int* d_out_count,
+                            hipStream_t stream) {
+  if (!e || !d_out || !d_out_count) return UNINA_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  PostParams pp;
+  fill_post_params(e, &pp, conf, iou, q, d_out, d_out_count, &e->d_result->candidates);
+  HIPCHK(e, postprocess_launch(pp, stream));
+  return UNINA_OK;
+}
+
+int unina_infer_async(unina_engine_t* e, const float* d_images, float conf, float iou, float q, GpuDetection* d_out,
+                      int* d_out_count, hipStream_t stream) {
+  if (!e) return UNINA_ERR_ARG;
+  if (d_images) {
+    int rc = unina_set_tensor_address(e, "images", const_cast<float*>(d_images));
+    if (rc != UNINA_OK) return rc;
+  }
+  int rc = unina_enqueue(e, stream);
+  if (rc != UNINA_OK) return rc;
+  return unina_postprocess_async(e, conf, iou, q, d_out, d_out_count, stream);
+}
+
+int unina_infer(unina_engine_t* e, const float* d_images, float conf, float iou, float q, GpuDetection* out,
+                int* out_count, hipStream_t stream) {
+  if (!e || !out || !out_count) return UNINA_ERR_ARG;
+  int rc = unina_infer_async(e, d_images, conf, iou, q, e->d_result->det, &e->d_result->count, stream);
+  if (rc != UNINA_OK) return rc;
+  HIPCHK(e, hipMemcpyAsync(e->h_result, e->d_result, sizeof(DeviceResult), hipMemcpyDeviceToHost, stream));
+  HIPCHK(e, hipStreamSynchronize(stream));
+  int n = e->h_result->count;
+  if (n < 0 || n > MAX_DETECTIONS) return fail(e, UNINA_ERR_STATE, "post-process returned count %d", n);
+  memcpy(out, e->h_result->det, sizeof(GpuDetection) * (size_t)n);
+  *out_count = n;
+  return UNINA_OK;
+}
+
+int unina_op_count(const unina_engine_t* e) { return e ? (int)e->ops.size() : -1; }
+
+int unina_get_op_info(const unina_engine_t* ce, int index, unina_op_info* info) {
+  unina_engine* e = const_cast<unina_engine*>(ce);
+  if (!e || !info || index < 0 || index >= (int)e->ops.size()) return UNINA_ERR_ARG;
+  if (e->plan_dirty) {
+    // planning needs addresses only for pointers; shapes/flops are valid regardless
+    int rc = plan(e);
+    if (rc != UNINA_OK) return rc;
+  }
+  *info = e->ops[index].info;
+  return UNINA_OK;
+}
+
+int unina_profile_ops(unina_engine_t* e, int iters, float* ms_per_op, hipStream_t stream) {
+  if (!e || !ms_per_op || iters < 1) return UNINA_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->bufs[e->images_buf].ptr) return fail(e, UNINA_ERR_STATE, "tensor 'images' is not bound");
+  if (e->plan_dirty) {
+    int rc = plan(e);
+    if (rc != UNINA_OK) return rc;
+  }
+  int rc = launch_all(e, stream);  // warm-up: every buffer holds real activations
+  if (rc != UNINA_OK) return rc;
+  hipEvent_t a, b;
+  HIPCHK(e, hipEventCreate(&a));
+  HIPCHK(e, hipEventCreate(&b));
+  for (size_t i = 0; i < e->ops.size(); ++i) {
+    HIPCHK(e, launch_op(e, i, stream));
+    HIPCHK(e, hipEventRecord(a, stream));
+    for (int it = 0; it < iters; ++it) HIPCHK(e, launch_op(e, i, stream));
+    HIPCHK(e, hipEventRecord(b, stream));
+    HIPCHK(e, hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(e, hipEventElapsedTime(&ms, a, b));
+    ms_per_op[i] = ms / (float)iters;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return UNINA_OK;
+}
+
+int unina_debug_read_buffer(unina_engine_t* e, const char* name, float* host_out, size_t capacity, int* c, int* h, int* w) {
+  if (!e || !name) return UNINA_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  const int i = find_buffer(e, name);
+  if (i < 0) return fail(e, UNINA_ERR_ARG, "unknown buffer '%s'", name);
+  const Buffer& b = e->bufs[i];
+  const size_t n = (size_t)b.d.h * b.d.w * b.d.c;
+  if (c) *c = (int)b.d.c;
+  if (h) *h = (int)b.d.h;
+  if (w) *w = (int)b.d.w;
+  if (capacity < n) return fail(e, UNINA_ERR_ARG, "buffer '%s' needs %zu floats", name, n);  // dims are still reported
+  HIPCHK(e, hipDeviceSynchronize());
+  if (b.d.dtype == kBufF16Nhwc) {
+    std::vector<uint16_t> tmp(n);
+    HIPCHK(e, hipMemcpy(tmp.data(), b.ptr, n * 2, hipMemcpyDeviceToHost));
+    const size_t hw = (size_t)b.d.h * b.d.w;
+    for (size_t p = 0; p < hw; ++p)
+      for (size_t ch = 0; ch < b.d.c; ++ch) host_out[ch * hw + p] = half_bits_to_float(tmp[p * b.d.c + ch]);
+  } else {
+    HIPCHK(e, hipMemcpy(host_out, b.ptr, n * 4, hipMemcpyDeviceToHost));
+  }
+  return UNINA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// kernels.h -- device-kernel launch interface of the engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "../../include/unina_mi355.h"
+
+namespace unina {
+
+typedef _Float16 half_t;
+
+// ------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution  D[cout][pixel] = sum_k W[cout][k] * X[pixel][k]   (+bias, ReLU, +residual)
+//   X : NHWC fp16 activation buffer, read through (ld, channel offset) so concat slices are free
+//   W : fp16 [n_pad][K], K = (kh, kw, cin)  -- BatchNorm already folded in
+// One launch covers up to two output-channel slices (merged sibling convs / two-group head layers).
+// ------------------------------------------------------------------------------------------------
+struct ConvSeg {
+  const half_t* w;     // [n_pad][K]
+  const float* bias;   // [n_pad]
+  half_t* dst;         // NHWC fp16 destination, channel offset already applied (unused when planar)
+  float* dst_planar;   // fp32 [n][Ho*Wo] destination (head outputs), or nullptr
+  int src_coff;        // channel offset of this slice's input
+  int n_count;         // valid output channels
+  int dst_ld;          // channels per pixel of the destination buffer
+  int up2;             // 1: write every output pixel to its 2x2 block of a (2Ho x 2Wo) destination
+  int tile0;           // first N-tile (blockIdx.y) that belongs to this slice
+};
+
+struct ConvParams {
+  const half_t* src;
+  int src_ld;          // channels per pixel of the source buffer
+  int H, W, Cin;       // input spatial size, input channels of each slice
+  int Ho, Wo, M;       // output spatial size, M = Ho*Wo
+  int ksize, stride, pad;
+  int relu;
+  const half_t* res;   // residual (added after ReLU), channel offset applied; nullptr = none
+  int res_ld;
+  int nseg;
+  ConvSeg seg[2];
+};
+
+// tile configurations of the conv kernel (block tile = BM pixels x BN output channels)
+enum ConvConfig : int { kCfg64x64 = 0, kCfg128x32 = 1, kCfg128x16 = 2, kCfgCount };
+struct ConvLaunch {
+  ConvConfig cfg;
+  dim3 grid, block;
+  const char* kernel_name;
+};
+ConvLaunch conv_plan(const ConvParams& p);
+hipError_t conv_launch(const ConvParams& p, const ConvLaunch& l, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// Stem: fp32 NCHW image -> 3x3/s2 conv (Cin=3) + bias + ReLU -> NHWC fp16
+// ------------------------------------------------------------------------------------------------
+struct StemParams {
+  const float* src;    // [3][H][W]
+  const float* w;      // [Co][27], (c,kh,kw)
+  const float* bias;   // [Co]
+  half_t* dst;         // [Ho][Wo][dst_ld]
+  int H, W, Ho, Wo, Co, dst_ld;
+};
+hipError_t stem_launch(const StemParams& p, hipStream_t stream, dim3* grid_out = nullptr, dim3* block_out = nullptr);
+
+// ------------------------------------------------------------------------------------------------
+// SPPF pool pyramid: y1 = pool5(x), y2 = pool5(y1), y3 = pool5(y2) (== 5x5, 9x9, 13x13 clipped windows of x)
+// x is channels [coff, coff+C) of buf; y1,y2,y3 are written at coff+C, coff+2C, coff+3C of the same buffer.
+// ------------------------------------------------------------------------------------------------
+struct PoolParams {
+  half_t* buf;
+  int H, W, C, ld, coff;
+};
+hipError_t sppf_pool_launch(const PoolParams& p, hipStream_t stream, dim3* grid_out = nullptr, dim3* block_out = nullptr);
+
+// Standalone nearest x2 upsample into a channel slice (the graph folds this into the producer conv; kept for
+// op tables that cannot fold it and for tests).
+struct UpsampleParams {
+  const half_t* src;
+  half_t* dst;
+  int H, W, C, src_ld, dst_ld;
+};
+hipError_t upsample2x_launch(const UpsampleParams& p, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// Fused post-process (one launch): decode three heads -> candidates -> top-1024 -> stable sort -> greedy NMS
+// ------------------------------------------------------------------------------------------------
+struct PostParams {
+  const float* cls[3];
+  const float* reg[3];
+  int gw[3], gh[3], stride[3];
+  int num_classes;
+  float conf_thr, iou_thr, conformal_q;
+  // workspace (engine-owned)
+  GpuDetection* cand;        // [nblocks][kPostBlock] per-block candidate segments
+  int* block_count;          // [nblocks]
+  unsigned int* ticket;      // arrival counter (zero at rest)
+  // outputs
+  GpuDetection* out;         // [MAX_DETECTIONS]
+  int* out_count;            // kept
+  int* out_candidates;       // optional (may be nullptr): number of cells that passed the threshold
+};
+constexpr int kPostBlock = 1024;
+int post_num_blocks(const int gw[3], const int gh[3]);
+hipError_t postprocess_launch(const PostParams& p, hipStream_t stream);
+
+}  // namespace unina

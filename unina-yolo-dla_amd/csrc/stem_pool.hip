@@ -1,0 +1,165 @@
+// stem_pool.hip -- the non-GEMM ops of the forward graph (gfx950).
+//   stem_conv_kernel   : backbone.stem  (model.py:175: ConvBlock(3, c1, k=3, s=2)) reading the fp32 NCHW image
+//   sppf_pool_kernel   : SPPF_DLA's three chained MaxPool2d(5,1,2)  (model.py:125,129-131)
+//   upsample2x_kernel  : Upsample(scale_factor=2, nearest)  (model.py:145-147), standalone form
+#include "kernels.h"
+
+namespace unina {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// ---------------------------------------------------------------------------------------------- stem
+// Cin = 3 makes K = 27: far too thin for a matrix-core tile, and the op is HBM-bound anyway
+// (4.9 MB fp32 in, 6.6 MB fp16 out at 640^2 against 0.18 GFLOP). Plain fp32 FMAs:
+// lane -> (pixel = tid/4, 8-channel group = tid%4), so a wave stores 64 x 16 B = 1 KiB contiguous NHWC.
+// Weights/bias sit in LDS (fp32, 32x27 + 32 floats).
+__global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
+  __shared__ float sw[27][32 + 1];
+  __shared__ float sb[32];
+  const int groups = p.Co / 8;                 // 4 for base_channels = 32
+  for (int i = threadIdx.x; i < p.Co * 27; i += blockDim.x) sw[i % 27][i / 27] = p.w[i];
+  for (int i = threadIdx.x; i < p.Co; i += blockDim.x) sb[i] = p.bias[i];
+  __syncthreads();
+  const int pix_per_block = blockDim.x / groups;
+  const int m = blockIdx.x * pix_per_block + threadIdx.x / groups;
+  const int g = threadIdx.x % groups;
+  if (m >= p.Ho * p.Wo) return;
+  const int oy = m / p.Wo, ox = m - oy * p.Wo;
+  float acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = sb[g * 8 + r];
+  const size_t plane = (size_t)p.H * p.W;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = oy * 2 + kh - 1;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ix = ox * 2 + kw - 1;
+        const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const float x = ok ? p.src[c * plane + (size_t)iy * p.W + ix] : 0.f;
+        const int k = (c * 3 + kh) * 3 + kw;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = __builtin_fmaf(x, sw[k][g * 8 + r], acc[r]);
+      }
+    }
+  half8 hv;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) hv[r] = (half_t)(acc[r] > 0.f ? acc[r] : 0.f);
+  *reinterpret_cast<half8*>(p.dst + (size_t)m * p.dst_ld + g * 8) = hv;
+}
+
+hipError_t stem_launch(const StemParams& p, hipStream_t stream, dim3* grid_out, dim3* block_out) {
+  if (p.Co > 32 || p.Co % 8) return hipErrorInvalidValue;
+  const int groups = p.Co / 8;
+  const int pix_per_block = 256 / groups;
+  dim3 grid((p.Ho * p.Wo + pix_per_block - 1) / pix_per_block), block(256);
+  if (grid_out) *grid_out = grid;
+  if (block_out) *block_out = block;
+  stem_conv_kernel<<<grid, block, 0, stream>>>(p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- SPPF pool
+// Three chained 5x5/s1/p2 max-pools of x equal the 5x5, 9x9 and 13x13 clipped-window maxima of x
+// (max is associative and the implicit -inf padding never wins). The kernel is separable and LDS-staged:
+// a block owns one output row y and a 64-channel slab:
+//   phase 1: for each of the (up to) 13 input rows y-6..y+6 compute, per column, nothing yet -- rows are
+//            just staged: LDS tile [13][W][64ch] would be 13*40*128 B = 66 KB at W=40, so instead the
+//            VERTICAL maxima are formed first while streaming rows from global memory:
+//              v5[x] = max rows y-2..y+2,  v9[x] = max rows y-4..y+4,  v13[x] = max rows y-6..y+6
+//            (each thread owns (x, 8 channels): 13 coalesced 16-byte loads), written to LDS;
+//   phase 2: horizontal maxima over v5/v9/v13 within +-2/4/6 columns read from LDS -> y1,y2,y3.
+// fp16 max is exact, so this is bit-identical to chaining the pools in any precision.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ h8 hmax8(h8 a, h8 b) {
+  h8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = a[i] > b[i] ? a[i] : b[i];
+  return r;
+}
+
+template <int CH>  // channels per block (multiple of 8)
+__global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  h8* v5 = reinterpret_cast<h8*>(smem);                 // [W][CH/8]
+  h8* v9 = v5 + p.W * (CH / 8);
+  h8* v13 = v9 + p.W * (CH / 8);
+  const int y = blockIdx.x;
+  const int c0 = blockIdx.y * CH;
+  const int nvec = p.W * (CH / 8);
+  const half_t* x = p.buf + p.coff + c0;
+  const half_t ninf = (half_t)(-65504.0f);              // below every finite fp16 (post-ReLU inputs are >= 0)
+  const h8 lo = {ninf, ninf, ninf, ninf, ninf, ninf, ninf, ninf};
+  for (int t = threadIdx.x; t < nvec; t += blockDim.x) {
+    const int xx = t / (CH / 8), cv = t % (CH / 8);
+    h8 m5 = lo, m9 = lo, m13 = lo;
+#pragma unroll
+    for (int dy = -6; dy <= 6; ++dy) {
+      const int yy = y + dy;
+      if (yy < 0 || yy >= p.H) continue;
+      const h8 v = *reinterpret_cast<const h8*>(x + ((size_t)yy * p.W + xx) * p.ld + cv * 8);
+      m13 = hmax8(m13, v);
+      if (dy >= -4 && dy <= 4) m9 = hmax8(m9, v);
+      if (dy >= -2 && dy <= 2) m5 = hmax8(m5, v);
+    }
+    v5[t] = m5;
+    v9[t] = m9;
+    v13[t] = m13;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < nvec; t += blockDim.x) {
+    const int xx = t / (CH / 8), cv = t % (CH / 8);
+    h8 o5 = lo, o9 = lo, o13 = lo;
+#pragma unroll
+    for (int dx = -6; dx <= 6; ++dx) {
+      const int x2 = xx + dx;
+      if (x2 < 0 || x2 >= p.W) continue;
+      const int idx = x2 * (CH / 8) + cv;
+      o13 = hmax8(o13, v13[idx]);
+      if (dx >= -4 && dx <= 4) o9 = hmax8(o9, v9[idx]);
+      if (dx >= -2 && dx <= 2) o5 = hmax8(o5, v5[idx]);
+    }
+    half_t* o = p.buf + ((size_t)y * p.W + xx) * p.ld + p.coff + c0 + cv * 8;
+    *reinterpret_cast<h8*>(o + p.C) = o5;
+    *reinterpret_cast<h8*>(o + 2 * p.C) = o9;
+    *reinterpret_cast<h8*>(o + 3 * p.C) = o13;
+  }
+}
+
+hipError_t sppf_pool_launch(const PoolParams& p, hipStream_t stream, dim3* grid_out, dim3* block_out) {
+  constexpr int CH = 32;
+  if (p.C % CH) return hipErrorInvalidValue;
+  dim3 grid(p.H, p.C / CH), block(256);
+  const size_t smem = (size_t)3 * p.W * CH * sizeof(half_t);
+  if (smem > 160 * 1024) return hipErrorInvalidValue;
+  if (grid_out) *grid_out = grid;
+  if (block_out) *block_out = block;
+  sppf_pool_kernel<CH><<<grid, block, smem, stream>>>(p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- upsample
+__global__ __launch_bounds__(256) void upsample2x_kernel(const UpsampleParams p) {
+  const int vec = p.C / 8;
+  const size_t total = (size_t)4 * p.H * p.W * vec;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int cv = t % vec;
+    const size_t pix = t / vec;
+    const int ox = pix % (2 * p.W), oy = pix / (2 * p.W);
+    const half8 v = *reinterpret_cast<const half8*>(p.src + ((size_t)(oy >> 1) * p.W + (ox >> 1)) * p.src_ld + cv * 8);
+    *reinterpret_cast<half8*>(p.dst + pix * p.dst_ld + cv * 8) = v;
+  }
+}
+
+hipError_t upsample2x_launch(const UpsampleParams& p, hipStream_t stream) {
+  if (p.C % 8) return hipErrorInvalidValue;
+  const size_t total = (size_t)4 * p.H * p.W * (p.C / 8);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  upsample2x_kernel<<<blocks, 256, 0, stream>>>(p);
+  return hipGetLastError();
+}
+
+}  // namespace unina

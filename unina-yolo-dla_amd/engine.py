@@ -1,0 +1,245 @@
+"""Host-side mirror of the reference's engine interface, over the C ABI (include/unina_mi355.h).
+
+``Engine`` plays the role of the C++ ``TensorRTEngine`` wrapper (perception_node.cpp:223-351: load / bind
+tensor addresses / enqueueV3 / getInputDimensions) plus the fused per-frame path (perception_node.cpp:612-656).
+All compute happens inside libunina_mi355.so (hand-written HIP); torch is used only to own device memory and
+streams. There is NO fallback: if the shared library is missing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import tempfile
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import export as _export
+from .graph import Graph, OUTPUT_NAMES
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libunina_mi355.so")
+MAX_DETECTIONS = 1024
+
+DET_DTYPE = np.dtype([("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4"), ("confidence", "<f4"),
+                      ("class_id", "<i4"), ("valid", "<i4"), ("_pad", "<i4")])
+assert DET_DTYPE.itemsize == 32
+
+ERRORS = {1: "IO", 2: "FORMAT", 3: "HIP", 4: "ARG", 5: "STATE", 6: "UNSUPPORTED"}
+
+
+class OpInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("kernel", C.c_char * 64), ("kind", C.c_int), ("m", C.c_int), ("n", C.c_int),
+                ("k", C.c_int), ("flops", C.c_double), ("bytes", C.c_double), ("grid", C.c_int), ("block", C.c_int)]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+# every symbol include/unina_mi355.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "unina_load_engine", "unina_unload_engine", "unina_engine_input_dims", "unina_set_tensor_address",
+    "unina_tensor_address", "unina_enqueue", "unina_infer", "unina_infer_async", "unina_postprocess_async",
+    "unina_last_error", "unina_op_count", "unina_get_op_info", "unina_profile_ops", "unina_debug_read_buffer",
+    "unina_version",
+    "init_postprocess_resources", "cleanup_postprocess_resources", "reset_detection_counter", "get_detection_count",
+    "decode_yolo_head", "run_gpu_nms", "copy_valid_detections_to_host",
+]
+
+
+def load_library() -> C.CDLL:
+    """Loads libunina_mi355.so; raises if it has not been built (``python unina-yolo-dla_amd/build.py``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                          f"(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.unina_load_engine.argtypes = [C.c_char_p, ci, C.POINTER(vp)]
+    L.unina_unload_engine.argtypes = [vp]
+    L.unina_unload_engine.restype = None
+    L.unina_engine_input_dims.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+    L.unina_set_tensor_address.argtypes = [vp, C.c_char_p, vp]
+    L.unina_tensor_address.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.unina_enqueue.argtypes = [vp, vp]
+    L.unina_infer.argtypes = [vp, vp, cf, cf, cf, vp, C.POINTER(ci), vp]
+    L.unina_infer_async.argtypes = [vp, vp, cf, cf, cf, vp, vp, vp]
+    L.unina_postprocess_async.argtypes = [vp, cf, cf, cf, vp, vp, vp]
+    L.unina_last_error.argtypes = [vp]
+    L.unina_last_error.restype = C.c_char_p
+    L.unina_op_count.argtypes = [vp]
+    L.unina_get_op_info.argtypes = [vp, ci, C.POINTER(OpInfo)]
+    L.unina_profile_ops.argtypes = [vp, ci, C.POINTER(cf), vp]
+    L.unina_debug_read_buffer.argtypes = [vp, C.c_char_p, vp, C.c_size_t, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+    L.unina_version.restype = C.c_char_p
+    # gpu_postprocess.h drop-in symbols
+    L.reset_detection_counter.argtypes = [vp]
+    L.get_detection_count.argtypes = [C.POINTER(ci), vp]
+    L.decode_yolo_head.argtypes = [vp, vp, vp, ci, ci, ci, ci, cf, cf, vp]
+    L.run_gpu_nms.argtypes = [vp, ci, cf, vp]
+    L.copy_valid_detections_to_host.argtypes = [vp, vp, ci, C.POINTER(ci), vp]
+    _lib = L
+    return L
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise EngineError("no MI355X visible to this process (torch.cuda.is_available() is False)")
+    return torch
+
+
+def _stream_ptr(stream) -> int:
+    if stream is None:
+        stream = _torch().cuda.current_stream()
+    return stream if isinstance(stream, int) else stream.cuda_stream
+
+
+class Engine:
+    """One engine handle on one GPU. Use two handles to keep two frames in flight."""
+
+    def __init__(self, path: str, device: int = 0):
+        self.L = load_library()
+        torch = _torch()
+        self.device = device
+        self.h = C.c_void_p()
+        rc = self.L.unina_load_engine(path.encode(), device, C.byref(self.h))
+        if rc:
+            raise EngineError(f"unina_load_engine({path}) failed [{ERRORS.get(rc, rc)}]: "
+                              f"{self.L.unina_last_error(None).decode()}")
+        w, h, nc = C.c_int(), C.c_int(), C.c_int()
+        self._check(self.L.unina_engine_input_dims(self.h, C.byref(w), C.byref(h), C.byref(nc)))
+        self.width, self.height, self.num_classes = w.value, h.value, nc.value
+        dev = torch.device("cuda", device)
+        # the caller (this wrapper) owns the I/O buffers, as the node does (perception_node.cpp:696-707)
+        self.outputs: Dict[str, "torch.Tensor"] = {}
+        for name, s in zip(OUTPUT_NAMES, (4, 4, 8, 8, 16, 16)):
+            c = nc.value if name.endswith("cls") else 4
+            t = torch.zeros((1, c, h.value // s, w.value // s), dtype=torch.float32, device=dev)
+            self.outputs[name] = t
+            self._check(self.L.unina_set_tensor_address(self.h, name.encode(), t.data_ptr()))
+        self._images = None
+        self._det_buf = torch.zeros((MAX_DETECTIONS * 8 + 8,), dtype=torch.int32, device=dev)
+
+    # -- construction helpers -------------------------------------------------------------------------
+    @classmethod
+    def from_state_dict(cls, sd: Dict[str, np.ndarray], graph: Optional[Graph] = None, device: int = 0,
+                        path: Optional[str] = None) -> "Engine":
+        """export_trt.py's role + load: folds/fuses `sd` into an engine file (temporary unless `path`) and loads it."""
+        if path is None:
+            fd, tmp = tempfile.mkstemp(suffix=".une")
+            os.close(fd)
+            try:
+                _export.export_engine(sd, tmp, graph)
+                return cls(tmp, device)
+            finally:
+                os.unlink(tmp)
+        _export.export_engine(sd, path, graph)
+        return cls(path, device)
+
+    def _check(self, rc: int):
+        if rc:
+            raise EngineError(f"[{ERRORS.get(rc, rc)}] {self.L.unina_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            _torch().cuda.synchronize(self.device)
+            self.L.unina_unload_engine(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- TensorRTEngine-shaped path --------------------------------------------------------------------
+    def bind_images(self, images) -> None:
+        """images: torch cuda fp32 [1,3,H,W] contiguous (setInputTensorAddress("images", ...))."""
+        assert images.is_cuda and images.dtype == _torch().float32 and images.is_contiguous()
+        assert tuple(images.shape) == (1, 3, self.height, self.width), images.shape
+        self._images = images
+        self._check(self.L.unina_set_tensor_address(self.h, b"images", images.data_ptr()))
+
+    def enqueue(self, stream=None) -> None:
+        """enqueueV3: raw heads into self.outputs (asynchronous)."""
+        self._check(self.L.unina_enqueue(self.h, _stream_ptr(stream)))
+
+    def forward(self, images) -> Dict[str, np.ndarray]:
+        """Raw-head forward, synchronous; returns {name: [C,H,W] fp32 ndarray}."""
+        self.bind_images(images)
+        self.enqueue()
+        _torch().cuda.synchronize(self.device)
+        return {k: v[0].cpu().numpy() for k, v in self.outputs.items()}
+
+    # -- fused path ----------------------------------------------------------------------------------------
+    def infer(self, images, conf_thr: float = 0.5, iou_thr: float = 0.45, conformal_q: float = 0.1, stream=None):
+        """Forward + decode + NMS; returns a structured ndarray of kept detections (DET_DTYPE)."""
+        if images is not None:
+            self.bind_images(images)
+        out = np.zeros(MAX_DETECTIONS, dtype=DET_DTYPE)
+        n = C.c_int()
+        self._check(self.L.unina_infer(self.h, None, conf_thr, iou_thr, conformal_q, out.ctypes.data, C.byref(n),
+                                       _stream_ptr(stream)))
+        return out[:n.value].copy()
+
+    def infer_async(self, images, conf_thr: float = 0.5, iou_thr: float = 0.45, conformal_q: float = 0.1,
+                    out=None, stream=None):
+        """Asynchronous: results stay on the GPU in `out` (int32 tensor of 8 + 8*MAX_DETECTIONS words:
+        word 0 = count, records from word 8). Returns `out`."""
+        if images is not None:
+            self.bind_images(images)
+        out = self._det_buf if out is None else out
+        base = out.data_ptr()
+        self._check(self.L.unina_infer_async(self.h, None, conf_thr, iou_thr, conformal_q, base + 32, base,
+                                             _stream_ptr(stream)))
+        return out
+
+    def postprocess(self, conf_thr: float = 0.5, iou_thr: float = 0.45, conformal_q: float = 0.1, stream=None):
+        """Decode + NMS on whatever the six output tensors currently hold (synchronous)."""
+        base = self._det_buf.data_ptr()
+        self._check(self.L.unina_postprocess_async(self.h, conf_thr, iou_thr, conformal_q, base + 32, base,
+                                                   _stream_ptr(stream)))
+        return self.unpack(self._det_buf)
+
+    @staticmethod
+    def unpack(buf) -> np.ndarray:
+        """int32 result tensor (see infer_async) -> structured ndarray of the kept detections."""
+        host = buf.cpu().numpy()
+        n = int(host[0])
+        return host[8:8 + 8 * n].view(DET_DTYPE).copy()
+
+    # -- introspection ---------------------------------------------------------------------------------------
+    def op_infos(self) -> List[dict]:
+        out = []
+        for i in range(self.L.unina_op_count(self.h)):
+            info = OpInfo()
+            self._check(self.L.unina_get_op_info(self.h, i, C.byref(info)))
+            out.append(dict(name=info.name.decode(), kernel=info.kernel.decode(), kind=info.kind, m=info.m, n=info.n,
+                            k=info.k, flops=info.flops, bytes=info.bytes, grid=info.grid, block=info.block))
+        return out
+
+    def profile_ops(self, iters: int = 20, stream=None) -> List[dict]:
+        n = self.L.unina_op_count(self.h)
+        ms = (C.c_float * n)()
+        self._check(self.L.unina_profile_ops(self.h, iters, ms, _stream_ptr(stream)))
+        infos = self.op_infos()
+        for i, d in enumerate(infos):
+            d["ms"] = float(ms[i])
+        return infos
+
+    def read_buffer(self, name: str) -> np.ndarray:
+        """Internal activation buffer -> [C,H,W] fp32 (parity tests)."""
+        c, h, w = C.c_int(-1), C.c_int(), C.c_int()
+        self.L.unina_debug_read_buffer(self.h, name.encode(), None, 0, C.byref(c), C.byref(h), C.byref(w))  # dims only
+        if c.value < 0:
+            raise EngineError(f"unknown buffer {name!r}")
+        out = np.empty(c.value * h.value * w.value, dtype=np.float32)
+        self._check(self.L.unina_debug_read_buffer(self.h, name.encode(), out.ctypes.data, out.size, C.byref(c),
+                                                   C.byref(h), C.byref(w)))
+        return out.reshape(c.value, h.value, w.value)

@@ -1,0 +1,293 @@
+"""Engine builder: state_dict of graph (A)  ->  .une engine file for libunina_mi355.so.
+
+Plays the role of the reference's ``export_trt.py::export_pipeline`` (export_trt.py:497-566:
+ONNX export -> TensorRT build -> serialized plan) for the MI355X engine. Instead of an opaque plan
+the output is an explicit table of FUSED ops over NHWC fp16 activation buffers:
+
+* BatchNorm (eval) is folded into the conv:  W' = W*g/sqrt(var+eps),  b' = beta - mean*g/sqrt(var+eps)
+  (model.py:41-50; eps = 1e-5); ReLU is an epilogue flag.
+* every ``torch.cat`` (model.py:110,132,257,260,264,267) becomes a shared buffer: producers write
+  channel slices, so concat costs nothing.
+* C3k2 ``cv1``/``cv2`` (same input, model.py:107-108) and the head's ``cls_branch.0``/``reg_branch.0``
+  (same input, model.py:303) are merged into one implicit GEMM with two output slices; the head's
+  ``.1`` and ``.2`` layers run as one two-group launch.
+* the Bottleneck residual (model.py:73) is added in the 3x3 conv's epilogue, after its ReLU.
+* ``Upsample`` (model.py:145-147) is folded into the lateral 1x1 conv's store (each output pixel is
+  written to its 2x2 block of the FPN concat buffer).
+* the SPPF pool pyramid (model.py:129-131) is ONE op producing y1,y2,y3 into the 4-way concat buffer.
+
+67 reference convs -> 52 launches + 1 pool.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .graph import Graph, OUTPUT_NAMES, STRIDES
+
+MAGIC = b"UNINAENG"
+VERSION = 1
+FP16, INT8 = 0, 1
+BUF_F16, BUF_F32_PLANAR, BUF_F32_NCHW_IN = 0, 1, 2
+BUF_INPUT, BUF_OUTPUT = 1, 2
+OP_CONV, OP_STEM, OP_SPPF_POOL, OP_UPSAMPLE = 1, 2, 3, 4
+SEG_UP2, SEG_PLANAR_F32 = 1, 2
+BN_EPS = 1e-5
+
+_HDR = struct.Struct("<8sII3II2II3IQQ56x")
+_BUF = struct.Struct("<3III44s")
+_SEG = struct.Struct("<6IQQff16x")
+_OP_HEAD = struct.Struct("<4I2I2iI4If")
+assert _HDR.size == 128 and _BUF.size == 64 and _SEG.size == 64 and _OP_HEAD.size == 56
+
+
+@dataclass
+class View:
+    buf: int
+    coff: int
+    c: int
+
+
+@dataclass
+class Seg:
+    module: str               # reference module path whose weights this slice carries
+    src_coff: int
+    n_count: int
+    dst: View
+    flags: int = 0
+    w_off: int = 0
+    b_off: int = 0
+    n_pad: int = 0
+
+
+@dataclass
+class Op:
+    kind: int
+    name: str
+    src_buf: int
+    cin: int
+    k: int = 1
+    s: int = 1
+    relu: int = 1
+    res: Optional[View] = None
+    in_hw: Tuple[int, int] = (0, 0)
+    out_hw: Tuple[int, int] = (0, 0)
+    segs: List[Seg] = field(default_factory=list)
+
+
+def fold_bn(sd: Dict[str, np.ndarray], module: str):
+    """ConvBlock -> (W' [O,C,k,k] fp64, b' [O] fp64)."""
+    w = sd[f"{module}.conv.weight"].astype(np.float64)
+    g = sd[f"{module}.bn.weight"].astype(np.float64)
+    b = sd[f"{module}.bn.bias"].astype(np.float64)
+    m = sd[f"{module}.bn.running_mean"].astype(np.float64)
+    v = sd[f"{module}.bn.running_var"].astype(np.float64)
+    f = g / np.sqrt(v + BN_EPS)
+    return w * f[:, None, None, None], b - m * f
+
+
+class EngineBuilder:
+    def __init__(self, sd: Dict[str, np.ndarray], graph: Optional[Graph] = None):
+        self.sd = sd
+        self.g = graph or Graph()
+        if self.g.base_channels % 32:
+            raise NotImplementedError("engine kernels need Cin % 32 == 0 beyond the stem (base_channels multiple of 32)")
+        self.buffers: List[Tuple[str, int, int, int, int, int]] = []   # name,h,w,c,dtype,flags
+        self.ops: List[Op] = []
+        self.blob = bytearray()
+        self._lower()
+
+    # ---- tables -------------------------------------------------------------------------------
+    def buf(self, name: str, h: int, w: int, c: int, dtype: int = BUF_F16, flags: int = 0) -> int:
+        self.buffers.append((name, h, w, c, dtype, flags))
+        return len(self.buffers) - 1
+
+    def view(self, name: str, h: int, w: int, c: int) -> View:
+        return View(self.buf(name, h, w, c), 0, c)
+
+    def _hw(self, buf: int) -> Tuple[int, int]:
+        return self.buffers[buf][1], self.buffers[buf][2]
+
+    def _blob_add(self, arr: np.ndarray) -> int:
+        pad = (-len(self.blob)) % 256
+        self.blob += b"\0" * pad
+        off = len(self.blob)
+        self.blob += arr.tobytes()
+        return off
+
+    # ---- op emitters ---------------------------------------------------------------------------
+    def conv(self, items, src_buf: int, cin: int, k: int, s: int = 1, relu: bool = True,
+             res: Optional[View] = None, bn: bool = True):
+        """items: list of (module, src_coff, dst View, flags). One launch, len(items) output slices."""
+        ih, iw = self._hw(src_buf)
+        p = k // 2
+        oh, ow = (ih + 2 * p - k) // s + 1, (iw + 2 * p - k) // s + 1
+        op = Op(OP_CONV, "+".join(m for m, *_ in items), src_buf, cin, k, s, int(relu), res, (ih, iw), (oh, ow))
+        for module, src_coff, dst, flags in items:
+            if bn:
+                w, b = fold_bn(self.sd, module)
+            else:
+                w = self.sd[f"{module}.weight"].astype(np.float64)
+                b = self.sd[f"{module}.bias"].astype(np.float64)
+            n = w.shape[0]
+            assert w.shape[1] == cin and w.shape[2] == k, (module, w.shape, cin, k)
+            n_pad = -(-n // 16) * 16
+            wk = np.zeros((n_pad, k, k, cin), dtype=np.float16)
+            wk[:n] = np.transpose(w, (0, 2, 3, 1)).astype(np.float16)       # [O][kh][kw][C]: K = (kh,kw,cin)
+            bk = np.zeros((n_pad,), dtype=np.float32)
+            bk[:n] = b.astype(np.float32)
+            dh, dw = self._hw(dst.buf)
+            want = (2 * oh, 2 * ow) if flags & SEG_UP2 else (oh, ow)
+            assert (dh, dw) == want, (module, (dh, dw), want)
+            assert dst.c == n, (module, dst.c, n)
+            op.segs.append(Seg(module, src_coff, n, dst, flags, self._blob_add(wk), self._blob_add(bk), n_pad))
+        self.ops.append(op)
+
+    def c3k2(self, name: str, src: View, dst: View, n: int):
+        """C3k2 (model.py:76-110) -> 2 + 2n launches."""
+        h, w = self._hw(src.buf)
+        cout = dst.c
+        hid = cout // 2
+        cat = self.buf(f"{name}.cat", h, w, 2 * hid)
+        cur = self.view(f"{name}.cv1", h, w, hid)
+        self.conv([(f"{name}.cv1", src.coff, cur, 0), (f"{name}.cv2", src.coff, View(cat, hid, hid), 0)],
+                  src.buf, src.c, 1)
+        for i in range(n):
+            t = self.view(f"{name}.bottlenecks.{i}.cv1", h, w, hid)
+            self.conv([(f"{name}.bottlenecks.{i}.cv1", cur.coff, t, 0)], cur.buf, hid, 1)
+            out = View(cat, 0, hid) if i == n - 1 else self.view(f"{name}.bottlenecks.{i}", h, w, hid)
+            self.conv([(f"{name}.bottlenecks.{i}.cv2", t.coff, out, 0)], t.buf, hid, 3, res=cur)
+            cur = out
+        self.conv([(f"{name}.cv3", 0, dst, 0)], cat, 2 * hid, 1)
+
+    def head(self, name: str, feat: View, out_cls: int, out_reg: int):
+        """DetectionHead (model.py:274-303) -> 3 launches (both branches per launch)."""
+        h, w = self._hw(feat.buf)
+        c = feat.c
+        h0 = self.buf(f"{name}.h0", h, w, 2 * c)
+        h1 = self.buf(f"{name}.h1", h, w, 2 * c)
+        self.conv([(f"{name}.cls_branch.0", feat.coff, View(h0, 0, c), 0),
+                   (f"{name}.reg_branch.0", feat.coff, View(h0, c, c), 0)], feat.buf, c, 3)
+        self.conv([(f"{name}.cls_branch.1", 0, View(h1, 0, c), 0),
+                   (f"{name}.reg_branch.1", c, View(h1, c, c), 0)], h0, c, 3)
+        self.conv([(f"{name}.cls_branch.2", 0, View(out_cls, 0, self.g.num_classes), SEG_PLANAR_F32),
+                   (f"{name}.reg_branch.2", c, View(out_reg, 0, 4), SEG_PLANAR_F32)], h1, c, 1,
+                  relu=False, bn=False)
+
+    # ---- the network ---------------------------------------------------------------------------
+    def _lower(self):
+        g = self.g
+        bc = g.base_channels
+        c1, c2, c3, c4 = bc, 2 * bc, 4 * bc, 8 * bc
+        H, W = g.in_h, g.in_w
+        images = self.buf("images", H, W, 3, BUF_F32_NCHW_IN, BUF_INPUT)
+        outs = {}
+        for name, s in zip(OUTPUT_NAMES, (4, 4, 8, 8, 16, 16)):
+            c = g.num_classes if name.endswith("cls") else 4
+            outs[name] = self.buf(name, H // s, W // s, c, BUF_F32_PLANAR, BUF_OUTPUT)
+
+        # concat buffers of the neck (orders: model.py:257,260,264,267)
+        fpn1 = self.buf("neck.cat_fpn1", H // 8, W // 8, c3 + c3)      # [p4_up | p3]
+        fpn2 = self.buf("neck.cat_fpn2", H // 4, W // 4, c2 + c2)      # [p3_up | p2]
+        pan1 = self.buf("neck.cat_pan1", H // 8, W // 8, c2 + c3)      # [p2_down | p3_fused]
+        pan2 = self.buf("neck.cat_pan2", H // 16, W // 16, c3 + c4)    # [p3_down | p4 (pre-SPPF)]
+        p2, p3, p4 = View(fpn2, c2, c2), View(fpn1, c3, c3), View(pan2, c3, c4)
+        p3_fused = View(pan1, c2, c3)
+
+        # Backbone (model.py:205-219)
+        stem = self.view("backbone.stem", H // 2, W // 2, c1)
+        w, b = fold_bn(self.sd, "backbone.stem")
+        op = Op(OP_STEM, "backbone.stem", images, 3, 3, 2, 1, None, (H, W), (H // 2, W // 2))
+        op.segs.append(Seg("backbone.stem", 0, c1, stem, 0,
+                           self._blob_add(w.astype(np.float32).reshape(c1, 27)),      # [O][(c,kh,kw)] fp32
+                           self._blob_add(b.astype(np.float32)), c1))
+        self.ops.append(op)
+        s1 = self.view("backbone.stage1_conv", H // 4, W // 4, c2)
+        self.conv([("backbone.stage1_conv", 0, s1, 0)], stem.buf, c1, 3, 2)
+        if g.lite_p2:
+            self.conv([("backbone.stage1_block", 0, p2, 0)], s1.buf, c2, 3)
+        else:
+            self.c3k2("backbone.stage1_block", s1, p2, 1)
+        s2 = self.view("backbone.stage2_conv", H // 8, W // 8, c3)
+        self.conv([("backbone.stage2_conv", p2.coff, s2, 0)], p2.buf, c2, 3, 2)
+        self.c3k2("backbone.stage2_c3k2", s2, p3, 2)
+        s3 = self.view("backbone.stage3_conv", H // 16, W // 16, c4)
+        self.conv([("backbone.stage3_conv", p3.coff, s3, 0)], p3.buf, c3, 3, 2)
+        self.c3k2("backbone.stage3_c3k2", s3, p4, 2)
+        # SPPF_DLA (model.py:113-132)
+        hid = c4 // 2
+        sp = self.buf("backbone.sppf.cat", H // 16, W // 16, 4 * hid)
+        self.conv([("backbone.sppf.cv1", p4.coff, View(sp, 0, hid), 0)], p4.buf, c4, 1)
+        pool = Op(OP_SPPF_POOL, "backbone.sppf.pool1+pool2+pool3", sp, hid, 5, 1, 0, None,
+                  (H // 16, W // 16), (H // 16, W // 16))
+        pool.segs.append(Seg("backbone.sppf.pool", 0, 3 * hid, View(sp, hid, 3 * hid)))
+        self.ops.append(pool)
+        p4_sppf = self.view("backbone.sppf", H // 16, W // 16, c4)
+        self.conv([("backbone.sppf.cv2", 0, p4_sppf, 0)], sp, 4 * hid, 1)
+
+        # Neck (model.py:252-269)
+        self.conv([("neck.lateral_p3", 0, View(fpn1, 0, c3), SEG_UP2)], p4_sppf.buf, c4, 1)
+        self.c3k2("neck.fpn_c3k2_1", View(fpn1, 0, 2 * c3), p3_fused, 1)
+        self.conv([("neck.lateral_p2", p3_fused.coff, View(fpn2, 0, c2), SEG_UP2)], p3_fused.buf, c3, 1)
+        p2_fused = self.view("p2_fused", H // 4, W // 4, c2)
+        self.c3k2("neck.fpn_c3k2_2", View(fpn2, 0, 2 * c2), p2_fused, 1)
+        self.conv([("neck.down1", 0, View(pan1, 0, c2), 0)], p2_fused.buf, c2, 3, 2)
+        p3_out = self.view("p3_out", H // 8, W // 8, c3)
+        self.c3k2("neck.pan_c3k2_1", View(pan1, 0, c2 + c3), p3_out, 1)
+        self.conv([("neck.down2", 0, View(pan2, 0, c3), 0)], p3_out.buf, c3, 3, 2)
+        p4_out = self.view("p4_out", H // 16, W // 16, c4)
+        self.c3k2("neck.pan_c3k2_2", View(pan2, 0, c3 + c4), p4_out, 1)
+
+        # Heads (model.py:361-365)
+        self.head("head_p2", p2_fused, outs["p2_cls"], outs["p2_reg"])
+        self.head("head_p3", p3_out, outs["p3_cls"], outs["p3_reg"])
+        self.head("head_p4", p4_out, outs["p4_cls"], outs["p4_reg"])
+
+    # ---- serialisation --------------------------------------------------------------------------
+    def tobytes(self) -> bytes:
+        g = self.g
+        out = bytearray()
+        out += _HDR.pack(MAGIC, VERSION, FP16, 3, g.in_h, g.in_w, g.num_classes, len(self.buffers), len(self.ops),
+                         3, *STRIDES, len(self.blob), g.macs())
+        for name, h, w, c, dtype, flags in self.buffers:
+            out += _BUF.pack(h, w, c, dtype, flags, name.encode()[:43])
+        for op in self.ops:
+            rec = bytearray(_OP_HEAD.pack(op.kind, op.k, op.s, op.relu, op.src_buf, op.cin,
+                                          op.res.buf if op.res else -1, op.res.coff if op.res else 0,
+                                          len(op.segs), op.in_hw[0], op.in_hw[1], op.out_hw[0], op.out_hw[1], 1.0))
+            for i in range(2):
+                if i < len(op.segs):
+                    s = op.segs[i]
+                    rec += _SEG.pack(s.src_coff, s.n_count, s.n_pad, s.dst.buf, s.dst.coff, s.flags,
+                                     s.w_off, s.b_off, 1.0, 1.0)
+                else:
+                    rec += b"\0" * _SEG.size
+            rec += op.name.encode()[:71].ljust(72, b"\0")
+            assert len(rec) == 256
+            out += rec
+        out += self.blob
+        return bytes(out)
+
+    def save(self, path: str) -> None:
+        with open(path, "wb") as f:
+            f.write(self.tobytes())
+
+
+def export_engine(sd: Dict[str, np.ndarray], path: str, graph: Optional[Graph] = None) -> EngineBuilder:
+    """state_dict (reference key names) -> engine file. Returns the builder (op table for inspection)."""
+    b = EngineBuilder(sd, graph)
+    b.save(path)
+    return b
+
+
+def read_engine_header(path: str) -> dict:
+    with open(path, "rb") as f:
+        raw = f.read(_HDR.size)
+    (magic, version, precision, in_c, in_h, in_w, nc, n_buf, n_ops, n_heads, s0, s1, s2, blob, macs) = _HDR.unpack(raw)
+    if magic != MAGIC:
+        raise ValueError("not a UNINAENG file")
+    return dict(version=version, precision=precision, in_c=in_c, in_h=in_h, in_w=in_w, num_classes=nc,
+                n_buffers=n_buf, n_ops=n_ops, n_heads=n_heads, strides=(s0, s1, s2), blob_bytes=blob, macs=macs)
