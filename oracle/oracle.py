@@ -98,7 +98,10 @@ class StateDict:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: module globals may already be gone
+            pass
 
 
 def forward(sd: StateDict, x: np.ndarray, num_classes: int = 4, base_channels: int = 32, lite_p2: bool = False,

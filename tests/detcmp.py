@@ -19,7 +19,8 @@ def iou_matrix(a, b):
 def compare(test, ref, conf_thr, min_iou=0.999, score_tol=1e-3, max_unmatched_frac=0.02):
     """Returns a dict of statistics; raises AssertionError on a violation."""
     if len(test) == 0 and len(ref) == 0:
-        return dict(matched=0, unmatched_test=0, unmatched_ref=0, min_iou=1.0, max_dscore=0.0)
+        return {"matched": 0, "unmatched_test": 0, "unmatched_ref": 0, "min_iou": 1.0, "max_dscore": 0.0,
+                "median_dscore": 0.0, "frac_iou_ge_0.999": 1.0}
     m = iou_matrix(test, ref) if len(test) and len(ref) else np.zeros((len(test), len(ref)))
     same = test["class_id"][:, None] == ref["class_id"][None, :] if len(test) and len(ref) else m.astype(bool)
     m = np.where(same, m, 0.0)
@@ -55,6 +56,8 @@ def compare(test, ref, conf_thr, min_iou=0.999, score_tol=1e-3, max_unmatched_fr
         assert excused(ref[j], test), f"reference detection {j} {ref[j]} was not reproduced and is not borderline"
     total = max(len(ref), 1)
     assert (len(un_t) + len(un_r)) / total <= max_unmatched_frac, (len(un_t), len(un_r), total)
+    ious = m[ti, rj] if len(pairs) else np.ones(1)
     return dict(matched=len(pairs), unmatched_test=len(un_t), unmatched_ref=len(un_r),
-                min_iou=float(m[ti, rj].min()) if len(pairs) else 1.0,
-                max_dscore=float(dscore.max()) if len(pairs) else 0.0)
+                min_iou=float(ious.min()), max_dscore=float(dscore.max()) if len(pairs) else 0.0,
+                median_dscore=float(np.median(dscore)) if len(pairs) else 0.0,
+                **{"frac_iou_ge_0.999": float((ious >= 0.999).mean())})
