@@ -132,6 +132,16 @@ int unina_get_op_info(const unina_engine_t *e, int index, unina_op_info *info);
  * after one warm-up); ms_per_op[i] = mean milliseconds of op i. Used by bench.py's roofline leg. */
 int unina_profile_ops(unina_engine_t *e, int iters, float *ms_per_op, hipStream_t stream);
 
+/* Tile-configuration control of the implicit-GEMM conv kernel (autotuning, tests). cfg = -1 restores the heuristic.
+ * Returns UNINA_ERR_UNSUPPORTED if the configuration does not fit the op's shape. */
+int unina_conv_config_count(void);
+const char *unina_conv_config_name(int cfg);
+int unina_set_op_config(unina_engine_t *e, int op_index, int cfg);
+/* Times every fitting configuration of every conv op (`iters` launches each, HIP events on `stream`) and keeps the
+ * fastest -- the engine-build "tactic selection" the reference leaves to TensorRT (export_trt.py:459-468).
+ * Needs "images" bound. Results are bit-identical under every configuration. */
+int unina_autotune(unina_engine_t *e, int iters, hipStream_t stream);
+
 /* Copies an internal activation buffer to the host as fp32 NCHW ([C,H,W]) -- parity tests only.
  * `name` is a buffer name from the engine file (e.g. "p3_fused"); returns UNINA_ERR_ARG if unknown. */
 int unina_debug_read_buffer(unina_engine_t *e, const char *name, float *host_out, size_t capacity_floats,

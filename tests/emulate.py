@@ -38,6 +38,7 @@ def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = Tr
             k = op.k
             for s in op.segs:
                 w = np.frombuffer(blob, dtype="<f2", count=s.n_pad * k * k * op.cin, offset=s.w_off)
+                w = export.unpack_weights(w, s.n_pad, k * k * op.cin)
                 w = torch.from_numpy(w.reshape(s.n_pad, k, k, op.cin)[:s.n_count].astype(np.float32)).permute(0, 3, 1, 2).contiguous()
                 b = torch.from_numpy(np.frombuffer(blob, dtype="<f4", count=s.n_count, offset=s.b_off).copy())
                 y = F.conv2d(src[s.src_coff:s.src_coff + op.cin][None], w, b, stride=op.s, padding=k // 2)[0]

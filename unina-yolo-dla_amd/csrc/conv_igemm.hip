@@ -1,4 +1,4 @@
-// conv_igemm.hip -- implicit-GEMM convolution on CDNA4 matrix cores (gfx950).
+// conv_igemm.hip -- implicit-GEMM convolution on CDNA4 matrix cores (gfx950), LDS-DMA pipelined.
 //
 // Computes, for every output pixel m and output channel n of a slice,
 //     y[m][n] = act( bias[n] + sum_{kh,kw,c} W[n][kh][kw][c] * x[pix(m,kh,kw)][c] )  (+ residual[m][n])
@@ -6,13 +6,22 @@
 // (unina_yolo_dla/model.py:23-50), the Bottleneck shortcut add (model.py:73), the head output convs
 // (model.py:292,299: bias, no activation, fp32 out) and the folded nearest-x2 Upsample (model.py:145-147).
 //
-// Mapping to MFMA (v_mfma_f32_16x16x32_f16): the WEIGHTS are the A operand (rows = output channels) and
-// the ACTIVATIONS the B operand (columns = pixels), i.e. D = W * X^T. Both operands are K-contiguous in
-// memory (weights [n][K], activations NHWC), so every lane's fragment is one 16-byte load, and the
-// accumulator comes out with 4 consecutive output CHANNELS of one pixel per lane -> 8-byte NHWC stores.
-//   A frag: lane l holds W[n0 + (l&15)][k0 + 8*(l>>4) .. +8)
-//   B frag: lane l holds X[m0 + (l&15)][k0 + 8*(l>>4) .. +8)
+// MFMA mapping (v_mfma_f32_16x16x32_f16): WEIGHTS are the A operand (rows = output channels), ACTIVATIONS the
+// B operand (columns = pixels): D = W * X^T. Both are K-contiguous in memory, so a lane's fragment is 16 bytes,
+// and the accumulator holds 4 consecutive output CHANNELS of one pixel per lane -> 8-byte NHWC stores.
+//   A frag: lane l = W[n0 + (l&15)][k0 + 8*(l>>4) .. +8)      B frag: lane l = X[m0 + (l&15)][k0 + 8*(l>>4) .. +8)
 //   D     : lane l, reg r  ->  channel n0 + 4*(l>>4) + r, pixel m0 + (l&15)
+//
+// Data movement: the K loop runs over (tap, 32*KSUB input channels). Every K-step's operands are staged in LDS as
+// 1-KiB "fragment blocks" (16 rows x 32 k, fp16) filled by ONE global_load_lds_dwordx4 wave-instruction each
+// (LDS-DMA: no VGPR round trip). Inside a block the 16-byte slot of (row r, k-chunk c) is
+//     slot(r,c) = 4*r + (c ^ G[r>>2]),  G = {0,2,3,1}
+// so that (a) the loading lane s = 4*r + c' fetches chunk c'^G[r>>2] of row r: the 4 lanes of a row still read one
+// contiguous 64-byte segment (quad-coalesced), and (b) each of ds_read_b128's four 16-lane groups touches 16
+// distinct 16-byte bank slots: conflict-free fragment reads. Weights are stored by the exporter already in this
+// block image (export.py: pack_weights), so their loads are fully linear. Out-of-image taps and tile tails read a
+// zero page instead of branching.
+// Pipeline: STAGES LDS buffers, STAGES-1 K-steps in flight, one s_barrier per K-step, counted s_waitcnt vmcnt.
 #include "kernels.h"
 
 namespace unina {
@@ -21,35 +30,113 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-template <int WAVES_M, int WAVES_N, int WM_T, int WN_T>
-__global__ __launch_bounds__(256) void conv_igemm_f16(const ConvParams p) {
-  constexpr int BM = WAVES_M * WM_T * 16;
-  constexpr int BN = WAVES_N * WN_T * 16;
+namespace {
+
+__device__ __forceinline__ int swz_g(int r16) { return (0x78 >> (2 * (r16 >> 2))) & 3; }  // G = {0,2,3,1}
+
+__device__ __forceinline__ void glds16(const void* gptr, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+}  // namespace
+
+extern __shared__ __align__(16) unsigned char conv_smem[];
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(256) void conv_glds_f16(const ConvParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "256-thread blocks");
+  constexpr int WM_T = BM / (WAVES_M * 16), WN_T = BN / (WAVES_N * 16), KSUB = BK / 32;
+  constexpr int ABLK = (BM / 16) * KSUB, WBLK = (BN / 16) * KSUB, NBLK = ABLK + WBLK;
+  constexpr int LPT = (NBLK + 3) / 4;            // LDS-DMA instructions per wave per stage (same for every wave)
+  constexpr int STAGE_BYTES = LPT * 4 * 1024;
+  static_assert(WM_T >= 1 && WN_T >= 1 && KSUB >= 1, "tile");
+
   const int lane = threadIdx.x & 63;
-  const int wid = threadIdx.x >> 6;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wid % WAVES_M, wn = wid / WAVES_M;
   const int l15 = lane & 15, lq = lane >> 4;
 
   const int sidx = (p.nseg > 1 && (int)blockIdx.y >= p.seg[1].tile0) ? 1 : 0;
   const ConvSeg& sg = p.seg[sidx];
   const int n_pad = (sg.n_count + 15) & ~15;
-  const int n0 = ((int)blockIdx.y - sg.tile0) * BN + wn * (WN_T * 16);
-  if (n0 >= n_pad) return;  // no barriers in this kernel: a wave with no channels may leave
+  const int nb0 = ((int)blockIdx.y - sg.tile0) * BN;  // first channel of this block's tile (slice-relative)
+  const int m_blk = blockIdx.x * BM;
+  const int kblocks = p.ksize * p.ksize * (p.Cin / 32);  // 32-wide k blocks per weight row
 
-  const int K = p.ksize * p.ksize * p.Cin;
-  const int m_base = blockIdx.x * BM + wm * (WM_T * 16);
-
-  int oy[WM_T], ox[WM_T];
-  bool mvalid[WM_T];
+  // ---- per-thread description of the LPT blocks this wave loads every stage (block b = q*4 + wid) ----
+  // activation block (i,j): rows = pixels m_blk + 16*i .. +16, k = 32*j .. +32 of the K-step
+  // weight block     (n,j): rows = channels nb0 + 16*n .. +16
+  const int ld_row = lane >> 2;                                  // row (pixel / channel) this lane fetches
+  const int ld_chunk = (lane & 3) ^ swz_g(ld_row);              // 8-element k-chunk this lane fetches
+  int a_iy0[LPT], a_ix0[LPT];                                    // input coords of tap (0,0), or big negative if row invalid
+  const half_t* a_base[LPT];                                     // src + channel offset of this lane's chunk
+  const half_t* w_base[LPT];                                     // weight block address for k32 = 0 (nullptr = zero rows)
+  int kind[LPT];                                                 // 0 activation, 1 weight, 2 padding
 #pragma unroll
-  for (int i = 0; i < WM_T; ++i) {
-    const int m = m_base + i * 16 + l15;
-    mvalid[i] = m < p.M;
-    const int mm = mvalid[i] ? m : 0;
-    oy[i] = mm / p.Wo;
-    ox[i] = mm - oy[i] * p.Wo;
+  for (int q = 0; q < LPT; ++q) {
+    const int b = q * 4 + wid;
+    a_iy0[q] = a_ix0[q] = -(1 << 20);
+    a_base[q] = nullptr;
+    w_base[q] = nullptr;
+    if (b < ABLK) {
+      kind[q] = 0;
+      const int i = b / KSUB, j = b - i * KSUB;
+      const int m = m_blk + i * 16 + ld_row;
+      if (m < p.M) {
+        const int oy = m / p.Wo, ox = m - oy * p.Wo;
+        a_iy0[q] = oy * p.stride - p.pad;
+        a_ix0[q] = ox * p.stride - p.pad;
+      }
+      a_base[q] = p.src + sg.src_coff + j * 32 + ld_chunk * 8;
+    } else if (b < NBLK) {
+      kind[q] = 1;
+      const int bb = b - ABLK;
+      const int n = bb / KSUB, j = bb - n * KSUB;
+      const int nsub = (nb0 >> 4) + n;
+      if (nsub * 16 < n_pad) w_base[q] = sg.w + ((size_t)nsub * kblocks + j) * 512 + lane * 8;
+    } else {
+      kind[q] = 2;
+    }
   }
+
+  // K-step iterator for the NEXT stage to issue
+  int i_kh = 0, i_kw = 0, i_c0 = 0, i_k32 = 0, i_kt = 0;
+  const int nk = p.ksize * p.ksize * (p.Cin / BK);
+  const half_t* zeros = reinterpret_cast<const half_t*>(p.zeros);
+
+  auto issue = [&](int buf) {
+    unsigned char* sb = conv_smem + buf * STAGE_BYTES;
+    const bool live = i_kt < nk;
+#pragma unroll
+    for (int q = 0; q < LPT; ++q) {
+      const half_t* g = zeros;
+      if (live) {
+        if (kind[q] == 0) {
+          const int iy = a_iy0[q] + i_kh, ix = a_ix0[q] + i_kw;
+          if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) g = a_base[q] + (size_t)(iy * p.W + ix) * p.src_ld + i_c0;
+        } else if (kind[q] == 1) {
+          if (w_base[q]) g = w_base[q] + (size_t)i_k32 * 512;
+        }
+      }
+      glds16(g, sb + (q * 4 + wid) * 1024);
+    }
+    ++i_kt;
+    i_c0 += BK;
+    i_k32 += KSUB;
+    if (i_c0 >= p.Cin) {
+      i_c0 = 0;
+      if (++i_kw == p.ksize) {
+        i_kw = 0;
+        ++i_kh;
+      }
+    }
+  };
 
   floatx4 acc[WN_T][WM_T];
 #pragma unroll
@@ -57,52 +144,43 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < WM_T; ++i) acc[j][i] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  const half_t* wrow[WN_T];
-  bool nvalid[WN_T];
+  // ---- prologue: STAGES-1 K-steps in flight (steps past the end are all-zero dummies: counts stay uniform) ----
 #pragma unroll
-  for (int j = 0; j < WN_T; ++j) {
-    nvalid[j] = (n0 + j * 16) < n_pad;  // wave-uniform
-    wrow[j] = sg.w + (size_t)(n0 + j * 16 + l15) * K + lq * 8;
-  }
-  const half_t* src = p.src + sg.src_coff + lq * 8;
-  const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < STAGES - 1; ++s) issue(s);
 
-  int kbase = 0;
-  for (int kh = 0; kh < p.ksize; ++kh) {
-    for (int kw = 0; kw < p.ksize; ++kw) {
-      const half_t* px[WM_T];
-      bool pvalid[WM_T];
+  const int rd_off = (4 * l15 + (lq ^ swz_g(l15))) * 16;  // this lane's fragment slot inside any block
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<(STAGES - 2) * LPT>();   // this wave's loads of step kt have landed
+    __builtin_amdgcn_s_barrier();       // ... and everyone's; everyone is also done reading buffer (kt-1)%STAGES
+    issue((kt + STAGES - 1) % STAGES);  // refill the buffer freed by step kt-1
+    const unsigned char* sb = conv_smem + (kt % STAGES) * STAGE_BYTES + rd_off;
 #pragma unroll
-      for (int i = 0; i < WM_T; ++i) {
-        const int iy = oy[i] * p.stride + kh - p.pad;
-        const int ix = ox[i] * p.stride + kw - p.pad;
-        pvalid[i] = mvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        px[i] = src + (size_t)(pvalid[i] ? (iy * p.W + ix) : 0) * p.src_ld;
-      }
-      for (int c0 = 0; c0 < p.Cin; c0 += 32, kbase += 32) {
-        half8 a[WN_T], b[WM_T];
+    for (int j = 0; j < KSUB; ++j) {
+      half8 a[WN_T], b[WM_T];
 #pragma unroll
-        for (int j = 0; j < WN_T; ++j) a[j] = nvalid[j] ? *reinterpret_cast<const half8*>(wrow[j] + kbase) : zero8;
+      for (int i = 0; i < WM_T; ++i) b[i] = *reinterpret_cast<const half8*>(sb + (((wm * WM_T + i) * KSUB + j) << 10));
 #pragma unroll
-        for (int i = 0; i < WM_T; ++i) b[i] = pvalid[i] ? *reinterpret_cast<const half8*>(px[i] + c0) : zero8;
+      for (int n = 0; n < WN_T; ++n) a[n] = *reinterpret_cast<const half8*>(sb + ((ABLK + (wn * WN_T + n) * KSUB + j) << 10));
 #pragma unroll
-        for (int j = 0; j < WN_T; ++j)
+      for (int n = 0; n < WN_T; ++n)
 #pragma unroll
-          for (int i = 0; i < WM_T; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[i], acc[j][i], 0, 0, 0);
-      }
+        for (int i = 0; i < WM_T; ++i) acc[n][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[n], b[i], acc[n][i], 0, 0, 0);
     }
   }
+  wait_vmcnt<0>();  // drain the dummy tail before the wave retires
 
   // ---- epilogue: bias, ReLU, residual (after the ReLU: model.py:72-73), store ----
+  const int n_w0 = nb0 + wn * (WN_T * 16);
+  const int m_w0 = m_blk + wm * (WM_T * 16);
 #pragma unroll
   for (int j = 0; j < WN_T; ++j) {
-    const int n = n0 + j * 16 + lq * 4;  // first of this lane's 4 consecutive channels (slice-relative)
-    if (!nvalid[j] || n >= sg.n_count) continue;
+    const int n = n_w0 + j * 16 + lq * 4;  // first of this lane's 4 consecutive channels (slice-relative)
+    if (n >= sg.n_count) continue;
     const floatx4 bias = *reinterpret_cast<const floatx4*>(sg.bias + n);
 #pragma unroll
     for (int i = 0; i < WM_T; ++i) {
-      if (!mvalid[i]) continue;
-      const int m = m_base + i * 16 + l15;
+      const int m = m_w0 + i * 16 + l15;
+      if (m >= p.M) continue;
       floatx4 v = acc[j][i] + bias;
       if (p.relu) {
 #pragma unroll
@@ -122,7 +200,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(const ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) hv[r] = (half_t)v[r];
         if (sg.up2) {
-          const size_t row = (size_t)(2 * oy[i]) * (2 * p.Wo) + 2 * ox[i];
+          const int oy = m / p.Wo, ox = m - oy * p.Wo;
+          const size_t row = (size_t)(2 * oy) * (2 * p.Wo) + 2 * ox;
           half_t* d = sg.dst + row * sg.dst_ld + n;
           *reinterpret_cast<half4*>(d) = hv;
           *reinterpret_cast<half4*>(d + sg.dst_ld) = hv;
@@ -136,36 +215,102 @@ __global__ __launch_bounds__(256) void conv_igemm_f16(const ConvParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- launch side
 namespace {
+
 struct CfgInfo {
-  int bm, bn;
+  int bm, bn, bk, stages;
   const char* name;
+  void (*fn)(const ConvParams);
+  size_t smem;
 };
+
+template <int BM, int BN, int BK, int WM, int WN, int ST>
+constexpr size_t smem_of() {
+  return (size_t)ST * (((BM / 16 + BN / 16) * (BK / 32) + 3) / 4) * 4 * 1024;
+}
+
+#define CFG(BM, BN, BK, WM, WN, ST)                                                             \
+  {BM, BN, BK, ST, "conv_glds_f16<" #BM "," #BN "," #BK "," #WM "," #WN "," #ST ">",            \
+   conv_glds_f16<BM, BN, BK, WM, WN, ST>, smem_of<BM, BN, BK, WM, WN, ST>()}
+
 const CfgInfo kCfg[kCfgCount] = {
-    {64, 64, "conv_igemm_f16<2,2,2,2>"},
-    {128, 32, "conv_igemm_f16<4,1,2,2>"},
-    {128, 16, "conv_igemm_f16<4,1,2,1>"},
+    CFG(64, 64, 64, 2, 2, 4),    // kCfg64x64k64
+    CFG(64, 64, 32, 2, 2, 4),    // kCfg64x64k32
+    CFG(128, 64, 64, 2, 2, 3),   // kCfg128x64k64
+    CFG(128, 64, 32, 2, 2, 4),   // kCfg128x64k32
+    CFG(128, 128, 64, 2, 2, 3),  // kCfg128x128k64
+    CFG(128, 32, 64, 4, 1, 3),   // kCfg128x32k64
+    CFG(128, 32, 32, 4, 1, 4),   // kCfg128x32k32
+    CFG(128, 16, 64, 4, 1, 3),   // kCfg128x16k64
+    CFG(32, 64, 64, 1, 4, 4),    // kCfg32x64k64
 };
+#undef CFG
+
+int n_tiles(const ConvParams& p, int bn) {
+  int t = 0;
+  for (int s = 0; s < p.nseg; ++s) t += (((p.seg[s].n_count + 15) & ~15) + bn - 1) / bn;
+  return t;
+}
+
 }  // namespace
 
-ConvLaunch conv_plan(const ConvParams& p) {
+hipError_t conv_init() {
+  for (int c = 0; c < kCfgCount; ++c) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kCfg[c].fn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCfg[c].smem);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+bool conv_config_valid(const ConvParams& p, int cfg) {
+  if (cfg < 0 || cfg >= kCfgCount) return false;
+  const CfgInfo& c = kCfg[cfg];
+  if (p.Cin % c.bk) return false;
   int min_npad = 1 << 30;
   for (int s = 0; s < p.nseg; ++s) {
     const int np = (p.seg[s].n_count + 15) & ~15;
     if (np < min_npad) min_npad = np;
   }
+  return c.bn <= min_npad || (c.bn == 16);
+}
+
+ConvLaunch conv_plan_with(const ConvParams& p, int cfg) {
+  const CfgInfo& c = kCfg[cfg];
   ConvLaunch l;
-  l.cfg = min_npad >= 64 ? kCfg64x64 : (min_npad >= 32 ? kCfg128x32 : kCfg128x16);
-  const CfgInfo& c = kCfg[l.cfg];
-  int ntiles = 0;
-  for (int s = 0; s < p.nseg; ++s) ntiles += (((p.seg[s].n_count + 15) & ~15) + c.bn - 1) / c.bn;
-  l.grid = dim3((p.M + c.bm - 1) / c.bm, ntiles, 1);
+  l.cfg = (ConvConfig)cfg;
+  l.grid = dim3((p.M + c.bm - 1) / c.bm, n_tiles(p, c.bn), 1);
   l.block = dim3(256, 1, 1);
   l.kernel_name = c.name;
   return l;
 }
 
-// fills seg[].tile0 for the chosen config (the caller's params are const: work on a copy)
+// Heuristic: the widest tile that still yields >= ~1.5 workgroups per CU (256 CUs), K-step 64 when Cin allows.
+ConvLaunch conv_plan(const ConvParams& p) {
+  const int override_cfg = p.force_cfg;
+  if (override_cfg >= 0 && conv_config_valid(p, override_cfg)) return conv_plan_with(p, override_cfg);
+  const bool k64 = (p.Cin % 64) == 0;
+  int min_npad = 1 << 30;
+  for (int s = 0; s < p.nseg; ++s) {
+    const int np = (p.seg[s].n_count + 15) & ~15;
+    if (np < min_npad) min_npad = np;
+  }
+  int cfg;
+  if (min_npad < 32) cfg = kCfg128x16k64;
+  else if (min_npad < 64) cfg = k64 ? kCfg128x32k64 : kCfg128x32k32;
+  else {
+    auto blocks = [&](int c) { return ((p.M + kCfg[c].bm - 1) / kCfg[c].bm) * n_tiles(p, kCfg[c].bn); };
+    const int want = 384;
+    if (k64 && min_npad >= 128 && blocks(kCfg128x128k64) >= want) cfg = kCfg128x128k64;
+    else if (blocks(k64 ? kCfg128x64k64 : kCfg128x64k32) >= want) cfg = k64 ? kCfg128x64k64 : kCfg128x64k32;
+    else if (!k64 || blocks(kCfg64x64k64) >= want || p.M % 64) cfg = k64 ? kCfg64x64k64 : kCfg64x64k32;
+    else cfg = kCfg32x64k64;
+  }
+  if (!conv_config_valid(p, cfg)) cfg = k64 ? kCfg64x64k64 : kCfg64x64k32;
+  return conv_plan_with(p, cfg);
+}
+
 hipError_t conv_launch(const ConvParams& pin, const ConvLaunch& l, hipStream_t stream) {
   ConvParams p = pin;
   const CfgInfo& c = kCfg[l.cfg];
@@ -174,20 +319,10 @@ hipError_t conv_launch(const ConvParams& pin, const ConvLaunch& l, hipStream_t s
     p.seg[s].tile0 = t;
     t += (((p.seg[s].n_count + 15) & ~15) + c.bn - 1) / c.bn;
   }
-  switch (l.cfg) {
-    case kCfg64x64:
-      conv_igemm_f16<2, 2, 2, 2><<<l.grid, l.block, 0, stream>>>(p);
-      break;
-    case kCfg128x32:
-      conv_igemm_f16<4, 1, 2, 2><<<l.grid, l.block, 0, stream>>>(p);
-      break;
-    case kCfg128x16:
-      conv_igemm_f16<4, 1, 2, 1><<<l.grid, l.block, 0, stream>>>(p);
-      break;
-    default:
-      return hipErrorInvalidValue;
-  }
+  hipLaunchKernelGGL(c.fn, l.grid, l.block, c.smem, stream, p);
   return hipGetLastError();
 }
+
+const char* conv_config_name(int cfg) { return (cfg >= 0 && cfg < kCfgCount) ? kCfg[cfg].name : "?"; }
 
 }  // namespace unina

@@ -56,6 +56,8 @@ struct unina_engine {
   std::vector<PlannedOp> ops;
   void* d_blob = nullptr;
   void* d_arena = nullptr;
+  void* d_zeros = nullptr;          // zero page read by out-of-image taps
+  std::vector<int> force_cfg;       // per-op tile configuration override (-1 = heuristic)
   int images_buf = -1;
   int out_buf[6] = {-1, -1, -1, -1, -1, -1};
   // post-process workspace
@@ -130,6 +132,8 @@ int plan(unina_engine* e) {
         p.res_ld = (int)rb.d.c;
       }
       p.nseg = (int)d.nseg;
+      p.zeros = e->d_zeros;
+      p.force_cfg = i < e->force_cfg.size() ? e->force_cfg[i] : -1;
       int ntot = 0;
       double out_bytes = 0;
       for (int s = 0; s < p.nseg; ++s) {
@@ -181,8 +185,8 @@ int plan(unina_engine* e) {
       info.m = p.Ho * p.Wo; info.n = p.Co; info.k = 27;
       info.flops = 2.0 * info.m * info.n * 27;
       info.bytes = 4.0 * 3 * p.H * p.W + 2.0 * info.m * p.Co;
-      snprintf(info.kernel, sizeof info.kernel, "stem_conv_kernel");
-      info.grid = (info.m + (256 / (p.Co / 8)) - 1) / (256 / (p.Co / 8));
+      snprintf(info.kernel, sizeof info.kernel, "stem_conv_kernel<%d>", p.Co);
+      info.grid = (info.m + 255) / 256;
       info.block = 256;
     } else if (d.kind == kOpSppfPool) {
       PoolParams& p = op.pp;
@@ -367,6 +371,9 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   size_t arena = 0;
   for (auto& b : e->bufs)
     if (!(b.d.flags & kBufInput)) arena += (b.bytes + 255) & ~(size_t)255;
+  LOADCHK(conv_init());
+  LOADCHK(hipMalloc(&e->d_zeros, 256));
+  LOADCHK(hipMemset(e->d_zeros, 0, 256));
   LOADCHK(hipMalloc(&e->d_arena, arena ? arena : 256));
   LOADCHK(hipMemset(e->d_arena, 0, arena ? arena : 256));
   size_t off = 0;
@@ -405,7 +412,7 @@ void unina_unload_engine(unina_engine_t* e) {
   (void)hipSetDevice(e->device);
   drop_graph(e);
   if (e->capture_stream) (void)hipStreamDestroy(e->capture_stream);
-  void* dev[] = {e->d_blob, e->d_arena, e->d_cand, e->d_block_count, e->d_ticket, e->d_result};
+  void* dev[] = {e->d_blob, e->d_arena, e->d_zeros, e->d_cand, e->d_block_count, e->d_ticket, e->d_result};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (e->h_result) (void)hipHostFree(e->h_result);
@@ -513,6 +520,68 @@ int unina_get_op_info(const unina_engine_t* ce, int index, unina_op_info* info) 
     if (rc != UNINA_OK) return rc;
   }
   *info = e->ops[index].info;
+  return UNINA_OK;
+}
+
+int unina_conv_config_count(void) { return (int)kCfgCount; }
+
+const char* unina_conv_config_name(int cfg) { return conv_config_name(cfg); }
+
+int unina_set_op_config(unina_engine_t* e, int op_index, int cfg) {
+  if (!e || op_index < 0 || op_index >= (int)e->ops.size()) return UNINA_ERR_ARG;
+  if (e->plan_dirty) {
+    int rc = plan(e);
+    if (rc != UNINA_OK) return rc;
+  }
+  if (e->ops[op_index].d.kind != kOpConv) return fail(e, UNINA_ERR_ARG, "op %d is not a convolution", op_index);
+  if (cfg >= 0 && !conv_config_valid(e->ops[op_index].cp, cfg)) return fail(e, UNINA_ERR_UNSUPPORTED, "config %d does not fit op %d", cfg, op_index);
+  if (e->force_cfg.size() < e->ops.size()) e->force_cfg.assign(e->ops.size(), -1);
+  e->force_cfg[op_index] = cfg;
+  e->plan_dirty = true;
+  return UNINA_OK;
+}
+
+// Tactic selection by timing, like the reference's TensorRT build step (export_trt.py:459-468) does on the target:
+// every conv op is timed with every tile configuration that fits it and keeps the fastest. Results do not change
+// (each output element accumulates its K terms in the same order under every configuration).
+int unina_autotune(unina_engine_t* e, int iters, hipStream_t stream) {
+  if (!e || iters < 1) return UNINA_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->bufs[e->images_buf].ptr) return fail(e, UNINA_ERR_STATE, "tensor 'images' is not bound");
+  if (e->plan_dirty) {
+    int rc = plan(e);
+    if (rc != UNINA_OK) return rc;
+  }
+  int rc = launch_all(e, stream);
+  if (rc != UNINA_OK) return rc;
+  if (e->force_cfg.size() < e->ops.size()) e->force_cfg.assign(e->ops.size(), -1);
+  hipEvent_t a, b;
+  HIPCHK(e, hipEventCreate(&a));
+  HIPCHK(e, hipEventCreate(&b));
+  for (size_t i = 0; i < e->ops.size(); ++i) {
+    if (e->ops[i].d.kind != kOpConv) continue;
+    float best = 1e30f;
+    int best_cfg = -1;
+    for (int cfg = 0; cfg < (int)kCfgCount; ++cfg) {
+      if (!conv_config_valid(e->ops[i].cp, cfg)) continue;
+      const ConvLaunch l = conv_plan_with(e->ops[i].cp, cfg);
+      HIPCHK(e, conv_launch(e->ops[i].cp, l, stream));
+      HIPCHK(e, hipEventRecord(a, stream));
+      for (int it = 0; it < iters; ++it) HIPCHK(e, conv_launch(e->ops[i].cp, l, stream));
+      HIPCHK(e, hipEventRecord(b, stream));
+      HIPCHK(e, hipEventSynchronize(b));
+      float ms = 0.f;
+      HIPCHK(e, hipEventElapsedTime(&ms, a, b));
+      if (ms < best) {
+        best = ms;
+        best_cfg = cfg;
+      }
+    }
+    e->force_cfg[i] = best_cfg;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  e->plan_dirty = true;
   return UNINA_OK;
 }
 

@@ -9,7 +9,7 @@
 namespace unina {
 
 constexpr char kMagic[8] = {'U', 'N', 'I', 'N', 'A', 'E', 'N', 'G'};
-constexpr uint32_t kVersion = 1;
+constexpr uint32_t kVersion = 2;  // 2: conv weights stored as swizzled 1-KiB fragment blocks
 
 enum Precision : uint32_t { kFp16 = 0, kInt8 = 1 };
 enum BufDtype : uint32_t { kBufF16Nhwc = 0, kBufF32Planar = 1, kBufF32NchwInput = 2, kBufI8Nhwc = 3 };
@@ -47,7 +47,8 @@ struct SegDesc {             // 64 bytes: one slice of an op's output-channel (N
   uint32_t n_pad;            // rows stored in the weight matrix (n_count rounded up to 16, zero rows)
   uint32_t dst_buf, dst_coff;
   uint32_t flags;            // SegFlags
-  uint64_t w_off;            // blob offset: fp16 [n_pad][K], K ordered (kh, kw, cin); stem: fp32 [n][27] ordered (c,kh,kw)
+  uint64_t w_off;            // blob offset: conv: fp16 fragment blocks [n_pad/16][K/32][64][8], K = (kh,kw,cin) (export.py pack_weights);
+                             //              stem: fp32 [n][27] ordered (c,kh,kw)
   uint64_t b_off;            // blob offset: fp32 [n_pad] folded bias
   float w_scale, out_scale;  // int8 engines only
   uint8_t reserved[16];

@@ -16,7 +16,7 @@ typedef _Float16 half_t;
 // One launch covers up to two output-channel slices (merged sibling convs / two-group head layers).
 // ------------------------------------------------------------------------------------------------
 struct ConvSeg {
-  const half_t* w;     // [n_pad][K]
+  const half_t* w;     // packed 1-KiB fragment blocks [n_pad/16][K/32][64 slots][8] (export.py: pack_weights)
   const float* bias;   // [n_pad]
   half_t* dst;         // NHWC fp16 destination, channel offset already applied (unused when planar)
   float* dst_planar;   // fp32 [n][Ho*Wo] destination (head outputs), or nullptr
@@ -38,16 +38,25 @@ struct ConvParams {
   int res_ld;
   int nseg;
   ConvSeg seg[2];
+  const void* zeros;   // >= 16 bytes of zeros in HBM: source of out-of-image taps / tile tails
+  int force_cfg;       // >= 0: use this tile configuration (autotuner / tests); -1: heuristic
 };
 
-// tile configurations of the conv kernel (block tile = BM pixels x BN output channels)
-enum ConvConfig : int { kCfg64x64 = 0, kCfg128x32 = 1, kCfg128x16 = 2, kCfgCount };
+// tile configurations of the conv kernel: block tile = BM pixels x BN output channels, K-step BK
+enum ConvConfig : int {
+  kCfg64x64k64 = 0, kCfg64x64k32, kCfg128x64k64, kCfg128x64k32, kCfg128x128k64,
+  kCfg128x32k64, kCfg128x32k32, kCfg128x16k64, kCfg32x64k64, kCfgCount
+};
 struct ConvLaunch {
   ConvConfig cfg;
   dim3 grid, block;
   const char* kernel_name;
 };
-ConvLaunch conv_plan(const ConvParams& p);
+hipError_t conv_init();                                  // once per process: raise the dynamic-LDS limit of every instantiation
+bool conv_config_valid(const ConvParams& p, int cfg);
+ConvLaunch conv_plan(const ConvParams& p);               // heuristic (or p.force_cfg)
+ConvLaunch conv_plan_with(const ConvParams& p, int cfg);
+const char* conv_config_name(int cfg);
 hipError_t conv_launch(const ConvParams& p, const ConvLaunch& l, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------

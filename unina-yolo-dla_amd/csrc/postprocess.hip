@@ -22,8 +22,9 @@
 //
 // Structure of (1): every block decodes 1024 cells and writes its survivors, in order, to its own segment of
 // the workspace; the block that draws the last arrival ticket (agent-scope release/acquire hand-off) gathers
-// the segments in enumeration order, sorts in LDS (bitonic, 64-bit keys), runs the NMS with 64x1024-bit
-// suppression masks per 64-row chunk, and compacts with wave ballots.
+// the segments in enumeration order, rank-sorts them in LDS (64-bit keys), builds the upper-triangular
+// suppression bitmap with broadcast LDS reads (16 waves x 64x64-bit tiles), scans it greedily, and compacts
+// with wave ballots.
 // Built with -ffp-contract=off: the box arithmetic must round exactly like the reference's scalar code.
 #include "kernels.h"
 
@@ -37,33 +38,25 @@ constexpr int kT = kPostBlock;  // threads per block == cells per block
 constexpr int kWaves = kT / 64;
 constexpr int kMaxDet = MAX_DETECTIONS;
 constexpr int kWords = kMaxDet / 64;
+constexpr int kTriWords = 64 * (kWords * (kWords + 1) / 2);  // upper-triangular 64x64-bit tiles, worst case
 
+// All LDS of the post-process kernels lives in ONE dynamic array carved into this struct (108 KiB).
 struct Smem {
-  int scan[kT + 1];                  // block-count prefix (exclusive)
-  unsigned long long keys[kMaxDet];  // (conf bits << 32) | (0xFFFFFFFF - gathered position)
-  float x1[kMaxDet], y1[kMaxDet], x2[kMaxDet], y2[kMaxDet], conf[kMaxDet];
-  int cls[kMaxDet];
-  unsigned long long mask[64][kWords];
+  int scan[kT + 8];                   // block-count prefix (exclusive)
+  unsigned long long keys[kMaxDet];   // (conf bits << 32) | (0xFFFFFFFF - enumeration position)
+  float4 box[kMaxDet];                // x1,y1,x2,y2   (enumeration order, then sorted order)
+  float2 cc[kMaxDet];                 // confidence, class id (bit pattern)
+  unsigned long long mask[kTriWords]; // suppression bits: tile (c,w>=c), row r  ->  mask[tri(c) + r*(nw-c) + (w-c)]
+  unsigned long long rownz[kWords];   // per 64-row chunk: rows with a non-empty mask
   unsigned long long removed[kWords];
-  unsigned long long rownz;
   int wave_cnt[kWaves];
   int hist[256];
   int is_last;
   int misc[4];
 };
+constexpr size_t kPostSmemBytes = sizeof(Smem);
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-__device__ __forceinline__ float iou_eps(float ax1, float ay1, float ax2, float ay2, float bx1, float by1, float bx2,
-                                         float by2) {
-  const float ix1 = fmaxf(ax1, bx1), iy1 = fmaxf(ay1, by1);
-  const float ix2 = fminf(ax2, bx2), iy2 = fminf(ay2, by2);
-  if (ix1 >= ix2 || iy1 >= iy2) return 0.0f;
-  const float inter = (ix2 - ix1) * (iy2 - iy1);
-  const float area_a = (ax2 - ax1) * (ay2 - ay1);
-  const float area_b = (bx2 - bx1) * (by2 - by1);
-  return inter / (area_a + area_b - inter + 1e-6f);
-}
 
 // exclusive prefix of a 0/1 flag over the block, in thread order; returns this thread's offset, total in *total
 __device__ __forceinline__ int block_rank(bool flag, Smem& s, int* total) {
@@ -144,19 +137,26 @@ __device__ __forceinline__ bool arrive_and_check_last(unsigned int* ticket, Smem
   return true;
 }
 
-// exclusive prefix of block_count[0..nblocks) into s.scan[0..nblocks]; returns the total
+// exclusive prefix of block_count[0..nblocks) into s.scan[0..nblocks]; returns the total. nblocks <= kT.
 __device__ __forceinline__ int scan_block_counts(const int* block_count, int nblocks, Smem& s) {
   const int tid = threadIdx.x;
-  const int v = tid < nblocks ? __hip_atomic_load(block_count + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-  s.scan[tid + 1] = v;
-  if (tid == 0) s.scan[0] = 0;
-  __syncthreads();
-  for (int off = 1; off < kT; off <<= 1) {
-    const int add = (tid + 1 > off) ? s.scan[tid + 1 - off] : 0;
-    __syncthreads();
-    s.scan[tid + 1] += add;
-    __syncthreads();
+  if (tid < 64) {  // one wave: serial over 64-entry chunks, shuffle scan inside a chunk
+    int carry = 0;
+    for (int base = 0; base < nblocks; base += 64) {
+      const int i = base + tid;
+      const int v = i < nblocks ? __hip_atomic_load(block_count + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      int incl = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (tid >= off) incl += t;
+      }
+      if (i < nblocks) s.scan[i] = carry + incl - v;
+      carry += __shfl(incl, 63);
+    }
+    if (tid == 0) s.scan[nblocks] = carry;
   }
+  __syncthreads();
   return s.scan[nblocks];
 }
 
@@ -171,85 +171,119 @@ __device__ __forceinline__ const GpuDetection* cand_at(const GpuDetection* cand,
 }
 
 __device__ __forceinline__ void put(Smem& s, int pos, const GpuDetection* c) {
-  s.x1[pos] = c->x1; s.y1[pos] = c->y1; s.x2[pos] = c->x2; s.y2[pos] = c->y2;
-  s.conf[pos] = c->confidence; s.cls[pos] = c->class_id;
+  s.box[pos] = make_float4(c->x1, c->y1, c->x2, c->y2);
+  s.cc[pos] = make_float2(c->confidence, __int_as_float(c->class_id));
 }
 
-__device__ __forceinline__ int gathered_pos(const Smem& s, int i) {
-  return (int)(0xFFFFFFFFu - (unsigned int)(s.keys[i] & 0xFFFFFFFFull));
+__device__ __forceinline__ GpuDetection get(const Smem& s, int pos, int valid) {
+  GpuDetection d;
+  const float4 b = s.box[pos];
+  const float2 c = s.cc[pos];
+  d.x1 = b.x; d.y1 = b.y; d.x2 = b.z; d.y2 = b.w;
+  d.confidence = c.x;
+  d.class_id = __float_as_int(c.y);
+  d.valid = valid;
+  d._pad = 0;
+  return d;
 }
 
-// Records 0..n) are in s.{x1..cls} in enumeration order. Stable sort by confidence (descending) and greedy NMS.
-// On return (after a barrier) s.keys holds the sorted order and s.removed the suppression bits by SORTED index.
+__device__ __forceinline__ int tri_off(int c, int nw) { return 64 * (c * nw - (c * (c - 1)) / 2); }
+
+// Records 0..n) sit in s.box / s.cc in enumeration order. On return they are in SORTED order (confidence
+// descending, ties by enumeration order) and s.removed holds the greedy-NMS suppression bits by sorted index.
+//   sort : rank sort -- thread i counts the keys larger than its own with broadcast LDS reads (no barriers)
+//   masks: the upper-triangular 64x64 tiles are dealt round-robin to the 16 waves; lane = row, the 64 columns of
+//          a tile are visited in lock-step so every LDS read is a broadcast; the division only runs for pairs
+//          that really overlap
+//   scan : wave 0 walks the chunks in order and visits only rows that suppress something
 __device__ void sort_and_nms(Smem& s, int n, float iou_thr) {
   const int tid = threadIdx.x;
-  int np2 = 1;
-  while (np2 < n) np2 <<= 1;
-  if (tid < np2)
-    s.keys[tid] = tid < n ? (((unsigned long long)__float_as_uint(s.conf[tid]) << 32) | (0xFFFFFFFFu - (unsigned)tid)) : 0ull;
+  const int lane = tid & 63, wid = tid >> 6;
+  if (tid < n) s.keys[tid] = ((unsigned long long)__float_as_uint(s.cc[tid].x) << 32) | (0xFFFFFFFFu - (unsigned)tid);
   __syncthreads();
-  for (int k = 2; k <= np2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const int partner = tid ^ j;
-      if (tid < np2 && partner > tid) {
-        const unsigned long long a = s.keys[tid], b = s.keys[partner];
-        const bool desc = (tid & k) == 0;
-        if (desc ? (a < b) : (a > b)) {
-          s.keys[tid] = b;
-          s.keys[partner] = a;
-        }
-      }
-      __syncthreads();
+  float4 mybox;
+  float2 mycc;
+  int rank = 0;
+  if (tid < n) {
+    const unsigned long long mine = s.keys[tid];
+    mybox = s.box[tid];
+    mycc = s.cc[tid];
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {
+      rank += (s.keys[j] > mine) + (s.keys[j + 1] > mine) + (s.keys[j + 2] > mine) + (s.keys[j + 3] > mine);
     }
+    for (; j < n; ++j) rank += s.keys[j] > mine;
   }
+  __syncthreads();
+  if (tid < n) {
+    s.box[rank] = mybox;
+    s.cc[rank] = mycc;
+  }
+  if (tid < kWords) s.rownz[tid] = 0ull;
+  __syncthreads();
+
   const int nw = (n + 63) >> 6;
-  unsigned long long removed_reg = 0ull;  // lane w (< kWords) of wave 0 owns word w
-  for (int c = 0; c < nw; ++c) {
-    if (tid == 0) s.rownz = 0ull;
-    __syncthreads();
-    {
-      const int r = tid >> 4, w = tid & 15;  // 64 rows x 16 words of 64 columns
-      const int i = c * 64 + r;
-      unsigned long long bits = 0ull;
-      if (i < n && w >= c && w < nw) {
-        const int pi = gathered_pos(s, i);
-        const float ax1 = s.x1[pi], ay1 = s.y1[pi], ax2 = s.x2[pi], ay2 = s.y2[pi], ac = s.conf[pi];
-        const int acls = s.cls[pi];
-        for (int b = 0; b < 64; ++b) {
-          const int j = w * 64 + b;
-          if (j <= i || j >= n) continue;
-          const int pj = gathered_pos(s, j);
-          if (s.cls[pj] != acls) continue;
-          if (!(ac > s.conf[pj])) continue;  // only a strictly higher confidence suppresses
-          if (iou_eps(ax1, ay1, ax2, ay2, s.x1[pj], s.y1[pj], s.x2[pj], s.y2[pj]) > iou_thr) bits |= 1ull << b;
-        }
-      }
-      s.mask[r][w] = bits;
-      if (bits) atomicOr(&s.rownz, 1ull << r);
+  const int ntiles = nw * (nw + 1) / 2;
+  for (int t = wid; t < ntiles; t += kWaves) {
+    int c = 0, rem = t;  // tile t -> (chunk row c, word w >= c)
+    while (rem >= nw - c) {
+      rem -= nw - c;
+      ++c;
     }
-    __syncthreads();
-    if (tid < 64) {  // wave 0 resolves this chunk in order, visiting only the rows that suppress something
-      unsigned long long todo = s.rownz;
+    const int w = c + rem;
+    const int i = c * 64 + lane;
+    const bool row_ok = i < n;
+    const float4 a = s.box[row_ok ? i : 0];
+    const float2 ac = s.cc[row_ok ? i : 0];
+    const float area_a = (a.z - a.x) * (a.w - a.y);
+    unsigned long long bits = 0ull;
+    const int jend = min(64, n - w * 64);
+    for (int b = 0; b < jend; ++b) {
+      const int j = w * 64 + b;
+      const float4 bb = s.box[j];  // same address in every lane: LDS broadcast
+      const float2 bc = s.cc[j];
+      const float ix1 = fmaxf(a.x, bb.x), iy1 = fmaxf(a.y, bb.y);
+      const float ix2 = fminf(a.z, bb.z), iy2 = fminf(a.w, bb.w);
+      const bool cand = row_ok && j > i && __float_as_int(bc.y) == __float_as_int(ac.y) && ac.x > bc.x &&
+                        !(ix1 >= ix2 || iy1 >= iy2);
+      if (cand) {
+        const float inter = (ix2 - ix1) * (iy2 - iy1);
+        const float area_b = (bb.z - bb.x) * (bb.w - bb.y);
+        if (inter / (area_a + area_b - inter + 1e-6f) > iou_thr) bits |= 1ull << b;
+      }
+    }
+    s.mask[tri_off(c, nw) + lane * (nw - c) + (w - c)] = bits;
+    const unsigned long long nz = __ballot(bits != 0ull);
+    if (lane == 0 && nz) atomicOr(&s.rownz[c], nz);
+  }
+  __syncthreads();
+
+  if (tid < 64) {
+    unsigned long long removed_reg = 0ull;  // lane w (< kWords) owns word w of the suppression bitmap
+    for (int c = 0; c < nw; ++c) {
+      unsigned long long todo = s.rownz[c];
       unsigned long long cur = __shfl(removed_reg, c);
+      const int base = tri_off(c, nw), stride = nw - c;
       while (todo) {
         const int r = __ffsll((long long)todo) - 1;
         todo &= todo - 1ull;
         if ((cur >> r) & 1ull) continue;  // row r was itself suppressed: it suppresses nothing
-        if (tid < kWords) removed_reg |= s.mask[r][tid];
+        if (lane >= c && lane < nw) removed_reg |= s.mask[base + r * stride + (lane - c)];
         cur = __shfl(removed_reg, c);
       }
     }
-    __syncthreads();
+    if (lane < kWords) s.removed[lane] = removed_reg;
   }
-  if (tid < kWords) s.removed[tid] = removed_reg;
   __syncthreads();
 }
 
 }  // namespace
 
 // ================================================================================================ fused kernel
+extern __shared__ __align__(16) unsigned char post_smem[];
+
 __global__ __launch_bounds__(kPostBlock) void postprocess_kernel(const PostParams p) {
-  __shared__ Smem s;
+  Smem& s = *reinterpret_cast<Smem*>(post_smem);
   const int tid = threadIdx.x;
   const int n0 = p.gw[0] * p.gh[0], n1 = p.gw[1] * p.gh[1], n2 = p.gw[2] * p.gh[2];
   const int ncells = n0 + n1 + n2;
@@ -332,22 +366,15 @@ __global__ __launch_bounds__(kPostBlock) void postprocess_kernel(const PostParam
   const bool kept = tid < n && !((s.removed[tid >> 6] >> (tid & 63)) & 1ull);
   int nkept;
   const int opos = block_rank(kept, s, &nkept);
-  if (kept) {
-    const int my = gathered_pos(s, tid);
-    GpuDetection d;
-    d.x1 = s.x1[my]; d.y1 = s.y1[my]; d.x2 = s.x2[my]; d.y2 = s.y2[my];
-    d.confidence = s.conf[my];
-    d.class_id = s.cls[my];
-    d.valid = 1;
-    d._pad = 0;
-    p.out[opos] = d;
-  }
+  if (kept) p.out[opos] = get(s, tid, 1);
   if (tid == 0) {
     *p.out_count = nkept;
     if (p.out_candidates) *p.out_candidates = total;
     __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
   }
 }
+
+namespace { hipError_t post_init(); }
 
 int post_num_blocks(const int gw[3], const int gh[3]) {
   const int cells = gw[0] * gh[0] + gw[1] * gh[1] + gw[2] * gh[2];
@@ -357,7 +384,13 @@ int post_num_blocks(const int gw[3], const int gh[3]) {
 hipError_t postprocess_launch(const PostParams& p, hipStream_t stream) {
   const int nb = post_num_blocks(p.gw, p.gh);
   if (nb < 1 || nb > kPostBlock) return hipErrorInvalidValue;
-  postprocess_kernel<<<nb, kPostBlock, 0, stream>>>(p);
+  static bool attr_set = false;  // raise the dynamic-LDS limit once per process
+  if (!attr_set) {
+    hipError_t e = post_init();
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  postprocess_kernel<<<nb, kPostBlock, kPostSmemBytes, stream>>>(p);
   return hipGetLastError();
 }
 
@@ -386,7 +419,7 @@ __global__ __launch_bounds__(kPostBlock) void decode_head_append_kernel(const fl
                                                                         GpuDetection* cand, int* block_count,
                                                                         unsigned int* ticket, int gw, int gh, int stride,
                                                                         int num_classes, float conf_thr, float q) {
-  __shared__ Smem s;
+  Smem& s = *reinterpret_cast<Smem*>(post_smem);
   const int tid = threadIdx.x;
   const int idx = blockIdx.x * kT + tid;
   bool pass = false;
@@ -410,32 +443,33 @@ __global__ __launch_bounds__(kPostBlock) void decode_head_append_kernel(const fl
 }
 
 __global__ __launch_bounds__(kPostBlock) void nms_inplace_kernel(GpuDetection* dets, int n, float iou_thr) {
-  __shared__ Smem s;
+  Smem& s = *reinterpret_cast<Smem*>(post_smem);
   const int tid = threadIdx.x;
   if (tid < n) put(s, tid, dets + tid);
   __syncthreads();
   sort_and_nms(s, n, iou_thr);
-  if (tid < n) {
-    const int my = gathered_pos(s, tid);
-    GpuDetection d;
-    d.x1 = s.x1[my]; d.y1 = s.y1[my]; d.x2 = s.x2[my]; d.y2 = s.y2[my];
-    d.confidence = s.conf[my];
-    d.class_id = s.cls[my];
-    d.valid = ((s.removed[tid >> 6] >> (tid & 63)) & 1ull) ? 0 : 1;
-    d._pad = 0;
-    dets[tid] = d;
-  }
+  if (tid < n) dets[tid] = get(s, tid, ((s.removed[tid >> 6] >> (tid & 63)) & 1ull) ? 0 : 1);
 }
 
 __global__ __launch_bounds__(kPostBlock) void compact_valid_kernel(const GpuDetection* dets, int n, GpuDetection* out,
                                                                    int* num_selected) {
-  __shared__ Smem s;
+  Smem& s = *reinterpret_cast<Smem*>(post_smem);
   const int tid = threadIdx.x;
   const bool v = tid < n && dets[tid].valid != 0;  // IsValidDetection (gpu_postprocess.cu:247-251)
   int tot;
   const int pos = block_rank(v, s, &tot);
   if (v) out[pos] = dets[tid];
   if (tid == 0) *num_selected = tot;
+}
+
+hipError_t post_init() {
+  const void* fns[] = {reinterpret_cast<const void*>(postprocess_kernel), reinterpret_cast<const void*>(decode_head_append_kernel),
+                       reinterpret_cast<const void*>(nms_inplace_kernel), reinterpret_cast<const void*>(compact_valid_kernel)};
+  for (const void* f : fns) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPostSmemBytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 }  // namespace
@@ -447,6 +481,7 @@ extern "C" {
 
 hipError_t init_postprocess_resources(void) {
   hipError_t err;
+  if ((err = unina::post_init()) != hipSuccess) return err;
   if ((err = hipMalloc(&g_ws.d_count, sizeof(int))) != hipSuccess) return err;
   if ((err = hipMalloc(&g_ws.d_cand, sizeof(GpuDetection) * (size_t)unina::kStepMaxBlocks * unina::kPostBlock)) != hipSuccess) return err;
   if ((err = hipMalloc(&g_ws.d_block_count, sizeof(int) * unina::kStepMaxBlocks)) != hipSuccess) return err;
@@ -483,7 +518,7 @@ hipError_t decode_yolo_head(const float* d_cls, const float* d_reg, GpuDetection
   const int cells = grid_w * grid_h;
   const int nb = (cells + unina::kPostBlock - 1) / unina::kPostBlock;
   if (cells <= 0 || nb > g_ws.cand_blocks) return hipErrorInvalidValue;
-  unina::decode_head_append_kernel<<<nb, unina::kPostBlock, 0, stream>>>(
+  unina::decode_head_append_kernel<<<nb, unina::kPostBlock, unina::kPostSmemBytes, stream>>>(
       d_cls, d_reg, d_detections, g_ws.d_count, g_ws.d_cand, g_ws.d_block_count, g_ws.d_ticket, grid_w, grid_h, stride,
       num_classes, conf_threshold, conformal_q);
   return hipGetLastError();
@@ -492,7 +527,7 @@ hipError_t decode_yolo_head(const float* d_cls, const float* d_reg, GpuDetection
 hipError_t run_gpu_nms(GpuDetection* d_detections, int num_detections, float iou_threshold, hipStream_t stream) {
   if (num_detections == 0) return hipSuccess;
   if (num_detections < 0 || num_detections > MAX_DETECTIONS) return hipErrorInvalidValue;
-  unina::nms_inplace_kernel<<<1, unina::kPostBlock, 0, stream>>>(d_detections, num_detections, iou_threshold);
+  unina::nms_inplace_kernel<<<1, unina::kPostBlock, unina::kPostSmemBytes, stream>>>(d_detections, num_detections, iou_threshold);
   return hipGetLastError();
 }
 
@@ -504,7 +539,7 @@ hipError_t copy_valid_detections_to_host(const GpuDetection* d_detections, GpuDe
   }
   if (!g_ws.d_compact) return hipErrorNotInitialized;
   if (num_detections < 0 || num_detections > MAX_DETECTIONS) return hipErrorInvalidValue;
-  unina::compact_valid_kernel<<<1, unina::kPostBlock, 0, stream>>>(d_detections, num_detections, g_ws.d_compact,
+  unina::compact_valid_kernel<<<1, unina::kPostBlock, unina::kPostSmemBytes, stream>>>(d_detections, num_detections, g_ws.d_compact,
                                                                     g_ws.d_num_selected);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return err;

@@ -10,24 +10,21 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // ---------------------------------------------------------------------------------------------- stem
 // Cin = 3 makes K = 27: far too thin for a matrix-core tile, and the op is HBM-bound anyway
-// (4.9 MB fp32 in, 6.6 MB fp16 out at 640^2 against 0.18 GFLOP). Plain fp32 FMAs:
-// lane -> (pixel = tid/4, 8-channel group = tid%4), so a wave stores 64 x 16 B = 1 KiB contiguous NHWC.
-// Weights/bias sit in LDS (fp32, 32x27 + 32 floats).
+// (4.9 MB fp32 in, 6.6 MB fp16 out at 640^2 against 0.18 GFLOP). Plain fp32 FMAs, one thread per output pixel
+// and ALL output channels: a wave's 27 input loads each cover 64 neighbouring pixels (stride-2 fp32: every fetched
+// line is used), the 27x32 folded weights are LDS broadcast reads (ds_read_b128, same address in every lane), and
+// each lane stores its pixel's 64 contiguous NHWC bytes.
+template <int CO>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
-  __shared__ float sw[27][32 + 1];
-  __shared__ float sb[32];
-  const int groups = p.Co / 8;                 // 4 for base_channels = 32
-  for (int i = threadIdx.x; i < p.Co * 27; i += blockDim.x) sw[i % 27][i / 27] = p.w[i];
-  for (int i = threadIdx.x; i < p.Co; i += blockDim.x) sb[i] = p.bias[i];
+  __shared__ __align__(16) float sw[27 * CO];
+  __shared__ __align__(16) float sb[CO];
+  for (int i = threadIdx.x; i < CO * 27; i += blockDim.x) sw[(i % 27) * CO + (i / 27)] = p.w[i];  // -> [k][co]
+  for (int i = threadIdx.x; i < CO; i += blockDim.x) sb[i] = p.bias[i];
   __syncthreads();
-  const int pix_per_block = blockDim.x / groups;
-  const int m = blockIdx.x * pix_per_block + threadIdx.x / groups;
-  const int g = threadIdx.x % groups;
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= p.Ho * p.Wo) return;
   const int oy = m / p.Wo, ox = m - oy * p.Wo;
-  float acc[8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) acc[r] = sb[g * 8 + r];
+  float x[27];
   const size_t plane = (size_t)p.H * p.W;
 #pragma unroll
   for (int c = 0; c < 3; ++c)
@@ -38,26 +35,40 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
       for (int kw = 0; kw < 3; ++kw) {
         const int ix = ox * 2 + kw - 1;
         const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        const float x = ok ? p.src[c * plane + (size_t)iy * p.W + ix] : 0.f;
-        const int k = (c * 3 + kh) * 3 + kw;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) acc[r] = __builtin_fmaf(x, sw[k][g * 8 + r], acc[r]);
+        x[(c * 3 + kh) * 3 + kw] = ok ? p.src[c * plane + (size_t)iy * p.W + ix] : 0.f;
       }
     }
-  half8 hv;
+  float acc[CO];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) hv[r] = (half_t)(acc[r] > 0.f ? acc[r] : 0.f);
-  *reinterpret_cast<half8*>(p.dst + (size_t)m * p.dst_ld + g * 8) = hv;
+  for (int r = 0; r < CO; ++r) acc[r] = sb[r];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+#pragma unroll
+    for (int r = 0; r < CO; r += 4) {
+      const float4 w4 = *reinterpret_cast<const float4*>(&sw[k * CO + r]);
+      acc[r + 0] = __builtin_fmaf(x[k], w4.x, acc[r + 0]);
+      acc[r + 1] = __builtin_fmaf(x[k], w4.y, acc[r + 1]);
+      acc[r + 2] = __builtin_fmaf(x[k], w4.z, acc[r + 2]);
+      acc[r + 3] = __builtin_fmaf(x[k], w4.w, acc[r + 3]);
+    }
+  }
+  half_t* d = p.dst + (size_t)m * p.dst_ld;
+#pragma unroll
+  for (int r = 0; r < CO; r += 8) {
+    half8 hv;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) hv[q] = (half_t)(acc[r + q] > 0.f ? acc[r + q] : 0.f);
+    *reinterpret_cast<half8*>(d + r) = hv;
+  }
 }
 
 hipError_t stem_launch(const StemParams& p, hipStream_t stream, dim3* grid_out, dim3* block_out) {
-  if (p.Co > 32 || p.Co % 8) return hipErrorInvalidValue;
-  const int groups = p.Co / 8;
-  const int pix_per_block = 256 / groups;
-  dim3 grid((p.Ho * p.Wo + pix_per_block - 1) / pix_per_block), block(256);
+  dim3 grid((p.Ho * p.Wo + 255) / 256), block(256);
   if (grid_out) *grid_out = grid;
   if (block_out) *block_out = block;
-  stem_conv_kernel<<<grid, block, 0, stream>>>(p);
+  if (p.Co == 32) stem_conv_kernel<32><<<grid, block, 0, stream>>>(p);
+  else if (p.Co == 64) stem_conv_kernel<64><<<grid, block, 0, stream>>>(p);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

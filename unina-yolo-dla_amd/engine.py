@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "unina_load_engine", "unina_unload_engine", "unina_engine_input_dims", "unina_set_tensor_address",
     "unina_tensor_address", "unina_enqueue", "unina_infer", "unina_infer_async", "unina_postprocess_async",
     "unina_last_error", "unina_op_count", "unina_get_op_info", "unina_profile_ops", "unina_debug_read_buffer",
-    "unina_version",
+    "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune",
     "init_postprocess_resources", "cleanup_postprocess_resources", "reset_detection_counter", "get_detection_count",
     "decode_yolo_head", "run_gpu_nms", "copy_valid_detections_to_host",
 ]
@@ -77,6 +77,10 @@ def load_library() -> C.CDLL:
     L.unina_profile_ops.argtypes = [vp, ci, C.POINTER(cf), vp]
     L.unina_debug_read_buffer.argtypes = [vp, C.c_char_p, vp, C.c_size_t, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     L.unina_version.restype = C.c_char_p
+    L.unina_conv_config_name.restype = C.c_char_p
+    L.unina_conv_config_name.argtypes = [ci]
+    L.unina_set_op_config.argtypes = [vp, ci, ci]
+    L.unina_autotune.argtypes = [vp, ci, vp]
     # gpu_postprocess.h drop-in symbols
     L.reset_detection_counter.argtypes = [vp]
     L.get_detection_count.argtypes = [C.POINTER(ci), vp]
@@ -232,6 +236,27 @@ class Engine:
         for i, d in enumerate(infos):
             d["ms"] = float(ms[i])
         return infos
+
+    def autotune(self, images=None, iters: int = 10, stream=None) -> None:
+        """Pick the fastest tile configuration per conv op by timing on this GPU (results are unchanged)."""
+        if images is None and self._images is None:
+            images = _torch().zeros((1, 3, self.height, self.width), dtype=_torch().float32,
+                                    device=_torch().device("cuda", self.device))
+        if images is not None:
+            self.bind_images(images)
+        self._check(self.L.unina_autotune(self.h, iters, _stream_ptr(stream)))
+        _torch().cuda.synchronize(self.device)
+
+    def conv_configs(self) -> List[str]:
+        return [self.L.unina_conv_config_name(i).decode() for i in range(self.L.unina_conv_config_count())]
+
+    def set_op_config(self, op_index: int, cfg: int) -> bool:
+        """Force a tile configuration for one conv op (-1 = heuristic). Returns False if it does not fit."""
+        rc = self.L.unina_set_op_config(self.h, op_index, cfg)
+        if rc == 6:
+            return False
+        self._check(rc)
+        return True
 
     def read_buffer(self, name: str) -> np.ndarray:
         """Internal activation buffer -> [C,H,W] fp32 (parity tests)."""

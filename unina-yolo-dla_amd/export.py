@@ -29,7 +29,7 @@ import numpy as np
 from .graph import Graph, OUTPUT_NAMES, STRIDES
 
 MAGIC = b"UNINAENG"
-VERSION = 1
+VERSION = 2
 FP16, INT8 = 0, 1
 BUF_F16, BUF_F32_PLANAR, BUF_F32_NCHW_IN = 0, 1, 2
 BUF_INPUT, BUF_OUTPUT = 1, 2
@@ -76,6 +76,33 @@ class Op:
     in_hw: Tuple[int, int] = (0, 0)
     out_hw: Tuple[int, int] = (0, 0)
     segs: List[Seg] = field(default_factory=list)
+
+
+_SWZ_G = (0, 2, 3, 1)
+
+
+def pack_weights(wk: np.ndarray) -> np.ndarray:
+    """[n_pad][K] fp16 (K = (kh,kw,cin), n_pad % 16 == 0, K % 32 == 0) -> the LDS image the conv kernel DMA-loads:
+    1-KiB blocks [n_pad/16][K/32], each 64 slots x 8 halfs with slot(r, c) = 4*r + (c ^ G[r>>2]), G = (0,2,3,1)
+    (conv_igemm.hip: conflict-free ds_read_b128 fragment reads)."""
+    n_pad, K = wk.shape
+    assert n_pad % 16 == 0 and K % 32 == 0, (n_pad, K)
+    blk = wk.reshape(n_pad // 16, 16, K // 32, 4, 8).transpose(0, 2, 1, 3, 4)       # [nsub][k32][r][c][8]
+    out = np.empty_like(blk)
+    for r in range(16):
+        for c in range(4):
+            out[:, :, r, c ^ _SWZ_G[r >> 2]] = blk[:, :, r, c]
+    return np.ascontiguousarray(out).reshape(-1)
+
+
+def unpack_weights(packed: np.ndarray, n_pad: int, K: int) -> np.ndarray:
+    """Inverse of pack_weights (tests / emulator)."""
+    blk = packed.reshape(n_pad // 16, K // 32, 16, 4, 8)
+    out = np.empty_like(blk)
+    for r in range(16):
+        for c in range(4):
+            out[:, :, r, c] = blk[:, :, r, c ^ _SWZ_G[r >> 2]]
+    return np.ascontiguousarray(out.transpose(0, 2, 1, 3, 4)).reshape(n_pad, K)
 
 
 def fold_bn(sd: Dict[str, np.ndarray], module: str):
@@ -143,7 +170,8 @@ class EngineBuilder:
             want = (2 * oh, 2 * ow) if flags & SEG_UP2 else (oh, ow)
             assert (dh, dw) == want, (module, (dh, dw), want)
             assert dst.c == n, (module, dst.c, n)
-            op.segs.append(Seg(module, src_coff, n, dst, flags, self._blob_add(wk), self._blob_add(bk), n_pad))
+            op.segs.append(Seg(module, src_coff, n, dst, flags,
+                               self._blob_add(pack_weights(wk.reshape(n_pad, k * k * cin))), self._blob_add(bk), n_pad))
         self.ops.append(op)
 
     def c3k2(self, name: str, src: View, dst: View, n: int):
