@@ -23,6 +23,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, assigned round-robin at
+# stream creation): with the default, the two per-frame streams can land on ONE queue and serialise (measured:
+# 2 560 vs 4 340 frames/s). Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
@@ -30,7 +34,7 @@ FLOPS_PER_FRAME = {640: 35_664_691_200, 1280: 142_658_764_800}
 PEAK_TFLOPS = {"f16": 2500.0}                                     # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 N_FRAMES = 16            # distinct synthetic frames cycled through
-IN_FLIGHT = 2            # engine handles per GPU = frames in flight
+IN_FLIGHT = int(os.environ.get("UNINA_IN_FLIGHT", "2"))   # engine handles per GPU = frames in flight
 GATHER_EVERY = 16        # frames per RCCL all-gather of detection slots
 
 
@@ -43,8 +47,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--latency-frames", type=int, default=300)
+    ap.add_argument("--streams", type=int, default=0, help="parallel graph paths per engine (0 = library default)")
+    ap.add_argument("--tune-cache", default=os.environ.get("UNINA_TUNE_CACHE", ""), help="tactic cache file (JSON)")
     args = ap.parse_args()
 
+    if args.streams > 0:
+        os.environ["UNINA_STREAMS"] = str(args.streams)
     import torch
     import torch.distributed as dist
     import unina_yolo_dla_amd as u
@@ -77,7 +85,7 @@ def main():
     gathered = torch.zeros((world, GATHER_EVERY, slot_words), dtype=torch.int32, device=dev) if world > 1 else None
     conf = 0.5 if S == 640 else 0.6
     for e in engines:                      # engine build step: per-op tile selection by timing (outside the timed region)
-        e.autotune(frames[0], iters=10)
+        e.autotune(frames[0], iters=10, cache=args.tune_cache or None)
     torch.cuda.synchronize()
 
     def run(n_frames):

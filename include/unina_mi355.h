@@ -147,6 +147,11 @@ int unina_autotune(unina_engine_t *e, int iters, hipStream_t stream);
 int unina_debug_read_buffer(unina_engine_t *e, const char *name, float *host_out, size_t capacity_floats,
                             int *c, int *h, int *w);
 
+/* Debug: wall_clock64 stamps (100 MHz) of the phases of the last unina_infer's post-process kernel; only written
+ * when the environment has UNINA_POST_STAMPS=1. out8[0..6]: decode done, hand-off done, gather done, sort done,
+ * masks done, scan done, output done. */
+int unina_debug_post_stamps(unina_engine_t *e, long long *out8);
+
 /* Library/build identification: "unina_mi355 <version> gfx950". */
 const char *unina_version(void);
 

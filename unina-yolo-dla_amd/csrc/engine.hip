@@ -45,6 +45,7 @@ struct DeviceResult {  // what the fused post-process writes; one D2H brings cou
   int candidates;
   int pad[6];
   GpuDetection det[MAX_DETECTIONS];
+  long long pad_stamps[8];  // debug phase stamps of the post-process kernel (UNINA_POST_STAMPS=1)
 };
 
 }  // namespace
@@ -71,6 +72,10 @@ struct unina_engine {
   bool use_graph = true;
   bool plan_dirty = true;
   hipStream_t capture_stream = nullptr;
+  std::vector<hipStream_t> side_streams;   // extra capture streams: independent branches become parallel graph paths
+  std::vector<hipEvent_t> op_events;       // one per op (capture-time dependency edges)
+  hipEvent_t fork_event = nullptr;
+  int n_streams = 1;                       // parallel graph paths (UNINA_STREAMS); measured no gain on ROCm 7.2, so 1
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   std::string err;
@@ -228,12 +233,112 @@ int launch_all(unina_engine* e, hipStream_t s, int which = 0 /*0 all, 1 eager on
   return UNINA_OK;
 }
 
+// ---- dependency analysis over the op table (buffer id + channel range granularity) ----
+struct Region {
+  int buf, c0, c1;
+};
+bool overlaps(const Region& a, const Region& b) { return a.buf == b.buf && a.c0 < b.c1 && b.c0 < a.c1; }
+
+void op_regions(const unina_engine* e, size_t i, std::vector<Region>* reads, std::vector<Region>* writes) {
+  const OpDesc& d = e->ops[i].d;
+  reads->clear();
+  writes->clear();
+  if (d.kind == kOpSppfPool) {
+    const int c0 = (int)d.seg[0].src_coff, C = (int)d.cin;
+    reads->push_back({(int)d.src_buf, c0, c0 + C});
+    writes->push_back({(int)d.src_buf, c0 + C, c0 + 4 * C});
+    return;
+  }
+  for (uint32_t s = 0; s < d.nseg; ++s) {
+    const SegDesc& sd = d.seg[s];
+    const int cin = d.kind == kOpStem ? 3 : (int)d.cin;
+    reads->push_back({(int)d.src_buf, (int)sd.src_coff, (int)sd.src_coff + cin});
+    writes->push_back({(int)sd.dst_buf, (int)sd.dst_coff, (int)(sd.dst_coff + sd.n_count)});
+    if (d.res_buf >= 0) reads->push_back({d.res_buf, d.res_coff, d.res_coff + (int)sd.n_count});
+  }
+}
+
+// preds[j] = ops i < j that j must wait for (RAW, WAR, WAW), transitively reduced only trivially
+std::vector<std::vector<int>> op_dependencies(const unina_engine* e) {
+  const size_t n = e->ops.size();
+  std::vector<std::vector<Region>> R(n), W(n);
+  for (size_t i = 0; i < n; ++i) op_regions(e, i, &R[i], &W[i]);
+  std::vector<std::vector<int>> preds(n);
+  for (size_t j = 0; j < n; ++j)
+    for (size_t i = 0; i < j; ++i) {
+      bool dep = false;
+      for (const Region& w : W[i]) {
+        for (const Region& r : R[j]) dep = dep || overlaps(w, r);
+        for (const Region& w2 : W[j]) dep = dep || overlaps(w, w2);
+      }
+      for (const Region& r : R[i])
+        for (const Region& w2 : W[j]) dep = dep || overlaps(r, w2);
+      if (dep) preds[j].push_back((int)i);
+    }
+  return preds;
+}
+
+// Captures the graph part of the forward. Ops are dealt to n_streams capture streams so that independent branches
+// (the three detection heads vs. the PAN path, C3k2 side paths) become parallel paths of the hipGraph; every
+// cross-stream dependency is an event edge. With n_streams == 1 this is a plain chain.
 int capture(unina_engine* e) {
   drop_graph(e);
-  HIPCHK(e, hipStreamBeginCapture(e->capture_stream, hipStreamCaptureModeThreadLocal));
-  int rc = launch_all(e, e->capture_stream, 2);
-  hipError_t end = hipStreamEndCapture(e->capture_stream, &e->graph);
+  const size_t n = e->ops.size();
+  const int S = e->n_streams < 1 ? 1 : e->n_streams;
+  while ((int)e->side_streams.size() < S - 1) {
+    hipStream_t st;
+    HIPCHK(e, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    e->side_streams.push_back(st);
+  }
+  while (e->op_events.size() < n) {
+    hipEvent_t ev;
+    HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    e->op_events.push_back(ev);
+  }
+  if (!e->fork_event) HIPCHK(e, hipEventCreateWithFlags(&e->fork_event, hipEventDisableTiming));
+  std::vector<hipStream_t> st(S);
+  st[0] = e->capture_stream;
+  for (int k = 1; k < S; ++k) st[k] = e->side_streams[k - 1];
+  const std::vector<std::vector<int>> preds = op_dependencies(e);
+
+  HIPCHK(e, hipStreamBeginCapture(st[0], hipStreamCaptureModeThreadLocal));
+  hipError_t err = hipEventRecord(e->fork_event, st[0]);
+  for (int k = 1; k < S && err == hipSuccess; ++k) err = hipStreamWaitEvent(st[k], e->fork_event, 0);
+  std::vector<int> stream_of(n, -1), tail(S, -1);  // tail[k] = last op captured on stream k
+  int rc = UNINA_OK;
+  for (size_t j = 0; j < n && err == hipSuccess && rc == UNINA_OK; ++j) {
+    if (is_eager(e, j)) continue;
+    int k = -1;
+    for (int p : preds[j])  // continue a chain where a predecessor is still the tail of its stream
+      if (stream_of[p] >= 0 && tail[stream_of[p]] == p) k = stream_of[p];
+    if (k < 0) {            // otherwise the stream whose tail is oldest (round-robin-ish)
+      k = 0;
+      for (int q = 1; q < S; ++q)
+        if (tail[q] < tail[k]) k = q;
+    }
+    for (int p : preds[j])
+      if (stream_of[p] >= 0 && stream_of[p] != k && err == hipSuccess) err = hipStreamWaitEvent(st[k], e->op_events[p], 0);
+    if (err != hipSuccess) break;
+    err = launch_op(e, j, st[k]);
+    if (err != hipSuccess) {
+      rc = fail(e, UNINA_ERR_HIP, "op %zu (%s): %s", j, e->ops[j].d.name, hipGetErrorString(err));
+      break;
+    }
+    err = hipEventRecord(e->op_events[j], st[k]);
+    stream_of[j] = k;
+    tail[k] = (int)j;
+  }
+  for (int k = 1; k < S && err == hipSuccess; ++k) {  // join the side streams back into the origin
+    if (tail[k] < 0) {
+      err = hipEventRecord(e->op_events[0], st[k]);  // never used: still has to be joined
+      if (err == hipSuccess) err = hipStreamWaitEvent(st[0], e->op_events[0], 0);
+      continue;
+    }
+    err = hipStreamWaitEvent(st[0], e->op_events[tail[k]], 0);
+  }
+  hipError_t end = hipStreamEndCapture(st[0], &e->graph);
   if (rc != UNINA_OK) return rc;
+  if (err != hipSuccess) return fail(e, UNINA_ERR_HIP, "graph capture: %s", hipGetErrorString(err));
   if (end != hipSuccess) return fail(e, UNINA_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(end));
   HIPCHK(e, hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0));
   return UNINA_OK;
@@ -285,6 +390,7 @@ int fill_post_params(unina_engine* e, PostParams* pp, float conf, float iou, flo
   pp->out = d_out;
   pp->out_count = d_count;
   pp->out_candidates = d_cand_count;
+  pp->stamps = getenv("UNINA_POST_STAMPS") ? reinterpret_cast<long long*>(e->d_result->pad_stamps) : nullptr;
   return UNINA_OK;
 }
 
@@ -402,6 +508,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
 #undef LOADCHK
   const char* ng = getenv("UNINA_NO_GRAPH");
   e->use_graph = !(ng && ng[0] == '1');
+  if (const char* ns = getenv("UNINA_STREAMS")) e->n_streams = atoi(ns) > 0 ? atoi(ns) : 1;
   e->plan_dirty = true;
   *out = e;
   return UNINA_OK;
@@ -412,6 +519,9 @@ void unina_unload_engine(unina_engine_t* e) {
   (void)hipSetDevice(e->device);
   drop_graph(e);
   if (e->capture_stream) (void)hipStreamDestroy(e->capture_stream);
+  for (hipStream_t st : e->side_streams) (void)hipStreamDestroy(st);
+  for (hipEvent_t ev : e->op_events) (void)hipEventDestroy(ev);
+  if (e->fork_event) (void)hipEventDestroy(e->fork_event);
   void* dev[] = {e->d_blob, e->d_arena, e->d_zeros, e->d_cand, e->d_block_count, e->d_ticket, e->d_result};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -506,6 +616,14 @@ int unina_infer(unina_engine_t* e, const float* d_images, float conf, float iou,
   if (n < 0 || n > MAX_DETECTIONS) return fail(e, UNINA_ERR_STATE, "post-process returned count %d", n);
   memcpy(out, e->h_result->det, sizeof(GpuDetection) * (size_t)n);
   *out_count = n;
+  return UNINA_OK;
+}
+
+int unina_debug_post_stamps(unina_engine_t* e, long long* out8) {
+  if (!e || !out8) return UNINA_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipDeviceSynchronize());
+  HIPCHK(e, hipMemcpy(out8, e->d_result->pad_stamps, sizeof(long long) * 8, hipMemcpyDeviceToHost));
   return UNINA_OK;
 }
 

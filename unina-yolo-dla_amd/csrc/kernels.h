@@ -107,6 +107,7 @@ struct PostParams {
   GpuDetection* out;         // [MAX_DETECTIONS]
   int* out_count;            // kept
   int* out_candidates;       // optional (may be nullptr): number of cells that passed the threshold
+  long long* stamps;         // optional debug: 8 wall_clock64 stamps of the last block's phases (nullptr = off)
 };
 constexpr int kPostBlock = 1024;
 int post_num_blocks(const int gw[3], const int gh[3]);

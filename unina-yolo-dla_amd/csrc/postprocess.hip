@@ -196,10 +196,14 @@ __device__ __forceinline__ int tri_off(int c, int nw) { return 64 * (c * nw - (c
 //          a tile are visited in lock-step so every LDS read is a broadcast; the division only runs for pairs
 //          that really overlap
 //   scan : wave 0 walks the chunks in order and visits only rows that suppress something
-__device__ void sort_and_nms(Smem& s, int n, float iou_thr) {
+__device__ void sort_and_nms(Smem& s, int n, float iou_thr, long long* stamps = nullptr) {
+#define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
-  if (tid < n) s.keys[tid] = ((unsigned long long)__float_as_uint(s.cc[tid].x) << 32) | (0xFFFFFFFFu - (unsigned)tid);
+  // keys; entries n..n8) are zero so that the fixed-trip, unrolled scans below never count them
+  const int n8 = (n + 7) & ~7;
+  if (tid < n8)
+    s.keys[tid] = tid < n ? (((unsigned long long)__float_as_uint(s.cc[tid].x) << 32) | (0xFFFFFFFFu - (unsigned)tid)) : 0ull;
   __syncthreads();
   float4 mybox;
   float2 mycc;
@@ -208,20 +212,29 @@ __device__ void sort_and_nms(Smem& s, int n, float iou_thr) {
     const unsigned long long mine = s.keys[tid];
     mybox = s.box[tid];
     mycc = s.cc[tid];
-    int j = 0;
-    for (; j + 4 <= n; j += 4) {
-      rank += (s.keys[j] > mine) + (s.keys[j + 1] > mine) + (s.keys[j + 2] > mine) + (s.keys[j + 3] > mine);
+    for (int j = 0; j < n8; j += 8) {  // 8 broadcast LDS reads in flight per wave
+      unsigned long long k[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) k[u] = s.keys[j + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rank += k[u] > mine;
     }
-    for (; j < n; ++j) rank += s.keys[j] > mine;
   }
   __syncthreads();
   if (tid < n) {
     s.box[rank] = mybox;
     s.cc[rank] = mycc;
   }
+  // pad the sorted arrays up to the next multiple of 64 with records that can never be suppressed (class -1)
+  const int n64 = (n + 63) & ~63;
+  if (tid >= n && tid < n64) {
+    s.box[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s.cc[tid] = make_float2(0.f, __int_as_float(-1));
+  }
   if (tid < kWords) s.rownz[tid] = 0ull;
   __syncthreads();
 
+  STAMP(3);
   const int nw = (n + 63) >> 6;
   const int ntiles = nw * (nw + 1) / 2;
   for (int t = wid; t < ntiles; t += kWaves) {
@@ -237,19 +250,27 @@ __device__ void sort_and_nms(Smem& s, int n, float iou_thr) {
     const float2 ac = s.cc[row_ok ? i : 0];
     const float area_a = (a.z - a.x) * (a.w - a.y);
     unsigned long long bits = 0ull;
-    const int jend = min(64, n - w * 64);
-    for (int b = 0; b < jend; ++b) {
-      const int j = w * 64 + b;
-      const float4 bb = s.box[j];  // same address in every lane: LDS broadcast
-      const float2 bc = s.cc[j];
-      const float ix1 = fmaxf(a.x, bb.x), iy1 = fmaxf(a.y, bb.y);
-      const float ix2 = fminf(a.z, bb.z), iy2 = fminf(a.w, bb.w);
-      const bool cand = row_ok && j > i && __float_as_int(bc.y) == __float_as_int(ac.y) && ac.x > bc.x &&
-                        !(ix1 >= ix2 || iy1 >= iy2);
-      if (cand) {
-        const float inter = (ix2 - ix1) * (iy2 - iy1);
-        const float area_b = (bb.z - bb.x) * (bb.w - bb.y);
-        if (inter / (area_a + area_b - inter + 1e-6f) > iou_thr) bits |= 1ull << b;
+    const int acls = __float_as_int(ac.y);
+    for (int b0 = 0; b0 < 64; b0 += 8) {  // fixed trip count: 16 broadcast LDS reads in flight
+      float4 bb[8];
+      float2 bc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        bb[u] = s.box[w * 64 + b0 + u];  // same address in every lane: LDS broadcast
+        bc[u] = s.cc[w * 64 + b0 + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = w * 64 + b0 + u;
+        const float ix1 = fmaxf(a.x, bb[u].x), iy1 = fmaxf(a.y, bb[u].y);
+        const float ix2 = fminf(a.z, bb[u].z), iy2 = fminf(a.w, bb[u].w);
+        const bool cand = row_ok && j > i && __float_as_int(bc[u].y) == acls && ac.x > bc[u].x &&
+                          !(ix1 >= ix2 || iy1 >= iy2);
+        if (cand) {
+          const float inter = (ix2 - ix1) * (iy2 - iy1);
+          const float area_b = (bb[u].z - bb[u].x) * (bb[u].w - bb[u].y);
+          if (inter / (area_a + area_b - inter + 1e-6f) > iou_thr) bits |= 1ull << (b0 + u);
+        }
       }
     }
     s.mask[tri_off(c, nw) + lane * (nw - c) + (w - c)] = bits;
@@ -257,6 +278,7 @@ __device__ void sort_and_nms(Smem& s, int n, float iou_thr) {
     if (lane == 0 && nz) atomicOr(&s.rownz[c], nz);
   }
   __syncthreads();
+  STAMP(4);
 
   if (tid < 64) {
     unsigned long long removed_reg = 0ull;  // lane w (< kWords) owns word w of the suppression bitmap
@@ -275,6 +297,8 @@ __device__ void sort_and_nms(Smem& s, int n, float iou_thr) {
     if (lane < kWords) s.removed[lane] = removed_reg;
   }
   __syncthreads();
+  STAMP(5);
+#undef STAMP
 }
 
 }  // namespace
@@ -304,7 +328,9 @@ __global__ __launch_bounds__(kPostBlock) void postprocess_kernel(const PostParam
     if (pass) p.cand[(size_t)blockIdx.x * kT + pos] = d;
     if (tid == 0) p.block_count[blockIdx.x] = total;
   }
+  if (p.stamps && tid == 0 && blockIdx.x == 0) p.stamps[0] = wall_clock64();
   if (!arrive_and_check_last(p.ticket, s)) return;
+  if (p.stamps && tid == 0) p.stamps[1] = wall_clock64();
 
   // ---- phase 2 (one block): gather in enumeration order ----
   const int nblocks = gridDim.x;  // <= kT (checked on the host)
@@ -360,7 +386,8 @@ __global__ __launch_bounds__(kPostBlock) void postprocess_kernel(const PostParam
   }
   __syncthreads();
 
-  sort_and_nms(s, n, p.iou_thr);
+  if (p.stamps && tid == 0) p.stamps[2] = wall_clock64();
+  sort_and_nms(s, n, p.iou_thr, p.stamps);
 
   // ---- compaction + output ----
   const bool kept = tid < n && !((s.removed[tid >> 6] >> (tid & 63)) & 1ull);
@@ -371,6 +398,7 @@ __global__ __launch_bounds__(kPostBlock) void postprocess_kernel(const PostParam
     *p.out_count = nkept;
     if (p.out_candidates) *p.out_candidates = total;
     __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    if (p.stamps) p.stamps[6] = wall_clock64();
   }
 }
 

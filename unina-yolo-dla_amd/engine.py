@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "unina_load_engine", "unina_unload_engine", "unina_engine_input_dims", "unina_set_tensor_address",
     "unina_tensor_address", "unina_enqueue", "unina_infer", "unina_infer_async", "unina_postprocess_async",
     "unina_last_error", "unina_op_count", "unina_get_op_info", "unina_profile_ops", "unina_debug_read_buffer",
-    "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune",
+    "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune", "unina_debug_post_stamps",
     "init_postprocess_resources", "cleanup_postprocess_resources", "reset_detection_counter", "get_detection_count",
     "decode_yolo_head", "run_gpu_nms", "copy_valid_detections_to_host",
 ]
@@ -81,6 +81,7 @@ def load_library() -> C.CDLL:
     L.unina_conv_config_name.argtypes = [ci]
     L.unina_set_op_config.argtypes = [vp, ci, ci]
     L.unina_autotune.argtypes = [vp, ci, vp]
+    L.unina_debug_post_stamps.argtypes = [vp, C.POINTER(C.c_longlong)]
     # gpu_postprocess.h drop-in symbols
     L.reset_detection_counter.argtypes = [vp]
     L.get_detection_count.argtypes = [C.POINTER(ci), vp]
@@ -237,8 +238,23 @@ class Engine:
             d["ms"] = float(ms[i])
         return infos
 
-    def autotune(self, images=None, iters: int = 10, stream=None) -> None:
-        """Pick the fastest tile configuration per conv op by timing on this GPU (results are unchanged)."""
+    def autotune(self, images=None, iters: int = 10, stream=None, cache: Optional[str] = None) -> None:
+        """Pick the fastest tile configuration per conv op by timing on this GPU (results are unchanged).
+        `cache`: JSON tactic cache (the role of TensorRT's timing cache): reused when it matches this engine."""
+        import json
+        names = self.conv_configs()
+        key = f"{self.width}x{self.height}:" + "|".join(f"{o['m']},{o['n']},{o['k']}" for o in self.op_infos())
+        if cache and os.path.exists(cache):
+            try:
+                with open(cache) as f:
+                    blob = json.load(f)
+                if blob.get("key") == key and blob.get("configs") == names:
+                    for i, c in enumerate(blob["choice"]):
+                        if c >= 0:
+                            self.set_op_config(i, c)
+                    return
+            except (ValueError, KeyError):
+                pass
         if images is None and self._images is None:
             images = _torch().zeros((1, 3, self.height, self.width), dtype=_torch().float32,
                                     device=_torch().device("cuda", self.device))
@@ -246,6 +262,16 @@ class Engine:
             self.bind_images(images)
         self._check(self.L.unina_autotune(self.h, iters, _stream_ptr(stream)))
         _torch().cuda.synchronize(self.device)
+        if cache:
+            choice = [names.index(o["kernel"]) if o["kernel"] in names else -1 for o in self.op_infos()]
+            with open(cache, "w") as f:
+                json.dump({"key": key, "configs": names, "choice": choice}, f)
+
+    def debug_stamps(self):
+        """Phase time stamps (100 MHz ticks) of the last unina_infer's post-process (needs UNINA_POST_STAMPS=1)."""
+        buf = (C.c_longlong * 8)()
+        self._check(self.L.unina_debug_post_stamps(self.h, buf))
+        return [int(v) for v in buf][:7]
 
     def conv_configs(self) -> List[str]:
         return [self.L.unina_conv_config_name(i).decode() for i in range(self.L.unina_conv_config_count())]
