@@ -56,7 +56,7 @@ def main():
     import torch
     import torch.distributed as dist
     import unina_yolo_dla_amd as u
-    from unina_yolo_dla_amd import export
+    from unina_yolo_dla_amd import export, gather
     from unina_yolo_dla_amd.engine import Engine, MAX_DETECTIONS
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,7 +99,7 @@ def main():
                 cur = torch.cuda.current_stream()
                 for s in streams:
                     cur.wait_stream(s)
-                dist.all_gather_into_tensor(gathered.view(world, -1), results.view(-1))
+                gather.gather_slots(results, out=gathered)
                 for s in streams:
                     s.wait_stream(cur)
 

@@ -13,11 +13,11 @@ run() {  # name, seconds, command...
 }
 [ -n "${SKIP_TESTS:-}" ] || run tests 420 python -m pytest tests -m gpu -q --timeout 300 ${PYTEST_ARGS:-}
 [ -n "${SKIP_TESTS:-}" ] || run smoke 120 python -c 'import __graft_entry__ as g; g.smoke()'
-run bench 300 python bench.py --gpus 1 ${BENCH_ARGS:-}
+run bench 300 python bench.py --gpus 1 --tune-cache /tmp/tune.json ${BENCH_ARGS:-}
 if [ -n "${PROFILE:-}" ]; then
   export TMPDIR=/tmp; cd /tmp
   rm -rf "$REPO/gpurun_out/prof"
-  TAILN=5 run rocprof 300 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof" -o trace --output-format csv -- python3 "$REPO/bench.py" --gpus 1 --steps 300 --warmup 50 --no-cpu-baseline --latency-frames 50
+  TAILN=5 run rocprof 300 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof" -o trace --output-format csv -- python3 "$REPO/bench.py" --gpus 1 --steps 300 --warmup 50 --no-cpu-baseline --latency-frames 50 --tune-cache /tmp/tune.json
   cd "$REPO"; find gpurun_out/prof -name '*stats*' | head; 
 fi
 exit 0
