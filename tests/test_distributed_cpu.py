@@ -55,7 +55,7 @@ def test_two_rank_gloo_gather_restores_frame_order():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, 8, q)) for r in range(2)]
     for p in procs:
         p.start()
-    ok = q.get(timeout=120)
+    ok = q.get(timeout=60)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

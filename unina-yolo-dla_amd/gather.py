@@ -47,7 +47,7 @@ def gather_slots(local, out=None, group=None):
     world = dist.get_world_size(group)
     if out is None:
         out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out.view(world, -1), local.reshape(-1), group=group)
+    dist.all_gather_into_tensor(out.view(-1), local.reshape(-1), group=group)   # flat concat: accepted by gloo and nccl
     return out
 
 
