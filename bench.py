@@ -31,7 +31,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np  # noqa: E402
 
 FLOPS_PER_FRAME = {640: 35_664_691_200, 1280: 142_658_764_800}   # SURVEY.md section 8d (2 x MACs, conv only)
-PEAK_TFLOPS = {"f16": 2500.0}                                     # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}                                     # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 N_FRAMES = 16            # distinct synthetic frames cycled through
 IN_FLIGHT = int(os.environ.get("UNINA_IN_FLIGHT", "2"))   # engine handles per GPU = frames in flight
@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--latency-frames", type=int, default=300)
+    ap.add_argument("--precision", choices=["fp16", "fp32"], default="fp16",
+                    help="fp16 = BASELINE configs[1] (headline); fp32 = native fp32-MFMA mode that meets the strict tolerance")
     ap.add_argument("--streams", type=int, default=0, help="parallel graph paths per engine (0 = library default)")
     ap.add_argument("--tune-cache", default=os.environ.get("UNINA_TUNE_CACHE", ""), help="tactic cache file (JSON)")
     args = ap.parse_args()
@@ -75,7 +77,8 @@ def main():
     sd = u.synth.make_state_dict(7, g)
     fd, path = tempfile.mkstemp(suffix=f".rank{rank}.une")
     os.close(fd)
-    export.export_engine(sd, path, g)
+    prec = export.FP32 if args.precision == "fp32" else export.FP16
+    export.export_engine(sd, path, g, prec)
     engines = [Engine(path, device=local) for _ in range(IN_FLIGHT)]
     os.unlink(path)
     streams = [torch.cuda.Stream(device=dev) for _ in range(IN_FLIGHT)]
@@ -137,6 +140,7 @@ def main():
 
         # ---- roofline of the dominant kernel: live HIP-event timing of every op on the launch stream ----
         ops = e0.profile_ops(iters=20)
+        dt = "f32" if args.precision == "fp32" else "f16"
         by_kernel = {}
         for o in ops:
             k = by_kernel.setdefault(o["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
@@ -148,8 +152,8 @@ def main():
             "bound": "mfma", "kernel": dom_name, "launches_per_frame": dom["launches"],
             "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 3),
             "flops_per_launch": dom["flops"] / dom["launches"],
-            "achieved": round(achieved_tf, 2), "peak": PEAK_TFLOPS["f16"], "unit": "TFLOP/s",
-            "frac": round(achieved_tf / PEAK_TFLOPS["f16"], 4), "traffic": None,
+            "achieved": round(achieved_tf, 2), "peak": PEAK_TFLOPS[dt], "unit": "TFLOP/s",
+            "frac": round(achieved_tf / PEAK_TFLOPS[dt], 4), "traffic": None,
             "algorithmic_gbs": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
             "sum_of_ops_ms": round(total_ms, 4),
             "whole_frame_tflops": round(fps / world * FLOPS_PER_FRAME.get(S, 0) / 1e12, 2),
@@ -163,8 +167,8 @@ def main():
             "metric": "frames/sec, 640x640 batch-1 (p99 latency alongside)" if S == 640 else f"frames/sec, {S}x{S} batch-1",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 5), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"unina-yolo-dla-m graph A fp16, batch=1, {S}x{S}, NMS on-GPU (BASELINE configs[1])",
+            "vs_baseline": None, "dtype": dt, "data": "synthetic",
+            "config": {"workload": f"unina-yolo-dla-m graph A {args.precision}, batch=1, {S}x{S}, NMS on-GPU (BASELINE configs[1])",
                        "frames_in_flight_per_gpu": IN_FLIGHT, "parallelism": f"replica x{world}, RCCL all-gather of detection slots every {GATHER_EVERY} frames" if world > 1 else "1 GPU",
                        "thresholds": {"conf": conf, "iou": 0.45, "conformal_q": 0.1}, "detections_last_frame": n_det},
             "latency_ms": {"p50": round(float(np.percentile(lat, 50)), 4), "p99": round(float(np.percentile(lat, 99)), 4),

@@ -12,7 +12,9 @@ from unina_yolo_dla_amd import export
 
 def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = True):
     """x: [1,3,H,W] fp32. Returns ({output name: [C,H,W] fp32}, {buffer name: [C,H,W] fp32})."""
-    q = (lambda t: t.half().float()) if fp16 else (lambda t: t)
+    fp32_engine = builder.precision == export.FP32
+    q = (lambda t: t.half().float()) if (fp16 and not fp32_engine) else (lambda t: t)
+    wdt = "<f4" if fp32_engine else "<f2"
     blob = bytes(builder.blob)
     bufs = {}
     for i, (name, h, w, c, dtype, flags) in enumerate(builder.buffers):
@@ -37,7 +39,7 @@ def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = Tr
         elif op.kind == export.OP_CONV:
             k = op.k
             for s in op.segs:
-                w = np.frombuffer(blob, dtype="<f2", count=s.n_pad * k * k * op.cin, offset=s.w_off)
+                w = np.frombuffer(blob, dtype=wdt, count=s.n_pad * k * k * op.cin, offset=s.w_off)
                 w = export.unpack_weights(w, s.n_pad, k * k * op.cin)
                 w = torch.from_numpy(w.reshape(s.n_pad, k, k, op.cin)[:s.n_count].astype(np.float32)).permute(0, 3, 1, 2).contiguous()
                 b = torch.from_numpy(np.frombuffer(blob, dtype="<f4", count=s.n_count, offset=s.b_off).copy())

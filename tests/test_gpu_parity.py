@@ -207,6 +207,62 @@ def test_fp16_engine_matches_fp16_emulator(pkg, sd7, eng640, torch_cuda):
         assert np.abs(got - named[bname]).max() <= 2e-3 * max(1.0, np.abs(named[bname]).max())
 
 
+# ---- fp32 precision mode: native fp32 MFMA, same graph, same kernels -> the north-star tolerance holds outright ----
+@pytest.fixture(scope="module")
+def eng640_fp32(pkg, sd7, torch_cuda):
+    from unina_yolo_dla_amd import export
+    from unina_yolo_dla_amd.engine import Engine
+    e = Engine.from_state_dict(sd7, precision=export.FP32)
+    yield e
+    e.close()
+
+
+def test_fp32_engine_heads_match_reference_fixture(pkg, eng640_fp32, torch_cuda):
+    gold = load_golden("frame640_seed1234.npz")
+    heads = eng640_fp32.forward(_frame(pkg, torch_cuda, 1234, 640))
+    for name in pkg.graph.OUTPUT_NAMES:
+        np.testing.assert_allclose(heads[name], gold[f"head/{name}"], atol=2e-4, rtol=0, err_msg=name)   # measured ~3e-5
+
+
+@pytest.mark.parametrize("q", [0.1, 0.0])
+def test_fp32_engine_meets_north_star_tolerance(pkg, eng640_fp32, oracle_mod, oracle_sd7, torch_cuda, q):
+    """BASELINE.json tolerance, every detection: IoU >= 0.999 and |score delta| < 1e-3 against the fp32 oracle, and
+    against the detections of the reference's own model.py + postprocess.hpp (fixture)."""
+    gold = load_golden("frame640_seed1234.npz")
+    for seed in (1234, 1235):
+        x = pkg.rng.frame(seed, 640, 640)
+        got = eng640_fp32.infer(torch_cuda.from_numpy(x).cuda(), 0.5, 0.45, q)
+        o = oracle_mod.forward(oracle_sd7, x)
+        want, _ = oracle_mod.postprocess([o[n] for n in pkg.graph.OUTPUT_NAMES], 0.5, 0.45, q)
+        stats = compare(got, want, 0.5, min_iou=0.999, score_tol=1e-3, max_unmatched_frac=0.005)
+        assert stats["matched"] >= len(want) - 2 and stats["max_dscore"] < 1e-4, stats
+        if seed == 1234:
+            ref = gold[f"ref_dets_q{q}"]
+            want = np.zeros(len(ref), dtype=got.dtype)
+            for f in ref.dtype.names:
+                want[f] = ref[f]
+            stats = compare(got, want, 0.5, min_iou=0.999, score_tol=1e-3, max_unmatched_frac=0.005)
+            assert stats["matched"] >= len(want) - 2, stats
+
+
+def test_fp32_engine_mini64_buffers(pkg, sd7, oracle_mod, oracle_sd7, torch_cuda):
+    from unina_yolo_dla_amd import export
+    from unina_yolo_dla_amd.engine import Engine
+    e = Engine.from_state_dict(sd7, pkg.graph.Graph(in_h=64, in_w=64), precision=export.FP32)
+    try:
+        x = pkg.rng.frame(1234, 64, 64)
+        heads = e.forward(torch_cuda.from_numpy(x).cuda())
+        ref = oracle_mod.forward(oracle_sd7, x, keep_all=True)
+        for name in pkg.graph.OUTPUT_NAMES:
+            np.testing.assert_allclose(heads[name], ref[name], atol=1e-4, rtol=0, err_msg=name)
+        for bname, oname in {"backbone.stem": "backbone.stem", "backbone.sppf.cat": "backbone.sppf.cat",
+                             "neck.cat_fpn2": "neck.cat_fpn2", "neck.cat_pan2": "neck.cat_pan2",
+                             "p4_out": "neck.pan_c3k2_2.cv3"}.items():
+            np.testing.assert_allclose(e.read_buffer(bname), ref[oname], atol=1e-4, rtol=1e-4, err_msg=bname)
+    finally:
+        e.close()
+
+
 def test_determinism_and_rebinding(pkg, eng640, torch_cuda):
     xs = [_frame(pkg, torch_cuda, s, 640) for s in (1, 2)]
     first = [eng640.infer(x).tobytes() for x in xs]

@@ -44,14 +44,45 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+
+// Element-type traits. A 1-KiB fragment block is always 16 rows x 4 chunks of 16 bytes:
+//   fp16: chunk = 8 k  -> block = 32 k, one v_mfma_f32_16x16x32_f16 per (A block, B block)
+//   fp32: chunk = 4 k  -> block = 16 k, four v_mfma_f32_16x16x4_f32 (exact fp32 products and accumulation);
+//         MFMA e takes element e of every lane's chunk, i.e. k = {4*lq + e}: A and B use the same k permutation.
+template <typename T> struct Elem;
+template <> struct Elem<half_t> {
+  static constexpr int kChunk = 8, kBlockK = 32;
+  typedef half8 frag;
+  typedef half4 out4;
+  static __device__ __forceinline__ floatx4 mma(const frag& a, const frag& b, floatx4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Elem<float> {
+  static constexpr int kChunk = 4, kBlockK = 16;
+  typedef floatx4_t frag;
+  typedef floatx4_t out4;
+  static __device__ __forceinline__ floatx4 mma(const frag& a, const frag& b, floatx4 c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
+    return c;
+  }
+};
+
 }  // namespace
 
 extern __shared__ __align__(16) unsigned char conv_smem[];
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
-__global__ __launch_bounds__(256) void conv_glds_f16(const ConvParams p) {
+// BK is counted in fragment blocks' worth of k: KSUB = BK/32 blocks per row-subtile per K-step, i.e. a K-step covers
+// KSUB*32 input channels in fp16 and KSUB*16 in fp32.
+template <typename T, int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(256) void conv_glds(const ConvParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "256-thread blocks");
+  typedef Elem<T> E;
+  typedef typename E::frag frag_t;
   constexpr int WM_T = BM / (WAVES_M * 16), WN_T = BN / (WAVES_N * 16), KSUB = BK / 32;
+  constexpr int KSTEP = KSUB * E::kBlockK;  // input channels per K-step
   constexpr int ABLK = (BM / 16) * KSUB, WBLK = (BN / 16) * KSUB, NBLK = ABLK + WBLK;
   constexpr int LPT = (NBLK + 3) / 4;            // LDS-DMA instructions per wave per stage (same for every wave)
   constexpr int STAGE_BYTES = LPT * 4 * 1024;
@@ -67,7 +98,7 @@ __global__ __launch_bounds__(256) void conv_glds_f16(const ConvParams p) {
   const int n_pad = (sg.n_count + 15) & ~15;
   const int nb0 = ((int)blockIdx.y - sg.tile0) * BN;  // first channel of this block's tile (slice-relative)
   const int m_blk = blockIdx.x * BM;
-  const int kblocks = p.ksize * p.ksize * (p.Cin / 32);  // 32-wide k blocks per weight row
+  const int kblocks = p.ksize * p.ksize * (p.Cin / E::kBlockK);  // k blocks per weight row
 
   // ---- per-thread description of the LPT blocks this wave loads every stage (block b = q*4 + wid) ----
   // activation block (i,j): rows = pixels m_blk + 16*i .. +16, k = 32*j .. +32 of the K-step
@@ -75,8 +106,8 @@ __global__ __launch_bounds__(256) void conv_glds_f16(const ConvParams p) {
   const int ld_row = lane >> 2;                                  // row (pixel / channel) this lane fetches
   const int ld_chunk = (lane & 3) ^ swz_g(ld_row);              // 8-element k-chunk this lane fetches
   int a_iy0[LPT], a_ix0[LPT];                                    // input coords of tap (0,0), or big negative if row invalid
-  const half_t* a_base[LPT];                                     // src + channel offset of this lane's chunk
-  const half_t* w_base[LPT];                                     // weight block address for k32 = 0 (nullptr = zero rows)
+  const T* a_base[LPT];                                          // src + channel offset of this lane's chunk
+  const T* w_base[LPT];                                          // weight block address for k block 0 (nullptr = zero rows)
   int kind[LPT];                                                 // 0 activation, 1 weight, 2 padding
 #pragma unroll
   for (int q = 0; q < LPT; ++q) {
@@ -93,13 +124,13 @@ __global__ __launch_bounds__(256) void conv_glds_f16(const ConvParams p) {
         a_iy0[q] = oy * p.stride - p.pad;
         a_ix0[q] = ox * p.stride - p.pad;
       }
-      a_base[q] = p.src + sg.src_coff + j * 32 + ld_chunk * 8;
+      a_base[q] = static_cast<const T*>(p.src) + sg.src_coff + j * E::kBlockK + ld_chunk * E::kChunk;
     } else if (b < NBLK) {
       kind[q] = 1;
       const int bb = b - ABLK;
       const int n = bb / KSUB, j = bb - n * KSUB;
       const int nsub = (nb0 >> 4) + n;
-      if (nsub * 16 < n_pad) w_base[q] = sg.w + ((size_t)nsub * kblocks + j) * 512 + lane * 8;
+      if (nsub * 16 < n_pad) w_base[q] = static_cast<const T*>(sg.w) + ((size_t)nsub * kblocks + j) * (1024 / sizeof(T)) + lane * E::kChunk;
     } else {
       kind[q] = 2;
     }
@@ -107,27 +138,27 @@ __global__ __launch_bounds__(256) void conv_glds_f16(const ConvParams p) {
 
   // K-step iterator for the NEXT stage to issue
   int i_kh = 0, i_kw = 0, i_c0 = 0, i_k32 = 0, i_kt = 0;
-  const int nk = p.ksize * p.ksize * (p.Cin / BK);
-  const half_t* zeros = reinterpret_cast<const half_t*>(p.zeros);
+  const int nk = p.ksize * p.ksize * (p.Cin / KSTEP);
+  const T* zeros = reinterpret_cast<const T*>(p.zeros);
 
   auto issue = [&](int buf) {
     unsigned char* sb = conv_smem + buf * STAGE_BYTES;
     const bool live = i_kt < nk;
 #pragma unroll
     for (int q = 0; q < LPT; ++q) {
-      const half_t* g = zeros;
+      const T* g = zeros;
       if (live) {
         if (kind[q] == 0) {
           const int iy = a_iy0[q] + i_kh, ix = a_ix0[q] + i_kw;
           if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) g = a_base[q] + (size_t)(iy * p.W + ix) * p.src_ld + i_c0;
         } else if (kind[q] == 1) {
-          if (w_base[q]) g = w_base[q] + (size_t)i_k32 * 512;
+          if (w_base[q]) g = w_base[q] + (size_t)i_k32 * (1024 / sizeof(T));
         }
       }
       glds16(g, sb + (q * 4 + wid) * 1024);
     }
     ++i_kt;
-    i_c0 += BK;
+    i_c0 += KSTEP;
     i_k32 += KSUB;
     if (i_c0 >= p.Cin) {
       i_c0 = 0;
@@ -156,15 +187,15 @@ __global__ __launch_bounds__(256) void conv_glds_f16(const ConvParams p) {
     const unsigned char* sb = conv_smem + (kt % STAGES) * STAGE_BYTES + rd_off;
 #pragma unroll
     for (int j = 0; j < KSUB; ++j) {
-      half8 a[WN_T], b[WM_T];
+      frag_t a[WN_T], b[WM_T];
 #pragma unroll
-      for (int i = 0; i < WM_T; ++i) b[i] = *reinterpret_cast<const half8*>(sb + (((wm * WM_T + i) * KSUB + j) << 10));
+      for (int i = 0; i < WM_T; ++i) b[i] = *reinterpret_cast<const frag_t*>(sb + (((wm * WM_T + i) * KSUB + j) << 10));
 #pragma unroll
-      for (int n = 0; n < WN_T; ++n) a[n] = *reinterpret_cast<const half8*>(sb + ((ABLK + (wn * WN_T + n) * KSUB + j) << 10));
+      for (int n = 0; n < WN_T; ++n) a[n] = *reinterpret_cast<const frag_t*>(sb + ((ABLK + (wn * WN_T + n) * KSUB + j) << 10));
 #pragma unroll
       for (int n = 0; n < WN_T; ++n)
 #pragma unroll
-        for (int i = 0; i < WM_T; ++i) acc[n][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[n], b[i], acc[n][i], 0, 0, 0);
+        for (int i = 0; i < WM_T; ++i) acc[n][i] = E::mma(a[n], b[i], acc[n][i]);
     }
   }
   wait_vmcnt<0>();  // drain the dummy tail before the wave retires
@@ -187,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_glds_f16(const ConvParams p) {
         for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
       }
       if (p.res) {
-        const half4 rv = *reinterpret_cast<const half4*>(p.res + (size_t)m * p.res_ld + n);
+        const typename E::out4 rv = *reinterpret_cast<const typename E::out4*>(static_cast<const T*>(p.res) + (size_t)m * p.res_ld + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
       }
@@ -196,19 +227,21 @@ __global__ __launch_bounds__(256) void conv_glds_f16(const ConvParams p) {
         for (int r = 0; r < 4; ++r)
           if (n + r < sg.n_count) sg.dst_planar[(size_t)(n + r) * p.M + m] = v[r];
       } else {
-        half4 hv;
+        typedef typename E::out4 out4;
+        out4 hv;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hv[r] = (half_t)v[r];
+        for (int r = 0; r < 4; ++r) hv[r] = (T)v[r];
+        T* dst = static_cast<T*>(sg.dst);
         if (sg.up2) {
           const int oy = m / p.Wo, ox = m - oy * p.Wo;
           const size_t row = (size_t)(2 * oy) * (2 * p.Wo) + 2 * ox;
-          half_t* d = sg.dst + row * sg.dst_ld + n;
-          *reinterpret_cast<half4*>(d) = hv;
-          *reinterpret_cast<half4*>(d + sg.dst_ld) = hv;
-          *reinterpret_cast<half4*>(d + (size_t)(2 * p.Wo) * sg.dst_ld) = hv;
-          *reinterpret_cast<half4*>(d + (size_t)(2 * p.Wo + 1) * sg.dst_ld) = hv;
+          T* d = dst + row * sg.dst_ld + n;
+          *reinterpret_cast<out4*>(d) = hv;
+          *reinterpret_cast<out4*>(d + sg.dst_ld) = hv;
+          *reinterpret_cast<out4*>(d + (size_t)(2 * p.Wo) * sg.dst_ld) = hv;
+          *reinterpret_cast<out4*>(d + (size_t)(2 * p.Wo + 1) * sg.dst_ld) = hv;
         } else {
-          *reinterpret_cast<half4*>(sg.dst + (size_t)m * sg.dst_ld + n) = hv;
+          *reinterpret_cast<out4*>(dst + (size_t)m * sg.dst_ld + n) = hv;
         }
       }
     }
@@ -230,22 +263,39 @@ constexpr size_t smem_of() {
   return (size_t)ST * (((BM / 16 + BN / 16) * (BK / 32) + 3) / 4) * 4 * 1024;
 }
 
-#define CFG(BM, BN, BK, WM, WN, ST)                                                             \
-  {BM, BN, BK, ST, "conv_glds_f16<" #BM "," #BN "," #BK "," #WM "," #WN "," #ST ">",            \
-   conv_glds_f16<BM, BN, BK, WM, WN, ST>, smem_of<BM, BN, BK, WM, WN, ST>()}
+#define CFG(T, TN, BM, BN, BK, WM, WN, ST)                                                         \
+  {BM, BN, BK, ST, "conv_glds<" TN "," #BM "," #BN "," #BK "," #WM "," #WN "," #ST ">",            \
+   conv_glds<T, BM, BN, BK, WM, WN, ST>, smem_of<BM, BN, BK, WM, WN, ST>()}
 
-const CfgInfo kCfg[kCfgCount] = {
-    CFG(64, 64, 64, 2, 2, 4),    // kCfg64x64k64
-    CFG(64, 64, 32, 2, 2, 4),    // kCfg64x64k32
-    CFG(128, 64, 64, 2, 2, 3),   // kCfg128x64k64
-    CFG(128, 64, 32, 2, 2, 4),   // kCfg128x64k32
-    CFG(128, 128, 64, 2, 2, 3),  // kCfg128x128k64
-    CFG(128, 32, 64, 4, 1, 3),   // kCfg128x32k64
-    CFG(128, 32, 32, 4, 1, 4),   // kCfg128x32k32
-    CFG(128, 16, 64, 4, 1, 3),   // kCfg128x16k64
-    CFG(32, 64, 64, 1, 4, 4),    // kCfg32x64k64
+// [dtype][config]; BK is in fp16-equivalent k (KSUB = BK/32 fragment blocks): a K-step covers BK channels in fp16
+// and BK/2 channels in fp32.
+const CfgInfo kCfg[2][kCfgCount] = {
+    {
+        CFG(half_t, "f16", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
+        CFG(half_t, "f16", 64, 64, 32, 2, 2, 4),    // kCfg64x64k32
+        CFG(half_t, "f16", 128, 64, 64, 2, 2, 3),   // kCfg128x64k64
+        CFG(half_t, "f16", 128, 64, 32, 2, 2, 4),   // kCfg128x64k32
+        CFG(half_t, "f16", 128, 128, 64, 2, 2, 3),  // kCfg128x128k64
+        CFG(half_t, "f16", 128, 32, 64, 4, 1, 3),   // kCfg128x32k64
+        CFG(half_t, "f16", 128, 32, 32, 4, 1, 4),   // kCfg128x32k32
+        CFG(half_t, "f16", 128, 16, 64, 4, 1, 3),   // kCfg128x16k64
+        CFG(half_t, "f16", 32, 64, 64, 1, 4, 4),    // kCfg32x64k64
+    },
+    {
+        CFG(float, "f32", 64, 64, 64, 2, 2, 4),
+        CFG(float, "f32", 64, 64, 32, 2, 2, 4),
+        CFG(float, "f32", 128, 64, 64, 2, 2, 3),
+        CFG(float, "f32", 128, 64, 32, 2, 2, 4),
+        CFG(float, "f32", 128, 128, 64, 2, 2, 3),
+        CFG(float, "f32", 128, 32, 64, 4, 1, 3),
+        CFG(float, "f32", 128, 32, 32, 4, 1, 4),
+        CFG(float, "f32", 128, 16, 64, 4, 1, 3),
+        CFG(float, "f32", 32, 64, 64, 1, 4, 4),
+    },
 };
 #undef CFG
+
+inline int kstep_of(const ConvParams& p, const CfgInfo& c) { return (c.bk / 32) * (p.dtype == kF32 ? 16 : 32); }
 
 int n_tiles(const ConvParams& p, int bn) {
   int t = 0;
@@ -256,18 +306,19 @@ int n_tiles(const ConvParams& p, int bn) {
 }  // namespace
 
 hipError_t conv_init() {
-  for (int c = 0; c < kCfgCount; ++c) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kCfg[c].fn),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCfg[c].smem);
-    if (e != hipSuccess) return e;
-  }
+  for (int d = 0; d < 2; ++d)
+    for (int c = 0; c < kCfgCount; ++c) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kCfg[d][c].fn),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCfg[d][c].smem);
+      if (e != hipSuccess) return e;
+    }
   return hipSuccess;
 }
 
 bool conv_config_valid(const ConvParams& p, int cfg) {
   if (cfg < 0 || cfg >= kCfgCount) return false;
-  const CfgInfo& c = kCfg[cfg];
-  if (p.Cin % c.bk) return false;
+  const CfgInfo& c = kCfg[p.dtype][cfg];
+  if (p.Cin % kstep_of(p, c)) return false;
   int min_npad = 1 << 30;
   for (int s = 0; s < p.nseg; ++s) {
     const int np = (p.seg[s].n_count + 15) & ~15;
@@ -277,7 +328,7 @@ bool conv_config_valid(const ConvParams& p, int cfg) {
 }
 
 ConvLaunch conv_plan_with(const ConvParams& p, int cfg) {
-  const CfgInfo& c = kCfg[cfg];
+  const CfgInfo& c = kCfg[p.dtype][cfg];
   ConvLaunch l;
   l.cfg = (ConvConfig)cfg;
   l.grid = dim3((p.M + c.bm - 1) / c.bm, n_tiles(p, c.bn), 1);
@@ -290,7 +341,7 @@ ConvLaunch conv_plan_with(const ConvParams& p, int cfg) {
 ConvLaunch conv_plan(const ConvParams& p) {
   const int override_cfg = p.force_cfg;
   if (override_cfg >= 0 && conv_config_valid(p, override_cfg)) return conv_plan_with(p, override_cfg);
-  const bool k64 = (p.Cin % 64) == 0;
+  const bool k64 = (p.Cin % (p.dtype == kF32 ? 32 : 64)) == 0;
   int min_npad = 1 << 30;
   for (int s = 0; s < p.nseg; ++s) {
     const int np = (p.seg[s].n_count + 15) & ~15;
@@ -300,7 +351,7 @@ ConvLaunch conv_plan(const ConvParams& p) {
   if (min_npad < 32) cfg = kCfg128x16k64;
   else if (min_npad < 64) cfg = k64 ? kCfg128x32k64 : kCfg128x32k32;
   else {
-    auto blocks = [&](int c) { return ((p.M + kCfg[c].bm - 1) / kCfg[c].bm) * n_tiles(p, kCfg[c].bn); };
+    auto blocks = [&](int c) { return ((p.M + kCfg[0][c].bm - 1) / kCfg[0][c].bm) * n_tiles(p, kCfg[0][c].bn); };
     const int want = 384;
     if (k64 && min_npad >= 128 && blocks(kCfg128x128k64) >= want) cfg = kCfg128x128k64;
     else if (blocks(k64 ? kCfg128x64k64 : kCfg128x64k32) >= want) cfg = k64 ? kCfg128x64k64 : kCfg128x64k32;
@@ -313,7 +364,7 @@ ConvLaunch conv_plan(const ConvParams& p) {
 
 hipError_t conv_launch(const ConvParams& pin, const ConvLaunch& l, hipStream_t stream) {
   ConvParams p = pin;
-  const CfgInfo& c = kCfg[l.cfg];
+  const CfgInfo& c = kCfg[p.dtype][l.cfg];
   int t = 0;
   for (int s = 0; s < p.nseg; ++s) {
     p.seg[s].tile0 = t;
@@ -323,6 +374,8 @@ hipError_t conv_launch(const ConvParams& pin, const ConvLaunch& l, hipStream_t s
   return hipGetLastError();
 }
 
-const char* conv_config_name(int cfg) { return (cfg >= 0 && cfg < kCfgCount) ? kCfg[cfg].name : "?"; }
+const char* conv_config_name(int cfg, int dtype) {
+  return (cfg >= 0 && cfg < kCfgCount && (dtype == kF16 || dtype == kF32)) ? kCfg[dtype][cfg].name : "?";
+}
 
 }  // namespace unina

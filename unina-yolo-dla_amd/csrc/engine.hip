@@ -104,6 +104,8 @@ size_t buffer_bytes(const BufferDesc& d) {
   return d.dtype == kBufF16Nhwc ? n * 2 : n * 4;
 }
 
+int engine_dtype(const unina_engine* e);
+
 void drop_graph(unina_engine* e) {
   if (e->exec) (void)hipGraphExecDestroy(e->exec);
   if (e->graph) (void)hipGraphDestroy(e->graph);
@@ -111,9 +113,14 @@ void drop_graph(unina_engine* e) {
   e->graph = nullptr;
 }
 
+int engine_dtype(const unina_engine* e) { return e->h.precision == kFp32 ? kF32 : kF16; }
+
 // (Re)computes kernel parameters from the current buffer addresses.
 int plan(unina_engine* e) {
   const char* blob = static_cast<const char*>(e->d_blob);
+  const int dt = engine_dtype(e);
+  const size_t esz = dt == kF32 ? 4 : 2;
+  const uint32_t act_dtype = dt == kF32 ? kBufF32Nhwc : kBufF16Nhwc;
   for (size_t i = 0; i < e->ops.size(); ++i) {
     PlannedOp& op = e->ops[i];
     const OpDesc& d = op.d;
@@ -125,7 +132,9 @@ int plan(unina_engine* e) {
     if (d.kind == kOpConv) {
       ConvParams& p = op.cp;
       memset(&p, 0, sizeof p);
-      p.src = static_cast<const half_t*>(src.ptr);
+      p.dtype = dt;
+      if (src.d.dtype != act_dtype) return fail(e, UNINA_ERR_FORMAT, "op %zu: source buffer dtype does not match the engine precision", i);
+      p.src = src.ptr;
       p.src_ld = (int)src.d.c;
       p.H = (int)d.in_h; p.W = (int)d.in_w; p.Cin = (int)d.cin;
       p.Ho = (int)d.out_h; p.Wo = (int)d.out_w; p.M = p.Ho * p.Wo;
@@ -133,7 +142,7 @@ int plan(unina_engine* e) {
       p.relu = (int)d.relu;
       if (d.res_buf >= 0) {
         const Buffer& rb = e->bufs[d.res_buf];
-        p.res = static_cast<const half_t*>(rb.ptr) + d.res_coff;
+        p.res = static_cast<const char*>(rb.ptr) + (size_t)d.res_coff * esz;
         p.res_ld = (int)rb.d.c;
       }
       p.nseg = (int)d.nseg;
@@ -145,7 +154,7 @@ int plan(unina_engine* e) {
         const SegDesc& sd = d.seg[s];
         const Buffer& db = e->bufs[sd.dst_buf];
         ConvSeg& cs = p.seg[s];
-        cs.w = reinterpret_cast<const half_t*>(blob + sd.w_off);
+        cs.w = blob + sd.w_off;
         cs.bias = reinterpret_cast<const float*>(blob + sd.b_off);
         cs.src_coff = (int)sd.src_coff;
         cs.n_count = (int)sd.n_count;
@@ -157,23 +166,24 @@ int plan(unina_engine* e) {
           cs.dst_ld = 0;
           out_bytes += 4.0 * sd.n_count * p.M;
         } else {
-          if (db.d.dtype != kBufF16Nhwc || sd.n_count % 4) return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: NHWC slice needs n %% 4 == 0", i);
-          cs.dst = static_cast<half_t*>(db.ptr) + sd.dst_coff;
+          if (db.d.dtype != act_dtype || sd.n_count % 4) return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: NHWC slice needs n %% 4 == 0", i);
+          cs.dst = static_cast<char*>(db.ptr) + (size_t)sd.dst_coff * esz;
           cs.dst_planar = nullptr;
           cs.dst_ld = (int)db.d.c;
-          out_bytes += 2.0 * sd.n_count * p.M * (cs.up2 ? 4 : 1);
+          out_bytes += (double)esz * sd.n_count * p.M * (cs.up2 ? 4 : 1);
         }
         ntot += (int)sd.n_count;
       }
       if (p.Cin % 32 || p.src_ld % 8) return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu (%s): Cin %% 32 != 0", i, d.name);
+      if (p.force_cfg >= 0 && !conv_config_valid(p, p.force_cfg)) p.force_cfg = -1;
       op.cl = conv_plan(p);
       const int K = p.ksize * p.ksize * p.Cin;
       info.m = p.M; info.n = ntot; info.k = K;
       info.flops = 2.0 * p.M * (double)ntot * K;
       // algorithmic bytes: each distinct input element once, weights once, outputs once, residual once
       const bool shared_src = p.nseg == 1 || d.seg[0].src_coff == d.seg[1].src_coff;
-      info.bytes = 2.0 * p.H * p.W * p.Cin * (shared_src ? 1 : p.nseg) + 2.0 * ntot * K + 4.0 * ntot + out_bytes +
-                   (p.res ? 2.0 * p.M * ntot : 0.0);
+      info.bytes = (double)esz * p.H * p.W * p.Cin * (shared_src ? 1 : p.nseg) + (double)esz * ntot * K + 4.0 * ntot + out_bytes +
+                   (p.res ? (double)esz * p.M * ntot : 0.0);
       snprintf(info.kernel, sizeof info.kernel, "%s", op.cl.kernel_name);
       info.grid = (int)(op.cl.grid.x * op.cl.grid.y);
       info.block = (int)op.cl.block.x;
@@ -181,24 +191,26 @@ int plan(unina_engine* e) {
       const SegDesc& sd = d.seg[0];
       const Buffer& db = e->bufs[sd.dst_buf];
       StemParams& p = op.sp;
+      p.dtype = dt;
       p.src = static_cast<const float*>(src.ptr);
       p.w = reinterpret_cast<const float*>(blob + sd.w_off);
       p.bias = reinterpret_cast<const float*>(blob + sd.b_off);
-      p.dst = static_cast<half_t*>(db.ptr) + sd.dst_coff;
+      p.dst = static_cast<char*>(db.ptr) + (size_t)sd.dst_coff * esz;
       p.H = (int)d.in_h; p.W = (int)d.in_w; p.Ho = (int)d.out_h; p.Wo = (int)d.out_w;
       p.Co = (int)sd.n_count; p.dst_ld = (int)db.d.c;
       info.m = p.Ho * p.Wo; info.n = p.Co; info.k = 27;
       info.flops = 2.0 * info.m * info.n * 27;
-      info.bytes = 4.0 * 3 * p.H * p.W + 2.0 * info.m * p.Co;
-      snprintf(info.kernel, sizeof info.kernel, "stem_conv_kernel<%d>", p.Co);
+      info.bytes = 4.0 * 3 * p.H * p.W + (double)esz * info.m * p.Co;
+      snprintf(info.kernel, sizeof info.kernel, "stem_conv_kernel<%s,%d>", dt == kF32 ? "f32" : "f16", p.Co);
       info.grid = (info.m + 255) / 256;
       info.block = 256;
     } else if (d.kind == kOpSppfPool) {
       PoolParams& p = op.pp;
-      p.buf = static_cast<half_t*>(src.ptr);
+      p.dtype = dt;
+      p.buf = src.ptr;
       p.H = (int)d.in_h; p.W = (int)d.in_w; p.C = (int)d.cin; p.ld = (int)src.d.c; p.coff = (int)d.seg[0].src_coff;
-      info.bytes = 2.0 * p.H * p.W * p.C * 4;
-      snprintf(info.kernel, sizeof info.kernel, "sppf_pool_kernel<32>");
+      info.bytes = (double)esz * p.H * p.W * p.C * 4;
+      snprintf(info.kernel, sizeof info.kernel, "sppf_pool_kernel<%s,32>", dt == kF32 ? "f32" : "f16");
       info.grid = p.H * (p.C / 32);
       info.block = 256;
     } else {
@@ -418,7 +430,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   if (fread(&e->h, sizeof e->h, 1, f) != 1) return bail(UNINA_ERR_FORMAT, "truncated header");
   if (memcmp(e->h.magic, kMagic, 8)) return bail(UNINA_ERR_FORMAT, "bad magic (not a UNINAENG file)");
   if (e->h.version != kVersion) return bail(UNINA_ERR_FORMAT, "unsupported engine file version");
-  if (e->h.precision != kFp16) return bail(UNINA_ERR_UNSUPPORTED, "this build executes fp16 engines only");
+  if (e->h.precision != kFp16 && e->h.precision != kFp32) return bail(UNINA_ERR_UNSUPPORTED, "this build executes fp16 and fp32 engines (no int8 yet)");
   if (e->h.n_heads != 3 || e->h.n_buffers == 0 || e->h.n_buffers > 4096 || e->h.n_ops == 0 || e->h.n_ops > 4096)
     return bail(UNINA_ERR_FORMAT, "implausible table sizes");
   e->bufs.resize(e->h.n_buffers);
@@ -441,7 +453,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
       const SegDesc& sd = o.d.seg[s];
       if (sd.dst_buf >= e->h.n_buffers) return bail(UNINA_ERR_FORMAT, "op table: bad destination buffer");
       if (o.d.kind == kOpConv) {
-        const uint64_t wbytes = (uint64_t)sd.n_pad * o.d.ksize * o.d.ksize * o.d.cin * 2;
+        const uint64_t wbytes = (uint64_t)sd.n_pad * o.d.ksize * o.d.ksize * o.d.cin * (e->h.precision == kFp32 ? 4 : 2);
         if (sd.w_off + wbytes > e->h.blob_bytes || sd.b_off + (uint64_t)sd.n_pad * 4 > e->h.blob_bytes || sd.w_off % 16 || sd.b_off % 16)
           return bail(UNINA_ERR_FORMAT, "op table: weight offset outside blob");
         const BufferDesc& sb = e->bufs[o.d.src_buf].d;
@@ -643,7 +655,7 @@ int unina_get_op_info(const unina_engine_t* ce, int index, unina_op_info* info) 
 
 int unina_conv_config_count(void) { return (int)kCfgCount; }
 
-const char* unina_conv_config_name(int cfg) { return conv_config_name(cfg); }
+const char* unina_conv_config_name(int cfg) { return conv_config_name(cfg, kF16); }
 
 int unina_set_op_config(unina_engine_t* e, int op_index, int cfg) {
   if (!e || op_index < 0 || op_index >= (int)e->ops.size()) return UNINA_ERR_ARG;
@@ -743,7 +755,13 @@ int unina_debug_read_buffer(unina_engine_t* e, const char* name, float* host_out
   if (w) *w = (int)b.d.w;
   if (capacity < n) return fail(e, UNINA_ERR_ARG, "buffer '%s' needs %zu floats", name, n);  // dims are still reported
   HIPCHK(e, hipDeviceSynchronize());
-  if (b.d.dtype == kBufF16Nhwc) {
+  if (b.d.dtype == kBufF32Nhwc) {
+    std::vector<float> tmp(n);
+    HIPCHK(e, hipMemcpy(tmp.data(), b.ptr, n * 4, hipMemcpyDeviceToHost));
+    const size_t hw = (size_t)b.d.h * b.d.w;
+    for (size_t p = 0; p < hw; ++p)
+      for (size_t ch = 0; ch < b.d.c; ++ch) host_out[ch * hw + p] = tmp[p * b.d.c + ch];
+  } else if (b.d.dtype == kBufF16Nhwc) {
     std::vector<uint16_t> tmp(n);
     HIPCHK(e, hipMemcpy(tmp.data(), b.ptr, n * 2, hipMemcpyDeviceToHost));
     const size_t hw = (size_t)b.d.h * b.d.w;

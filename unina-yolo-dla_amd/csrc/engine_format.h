@@ -11,8 +11,8 @@ namespace unina {
 constexpr char kMagic[8] = {'U', 'N', 'I', 'N', 'A', 'E', 'N', 'G'};
 constexpr uint32_t kVersion = 2;  // 2: conv weights stored as swizzled 1-KiB fragment blocks
 
-enum Precision : uint32_t { kFp16 = 0, kInt8 = 1 };
-enum BufDtype : uint32_t { kBufF16Nhwc = 0, kBufF32Planar = 1, kBufF32NchwInput = 2, kBufI8Nhwc = 3 };
+enum Precision : uint32_t { kFp16 = 0, kInt8 = 1, kFp32 = 2 };
+enum BufDtype : uint32_t { kBufF16Nhwc = 0, kBufF32Planar = 1, kBufF32NchwInput = 2, kBufI8Nhwc = 3, kBufF32Nhwc = 4 };
 enum BufFlags : uint32_t { kBufInput = 1, kBufOutput = 2 };
 enum OpKind : uint32_t { kOpConv = 1, kOpStem = 2, kOpSppfPool = 3, kOpUpsample = 4 };
 enum SegFlags : uint32_t { kSegUp2 = 1, kSegPlanarF32 = 2 };

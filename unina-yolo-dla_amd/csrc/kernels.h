@@ -8,6 +8,7 @@
 namespace unina {
 
 typedef _Float16 half_t;
+enum DType : int { kF16 = 0, kF32 = 1 };   // element type of activations + weights of an engine (accumulation is always fp32)
 
 // ------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution  D[cout][pixel] = sum_k W[cout][k] * X[pixel][k]   (+bias, ReLU, +residual)
@@ -16,9 +17,9 @@ typedef _Float16 half_t;
 // One launch covers up to two output-channel slices (merged sibling convs / two-group head layers).
 // ------------------------------------------------------------------------------------------------
 struct ConvSeg {
-  const half_t* w;     // packed 1-KiB fragment blocks [n_pad/16][K/32][64 slots][8] (export.py: pack_weights)
+  const void* w;       // packed 1-KiB fragment blocks [n_pad/16][K/kb][64 slots][16 B], kb = 32 (fp16) / 16 (fp32)
   const float* bias;   // [n_pad]
-  half_t* dst;         // NHWC fp16 destination, channel offset already applied (unused when planar)
+  void* dst;           // NHWC destination (engine dtype), channel offset already applied (unused when planar)
   float* dst_planar;   // fp32 [n][Ho*Wo] destination (head outputs), or nullptr
   int src_coff;        // channel offset of this slice's input
   int n_count;         // valid output channels
@@ -28,13 +29,14 @@ struct ConvSeg {
 };
 
 struct ConvParams {
-  const half_t* src;
+  int dtype;           // DType of src / weights / dst / res
+  const void* src;
   int src_ld;          // channels per pixel of the source buffer
   int H, W, Cin;       // input spatial size, input channels of each slice
   int Ho, Wo, M;       // output spatial size, M = Ho*Wo
   int ksize, stride, pad;
   int relu;
-  const half_t* res;   // residual (added after ReLU), channel offset applied; nullptr = none
+  const void* res;     // residual (added after ReLU), channel offset applied; nullptr = none
   int res_ld;
   int nseg;
   ConvSeg seg[2];
@@ -56,17 +58,18 @@ hipError_t conv_init();                                  // once per process: ra
 bool conv_config_valid(const ConvParams& p, int cfg);
 ConvLaunch conv_plan(const ConvParams& p);               // heuristic (or p.force_cfg)
 ConvLaunch conv_plan_with(const ConvParams& p, int cfg);
-const char* conv_config_name(int cfg);
+const char* conv_config_name(int cfg, int dtype = kF16);
 hipError_t conv_launch(const ConvParams& p, const ConvLaunch& l, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // Stem: fp32 NCHW image -> 3x3/s2 conv (Cin=3) + bias + ReLU -> NHWC fp16
 // ------------------------------------------------------------------------------------------------
 struct StemParams {
+  int dtype;           // DType of dst
   const float* src;    // [3][H][W]
   const float* w;      // [Co][27], (c,kh,kw)
   const float* bias;   // [Co]
-  half_t* dst;         // [Ho][Wo][dst_ld]
+  void* dst;           // [Ho][Wo][dst_ld]
   int H, W, Ho, Wo, Co, dst_ld;
 };
 hipError_t stem_launch(const StemParams& p, hipStream_t stream, dim3* grid_out = nullptr, dim3* block_out = nullptr);
@@ -76,7 +79,8 @@ hipError_t stem_launch(const StemParams& p, hipStream_t stream, dim3* grid_out =
 // x is channels [coff, coff+C) of buf; y1,y2,y3 are written at coff+C, coff+2C, coff+3C of the same buffer.
 // ------------------------------------------------------------------------------------------------
 struct PoolParams {
-  half_t* buf;
+  int dtype;
+  void* buf;
   int H, W, C, ld, coff;
 };
 hipError_t sppf_pool_launch(const PoolParams& p, hipStream_t stream, dim3* grid_out = nullptr, dim3* block_out = nullptr);

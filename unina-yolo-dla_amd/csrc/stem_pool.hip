@@ -14,7 +14,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // and ALL output channels: a wave's 27 input loads each cover 64 neighbouring pixels (stride-2 fp32: every fetched
 // line is used), the 27x32 folded weights are LDS broadcast reads (ds_read_b128, same address in every lane), and
 // each lane stores its pixel's 64 contiguous NHWC bytes.
-template <int CO>
+template <typename T, int CO>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
   __shared__ __align__(16) float sw[27 * CO];
   __shared__ __align__(16) float sb[CO];
@@ -52,13 +52,15 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
       acc[r + 3] = __builtin_fmaf(x[k], w4.w, acc[r + 3]);
     }
   }
-  half_t* d = p.dst + (size_t)m * p.dst_ld;
+  T* d = static_cast<T*>(p.dst) + (size_t)m * p.dst_ld;
+  constexpr int V = 16 / sizeof(T);  // elements per 16-byte store
+  typedef T vec_t __attribute__((ext_vector_type(V)));
 #pragma unroll
-  for (int r = 0; r < CO; r += 8) {
-    half8 hv;
+  for (int r = 0; r < CO; r += V) {
+    vec_t hv;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) hv[q] = (half_t)(acc[r + q] > 0.f ? acc[r + q] : 0.f);
-    *reinterpret_cast<half8*>(d + r) = hv;
+    for (int q = 0; q < V; ++q) hv[q] = (T)(acc[r + q] > 0.f ? acc[r + q] : 0.f);
+    *reinterpret_cast<vec_t*>(d + r) = hv;
   }
 }
 
@@ -66,8 +68,10 @@ hipError_t stem_launch(const StemParams& p, hipStream_t stream, dim3* grid_out, 
   dim3 grid((p.Ho * p.Wo + 255) / 256), block(256);
   if (grid_out) *grid_out = grid;
   if (block_out) *block_out = block;
-  if (p.Co == 32) stem_conv_kernel<32><<<grid, block, 0, stream>>>(p);
-  else if (p.Co == 64) stem_conv_kernel<64><<<grid, block, 0, stream>>>(p);
+  if (p.Co == 32 && p.dtype == kF16) stem_conv_kernel<half_t, 32><<<grid, block, 0, stream>>>(p);
+  else if (p.Co == 64 && p.dtype == kF16) stem_conv_kernel<half_t, 64><<<grid, block, 0, stream>>>(p);
+  else if (p.Co == 32 && p.dtype == kF32) stem_conv_kernel<float, 32><<<grid, block, 0, stream>>>(p);
+  else if (p.Co == 64 && p.dtype == kF32) stem_conv_kernel<float, 64><<<grid, block, 0, stream>>>(p);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -83,37 +87,52 @@ hipError_t stem_launch(const StemParams& p, hipStream_t stream, dim3* grid_out, 
 //            (each thread owns (x, 8 channels): 13 coalesced 16-byte loads), written to LDS;
 //   phase 2: horizontal maxima over v5/v9/v13 within +-2/4/6 columns read from LDS -> y1,y2,y3.
 // fp16 max is exact, so this is bit-identical to chaining the pools in any precision.
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ h8 hmax8(h8 a, h8 b) {
-  h8 r;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) r[i] = a[i] > b[i] ? a[i] : b[i];
-  return r;
-}
+template <typename T> struct PoolVec;
+template <> struct PoolVec<half_t> {
+  static constexpr int V = 8;
+  typedef _Float16 vec __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ half_t lowest() { return (half_t)(-65504.0f); }
+};
+template <> struct PoolVec<float> {
+  static constexpr int V = 4;
+  typedef float vec __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ float lowest() { return -3.402823466e38f; }
+};
 
-template <int CH>  // channels per block (multiple of 8)
+template <typename T, int CH>  // CH channels per block (multiple of the 16-byte vector width)
 __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolParams p) {
+  typedef PoolVec<T> PV;
+  typedef typename PV::vec vec_t;
+  constexpr int V = PV::V, NV = CH / V;
   extern __shared__ __align__(16) unsigned char smem[];
-  h8* v5 = reinterpret_cast<h8*>(smem);                 // [W][CH/8]
-  h8* v9 = v5 + p.W * (CH / 8);
-  h8* v13 = v9 + p.W * (CH / 8);
+  vec_t* v5 = reinterpret_cast<vec_t*>(smem);  // [W][NV]
+  vec_t* v9 = v5 + p.W * NV;
+  vec_t* v13 = v9 + p.W * NV;
   const int y = blockIdx.x;
   const int c0 = blockIdx.y * CH;
-  const int nvec = p.W * (CH / 8);
-  const half_t* x = p.buf + p.coff + c0;
-  const half_t ninf = (half_t)(-65504.0f);              // below every finite fp16 (post-ReLU inputs are >= 0)
-  const h8 lo = {ninf, ninf, ninf, ninf, ninf, ninf, ninf, ninf};
+  const int nvec = p.W * NV;
+  T* base = static_cast<T*>(p.buf);
+  const T* x = base + p.coff + c0;
+  vec_t lo;
+#pragma unroll
+  for (int i = 0; i < V; ++i) lo[i] = PV::lowest();  // below every finite value (post-ReLU inputs are >= 0)
+  auto vmax = [](vec_t a, vec_t b) {
+    vec_t r;
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = a[i] > b[i] ? a[i] : b[i];
+    return r;
+  };
   for (int t = threadIdx.x; t < nvec; t += blockDim.x) {
-    const int xx = t / (CH / 8), cv = t % (CH / 8);
-    h8 m5 = lo, m9 = lo, m13 = lo;
+    const int xx = t / NV, cv = t % NV;
+    vec_t m5 = lo, m9 = lo, m13 = lo;
 #pragma unroll
     for (int dy = -6; dy <= 6; ++dy) {
       const int yy = y + dy;
       if (yy < 0 || yy >= p.H) continue;
-      const h8 v = *reinterpret_cast<const h8*>(x + ((size_t)yy * p.W + xx) * p.ld + cv * 8);
-      m13 = hmax8(m13, v);
-      if (dy >= -4 && dy <= 4) m9 = hmax8(m9, v);
-      if (dy >= -2 && dy <= 2) m5 = hmax8(m5, v);
+      const vec_t v = *reinterpret_cast<const vec_t*>(x + ((size_t)yy * p.W + xx) * p.ld + cv * V);
+      m13 = vmax(m13, v);
+      if (dy >= -4 && dy <= 4) m9 = vmax(m9, v);
+      if (dy >= -2 && dy <= 2) m5 = vmax(m5, v);
     }
     v5[t] = m5;
     v9[t] = m9;
@@ -121,21 +140,21 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolParams p) {
   }
   __syncthreads();
   for (int t = threadIdx.x; t < nvec; t += blockDim.x) {
-    const int xx = t / (CH / 8), cv = t % (CH / 8);
-    h8 o5 = lo, o9 = lo, o13 = lo;
+    const int xx = t / NV, cv = t % NV;
+    vec_t o5 = lo, o9 = lo, o13 = lo;
 #pragma unroll
     for (int dx = -6; dx <= 6; ++dx) {
       const int x2 = xx + dx;
       if (x2 < 0 || x2 >= p.W) continue;
-      const int idx = x2 * (CH / 8) + cv;
-      o13 = hmax8(o13, v13[idx]);
-      if (dx >= -4 && dx <= 4) o9 = hmax8(o9, v9[idx]);
-      if (dx >= -2 && dx <= 2) o5 = hmax8(o5, v5[idx]);
+      const int idx = x2 * NV + cv;
+      o13 = vmax(o13, v13[idx]);
+      if (dx >= -4 && dx <= 4) o9 = vmax(o9, v9[idx]);
+      if (dx >= -2 && dx <= 2) o5 = vmax(o5, v5[idx]);
     }
-    half_t* o = p.buf + ((size_t)y * p.W + xx) * p.ld + p.coff + c0 + cv * 8;
-    *reinterpret_cast<h8*>(o + p.C) = o5;
-    *reinterpret_cast<h8*>(o + 2 * p.C) = o9;
-    *reinterpret_cast<h8*>(o + 3 * p.C) = o13;
+    T* o = base + ((size_t)y * p.W + xx) * p.ld + p.coff + c0 + cv * V;
+    *reinterpret_cast<vec_t*>(o + p.C) = o5;
+    *reinterpret_cast<vec_t*>(o + 2 * p.C) = o9;
+    *reinterpret_cast<vec_t*>(o + 3 * p.C) = o13;
   }
 }
 
@@ -143,11 +162,13 @@ hipError_t sppf_pool_launch(const PoolParams& p, hipStream_t stream, dim3* grid_
   constexpr int CH = 32;
   if (p.C % CH) return hipErrorInvalidValue;
   dim3 grid(p.H, p.C / CH), block(256);
-  const size_t smem = (size_t)3 * p.W * CH * sizeof(half_t);
-  if (smem > 160 * 1024) return hipErrorInvalidValue;
+  const size_t esz = p.dtype == kF32 ? 4 : 2;
+  const size_t smem = (size_t)3 * p.W * CH * esz;
+  if (smem > 64 * 1024) return hipErrorInvalidValue;
   if (grid_out) *grid_out = grid;
   if (block_out) *block_out = block;
-  sppf_pool_kernel<CH><<<grid, block, smem, stream>>>(p);
+  if (p.dtype == kF32) sppf_pool_kernel<float, CH><<<grid, block, smem, stream>>>(p);
+  else sppf_pool_kernel<half_t, CH><<<grid, block, smem, stream>>>(p);
   return hipGetLastError();
 }
 

@@ -134,17 +134,17 @@ class Engine:
     # -- construction helpers -------------------------------------------------------------------------
     @classmethod
     def from_state_dict(cls, sd: Dict[str, np.ndarray], graph: Optional[Graph] = None, device: int = 0,
-                        path: Optional[str] = None) -> "Engine":
+                        path: Optional[str] = None, precision: int = _export.FP16) -> "Engine":
         """export_trt.py's role + load: folds/fuses `sd` into an engine file (temporary unless `path`) and loads it."""
         if path is None:
             fd, tmp = tempfile.mkstemp(suffix=".une")
             os.close(fd)
             try:
-                _export.export_engine(sd, tmp, graph)
+                _export.export_engine(sd, tmp, graph, precision)
                 return cls(tmp, device)
             finally:
                 os.unlink(tmp)
-        _export.export_engine(sd, path, graph)
+        _export.export_engine(sd, path, graph, precision)
         return cls(path, device)
 
     def _check(self, rc: int):
@@ -243,7 +243,7 @@ class Engine:
         `cache`: JSON tactic cache (the role of TensorRT's timing cache): reused when it matches this engine."""
         import json
         names = self.conv_configs()
-        key = f"{self.width}x{self.height}:" + "|".join(f"{o['m']},{o['n']},{o['k']}" for o in self.op_infos())
+        key = f"{self.width}x{self.height}:{self.op_infos()[1]['kernel'][:13]}:" + "|".join(f"{o['m']},{o['n']},{o['k']}" for o in self.op_infos())
         if cache and os.path.exists(cache):
             try:
                 with open(cache) as f:
@@ -263,7 +263,8 @@ class Engine:
         self._check(self.L.unina_autotune(self.h, iters, _stream_ptr(stream)))
         _torch().cuda.synchronize(self.device)
         if cache:
-            choice = [names.index(o["kernel"]) if o["kernel"] in names else -1 for o in self.op_infos()]
+            norm = [o["kernel"].replace("<f32,", "<f16,") for o in self.op_infos()]
+            choice = [names.index(k) if k in names else -1 for k in norm]
             with open(cache, "w") as f:
                 json.dump({"key": key, "configs": names, "choice": choice}, f)
 

@@ -30,8 +30,8 @@ from .graph import Graph, OUTPUT_NAMES, STRIDES
 
 MAGIC = b"UNINAENG"
 VERSION = 2
-FP16, INT8 = 0, 1
-BUF_F16, BUF_F32_PLANAR, BUF_F32_NCHW_IN = 0, 1, 2
+FP16, INT8, FP32 = 0, 1, 2
+BUF_F16, BUF_F32_PLANAR, BUF_F32_NCHW_IN, BUF_I8, BUF_F32_NHWC = 0, 1, 2, 3, 4
 BUF_INPUT, BUF_OUTPUT = 1, 2
 OP_CONV, OP_STEM, OP_SPPF_POOL, OP_UPSAMPLE = 1, 2, 3, 4
 SEG_UP2, SEG_PLANAR_F32 = 1, 2
@@ -82,12 +82,15 @@ _SWZ_G = (0, 2, 3, 1)
 
 
 def pack_weights(wk: np.ndarray) -> np.ndarray:
-    """[n_pad][K] fp16 (K = (kh,kw,cin), n_pad % 16 == 0, K % 32 == 0) -> the LDS image the conv kernel DMA-loads:
-    1-KiB blocks [n_pad/16][K/32], each 64 slots x 8 halfs with slot(r, c) = 4*r + (c ^ G[r>>2]), G = (0,2,3,1)
-    (conv_igemm.hip: conflict-free ds_read_b128 fragment reads)."""
+    """[n_pad][K] fp16 or fp32 (K = (kh,kw,cin), n_pad % 16 == 0) -> the LDS image the conv kernel DMA-loads:
+    1-KiB blocks [n_pad/16][K/kb], each 64 slots x 16 bytes with slot(r, c) = 4*r + (c ^ G[r>>2]), G = (0,2,3,1)
+    (conv_igemm.hip: conflict-free ds_read_b128 fragment reads). A 16-byte chunk is 8 halfs / 4 floats, so a block
+    spans kb = 32 (fp16) or 16 (fp32) values of k."""
     n_pad, K = wk.shape
-    assert n_pad % 16 == 0 and K % 32 == 0, (n_pad, K)
-    blk = wk.reshape(n_pad // 16, 16, K // 32, 4, 8).transpose(0, 2, 1, 3, 4)       # [nsub][k32][r][c][8]
+    ce = 16 // wk.dtype.itemsize
+    kb = 4 * ce
+    assert n_pad % 16 == 0 and K % kb == 0, (n_pad, K)
+    blk = wk.reshape(n_pad // 16, 16, K // kb, 4, ce).transpose(0, 2, 1, 3, 4)       # [nsub][kblk][r][c][ce]
     out = np.empty_like(blk)
     for r in range(16):
         for c in range(4):
@@ -97,7 +100,8 @@ def pack_weights(wk: np.ndarray) -> np.ndarray:
 
 def unpack_weights(packed: np.ndarray, n_pad: int, K: int) -> np.ndarray:
     """Inverse of pack_weights (tests / emulator)."""
-    blk = packed.reshape(n_pad // 16, K // 32, 16, 4, 8)
+    ce = 16 // packed.dtype.itemsize
+    blk = packed.reshape(n_pad // 16, K // (4 * ce), 16, 4, ce)
     out = np.empty_like(blk)
     for r in range(16):
         for c in range(4):
@@ -117,8 +121,15 @@ def fold_bn(sd: Dict[str, np.ndarray], module: str):
 
 
 class EngineBuilder:
-    def __init__(self, sd: Dict[str, np.ndarray], graph: Optional[Graph] = None):
+    def __init__(self, sd: Dict[str, np.ndarray], graph: Optional[Graph] = None, precision: int = FP16):
+        """precision: FP16 (fp16 weights + activations, v_mfma_f32_16x16x32_f16) or FP32 (fp32 everywhere,
+        v_mfma_f32_16x16x4_f32: meets the north-star tolerance outright at 1/16 of the fp16 matrix rate)."""
+        if precision not in (FP16, FP32):
+            raise NotImplementedError("precision must be FP16 or FP32 (INT8: not built yet)")
         self.sd = sd
+        self.precision = precision
+        self.wdtype = np.float32 if precision == FP32 else np.float16
+        self.act_dtype = BUF_F32_NHWC if precision == FP32 else BUF_F16
         self.g = graph or Graph()
         if self.g.base_channels % 32:
             raise NotImplementedError("engine kernels need Cin % 32 == 0 beyond the stem (base_channels multiple of 32)")
@@ -128,8 +139,8 @@ class EngineBuilder:
         self._lower()
 
     # ---- tables -------------------------------------------------------------------------------
-    def buf(self, name: str, h: int, w: int, c: int, dtype: int = BUF_F16, flags: int = 0) -> int:
-        self.buffers.append((name, h, w, c, dtype, flags))
+    def buf(self, name: str, h: int, w: int, c: int, dtype: Optional[int] = None, flags: int = 0) -> int:
+        self.buffers.append((name, h, w, c, self.act_dtype if dtype is None else dtype, flags))
         return len(self.buffers) - 1
 
     def view(self, name: str, h: int, w: int, c: int) -> View:
@@ -162,8 +173,8 @@ class EngineBuilder:
             n = w.shape[0]
             assert w.shape[1] == cin and w.shape[2] == k, (module, w.shape, cin, k)
             n_pad = -(-n // 16) * 16
-            wk = np.zeros((n_pad, k, k, cin), dtype=np.float16)
-            wk[:n] = np.transpose(w, (0, 2, 3, 1)).astype(np.float16)       # [O][kh][kw][C]: K = (kh,kw,cin)
+            wk = np.zeros((n_pad, k, k, cin), dtype=self.wdtype)
+            wk[:n] = np.transpose(w, (0, 2, 3, 1)).astype(self.wdtype)      # [O][kh][kw][C]: K = (kh,kw,cin)
             bk = np.zeros((n_pad,), dtype=np.float32)
             bk[:n] = b.astype(np.float32)
             dh, dw = self._hw(dst.buf)
@@ -278,7 +289,7 @@ class EngineBuilder:
     def tobytes(self) -> bytes:
         g = self.g
         out = bytearray()
-        out += _HDR.pack(MAGIC, VERSION, FP16, 3, g.in_h, g.in_w, g.num_classes, len(self.buffers), len(self.ops),
+        out += _HDR.pack(MAGIC, VERSION, self.precision, 3, g.in_h, g.in_w, g.num_classes, len(self.buffers), len(self.ops),
                          3, *STRIDES, len(self.blob), g.macs())
         for name, h, w, c, dtype, flags in self.buffers:
             out += _BUF.pack(h, w, c, dtype, flags, name.encode()[:43])
@@ -304,9 +315,10 @@ class EngineBuilder:
             f.write(self.tobytes())
 
 
-def export_engine(sd: Dict[str, np.ndarray], path: str, graph: Optional[Graph] = None) -> EngineBuilder:
+def export_engine(sd: Dict[str, np.ndarray], path: str, graph: Optional[Graph] = None,
+                  precision: int = FP16) -> EngineBuilder:
     """state_dict (reference key names) -> engine file. Returns the builder (op table for inspection)."""
-    b = EngineBuilder(sd, graph)
+    b = EngineBuilder(sd, graph, precision)
     b.save(path)
     return b
 
