@@ -140,7 +140,7 @@ def main():
 
         # ---- roofline of the dominant kernel: live HIP-event timing of every op on the launch stream ----
         ops = e0.profile_ops(iters=20)
-        dt = "f32" if args.precision == "fp32" else "f16"
+        dname = "f32" if args.precision == "fp32" else "f16"
         by_kernel = {}
         for o in ops:
             k = by_kernel.setdefault(o["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
@@ -152,8 +152,8 @@ def main():
             "bound": "mfma", "kernel": dom_name, "launches_per_frame": dom["launches"],
             "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 3),
             "flops_per_launch": dom["flops"] / dom["launches"],
-            "achieved": round(achieved_tf, 2), "peak": PEAK_TFLOPS[dt], "unit": "TFLOP/s",
-            "frac": round(achieved_tf / PEAK_TFLOPS[dt], 4), "traffic": None,
+            "achieved": round(achieved_tf, 2), "peak": PEAK_TFLOPS[dname], "unit": "TFLOP/s",
+            "frac": round(achieved_tf / PEAK_TFLOPS[dname], 4), "traffic": None,
             "algorithmic_gbs": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
             "sum_of_ops_ms": round(total_ms, 4),
             "whole_frame_tflops": round(fps / world * FLOPS_PER_FRAME.get(S, 0) / 1e12, 2),
@@ -167,7 +167,7 @@ def main():
             "metric": "frames/sec, 640x640 batch-1 (p99 latency alongside)" if S == 640 else f"frames/sec, {S}x{S} batch-1",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 5), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dt, "data": "synthetic",
+            "vs_baseline": None, "dtype": dname, "data": "synthetic",
             "config": {"workload": f"unina-yolo-dla-m graph A {args.precision}, batch=1, {S}x{S}, NMS on-GPU (BASELINE configs[1])",
                        "frames_in_flight_per_gpu": IN_FLIGHT, "parallelism": f"replica x{world}, RCCL all-gather of detection slots every {GATHER_EVERY} frames" if world > 1 else "1 GPU",
                        "thresholds": {"conf": conf, "iou": 0.45, "conformal_q": 0.1}, "detections_last_frame": n_det},
