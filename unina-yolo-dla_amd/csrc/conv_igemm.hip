@@ -70,6 +70,59 @@ template <> struct Elem<float> {
   }
 };
 
+
+// Shared epilogue: bias, ReLU, residual (after the ReLU: model.py:72-73), then one of: NHWC store, NHWC store of the
+// 2x2 nearest-upsampled block (model.py:145-147), planar fp32 store (head outputs). m_of[i] is the output pixel
+// (row-major index into Ho x Wo) of this lane's column of pixel-subtile i, or -1 if it lies outside the image.
+template <typename T, int WM_T, int WN_T>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg& sg, floatx4 (&acc)[WN_T][WM_T],
+                                              const int (&m_of)[WM_T], int n_w0, int lq) {
+  typedef Elem<T> E;
+#pragma unroll
+  for (int j = 0; j < WN_T; ++j) {
+    const int n = n_w0 + j * 16 + lq * 4;  // first of this lane's 4 consecutive channels (slice-relative)
+    if (n >= sg.n_count) continue;
+    const floatx4 bias = *reinterpret_cast<const floatx4*>(sg.bias + n);
+#pragma unroll
+    for (int i = 0; i < WM_T; ++i) {
+      const int m = m_of[i];
+      if (m < 0) continue;
+      floatx4 v = acc[j][i] + bias;
+      if (p.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      }
+      if (p.res) {
+        const typename E::out4 rv = *reinterpret_cast<const typename E::out4*>(static_cast<const T*>(p.res) + (size_t)m * p.res_ld + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+      }
+      if (sg.dst_planar) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < sg.n_count) sg.dst_planar[(size_t)(n + r) * p.M + m] = v[r];
+      } else {
+        typedef typename E::out4 out4;
+        out4 hv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[r] = (T)v[r];
+        T* dst = static_cast<T*>(sg.dst);
+        if (sg.up2) {
+          const int oy = m / p.Wo, ox = m - oy * p.Wo;
+          const size_t row = (size_t)(2 * oy) * (2 * p.Wo) + 2 * ox;
+          T* d = dst + row * sg.dst_ld + n;
+          *reinterpret_cast<out4*>(d) = hv;
+          *reinterpret_cast<out4*>(d + sg.dst_ld) = hv;
+          *reinterpret_cast<out4*>(d + (size_t)(2 * p.Wo) * sg.dst_ld) = hv;
+          *reinterpret_cast<out4*>(d + (size_t)(2 * p.Wo + 1) * sg.dst_ld) = hv;
+        } else {
+          *reinterpret_cast<out4*>(dst + (size_t)m * sg.dst_ld + n) = hv;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern __shared__ __align__(16) unsigned char conv_smem[];
@@ -200,52 +253,160 @@ __global__ __launch_bounds__(256) void conv_glds(const ConvParams p) {
   }
   wait_vmcnt<0>();  // drain the dummy tail before the wave retires
 
-  // ---- epilogue: bias, ReLU, residual (after the ReLU: model.py:72-73), store ----
-  const int n_w0 = nb0 + wn * (WN_T * 16);
-  const int m_w0 = m_blk + wm * (WM_T * 16);
+  // ---- epilogue ----
+  int m_of[WM_T];
 #pragma unroll
-  for (int j = 0; j < WN_T; ++j) {
-    const int n = n_w0 + j * 16 + lq * 4;  // first of this lane's 4 consecutive channels (slice-relative)
-    if (n >= sg.n_count) continue;
-    const floatx4 bias = *reinterpret_cast<const floatx4*>(sg.bias + n);
+  for (int i = 0; i < WM_T; ++i) {
+    const int m = m_blk + (wm * WM_T + i) * 16 + l15;
+    m_of[i] = m < p.M ? m : -1;
+  }
+  conv_epilogue<T, WM_T, WN_T>(p, sg, acc, m_of, nb0 + wn * (WN_T * 16), lq);
+}
+
+
+// ================================================================================================ 3x3 halo kernel
+// 3x3 / stride 1 / pad 1 convolution with the INPUT PATCH RESIDENT IN LDS. A workgroup owns a TH x TW tile of output
+// pixels and BN output channels. Its (TH+2) x (TW+2) x Cin input patch is DMA'd into LDS once; all nine taps then read
+// their B fragments from that patch at shifted pixel addresses, and only the WEIGHTS stream through the STAGES-deep
+// LDS-DMA ring (same 1-KiB packed fragment blocks, same counted-vmcnt pipeline as conv_glds). Compared with the
+// im2col K-steps of conv_glds this removes the nine-fold re-fetch of every input pixel: L2->LDS traffic per
+// workgroup drops from (BM + BN)*K to (1.27..1.56)*BM*Cin + BN*K elements.
+// Patch image: pixel h = hy*(TW+2) + hx owns Cin elements = NCH 16-byte chunks; chunk c sits at slot c ^ (h & SWZ)
+// (SWZ = min(NCH,16)-1): a fragment read touches 16 different pixels at a (nearly) common chunk index, and the XOR
+// spreads them over the 16 bank slots; the loading lane fetches the matching source chunk, so every pixel's row is
+// still one contiguous global segment.
+template <typename T, int TH, int TW, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
+  static_assert(WAVES_M * WAVES_N == 4, "256-thread blocks");
+  typedef Elem<T> E;
+  typedef typename E::frag frag_t;
+  constexpr int BM = TH * TW, HW_ = TW + 2, NPIX = (TH + 2) * (TW + 2);
+  constexpr int WM_T = BM / (WAVES_M * 16), WN_T = BN / (WAVES_N * 16), KSUB = BK / 32;
+  constexpr int KSTEP = KSUB * E::kBlockK;
+  constexpr int WBLK = (BN / 16) * KSUB;
+  constexpr int LPT = (WBLK + 3) / 4;
+  constexpr int STAGE_BYTES = LPT * 4 * 1024;
+  constexpr int RING_BYTES = STAGES * STAGE_BYTES;
+  static_assert(WM_T >= 1 && WN_T >= 1 && (TW == 8 || TW == 16), "tile");
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wid % WAVES_M, wn = wid / WAVES_M;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  const int sidx = (p.nseg > 1 && (int)blockIdx.y >= p.seg[1].tile0) ? 1 : 0;
+  const ConvSeg& sg = p.seg[sidx];
+  const int n_pad = (sg.n_count + 15) & ~15;
+  const int nb0 = ((int)blockIdx.y - sg.tile0) * BN;
+  const int tiles_x = (p.Wo + TW - 1) / TW;
+  const int ty0 = ((int)blockIdx.x / tiles_x) * TH, tx0 = ((int)blockIdx.x % tiles_x) * TW;
+  const int nch = p.Cin / E::kChunk;              // 16-byte chunks per pixel (power of two)
+  const int nch_log = 31 - __builtin_clz(nch);
+  const int swz = (nch < 16 ? nch : 16) - 1;
+  const int kblocks = 9 * (p.Cin / E::kBlockK);
+  unsigned char* patch = conv_smem + RING_BYTES;
+  const T* zeros = reinterpret_cast<const T*>(p.zeros);
+
+  // ---- 1. patch DMA: slot s (16 B) of the image = pixel s / nch, slot-in-pixel s % nch ----
+  {
+    const int nslots = NPIX * nch;
+    const T* src = static_cast<const T*>(p.src) + sg.src_coff;
+    for (int s0 = wid * 64; s0 < nslots; s0 += 256) {
+      const int s = s0 + lane;
+      const T* g = zeros;
+      if (s < nslots) {
+        const int h = s >> nch_log, cs = s & (nch - 1);
+        const int hy = h / HW_, hx = h - hy * HW_;
+        const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+          g = src + (size_t)(iy * p.W + ix) * p.src_ld + ((cs ^ (h & swz)) * E::kChunk);
+      }
+      glds16(g, patch + (size_t)s0 * 16);
+    }
+  }
+
+  // ---- 2. weight ring (identical to conv_glds, activations removed) ----
+  const T* w_base[LPT];
+#pragma unroll
+  for (int q = 0; q < LPT; ++q) {
+    const int b = q * 4 + wid;
+    w_base[q] = nullptr;
+    if (b < WBLK) {
+      const int n = b / KSUB, j = b - n * KSUB;
+      const int nsub = (nb0 >> 4) + n;
+      if (nsub * 16 < n_pad) w_base[q] = static_cast<const T*>(sg.w) + ((size_t)nsub * kblocks + j) * (1024 / sizeof(T)) + lane * E::kChunk;
+    }
+  }
+  const int steps_per_tap = p.Cin / KSTEP;
+  const int nk = 9 * steps_per_tap;
+  int i_kt = 0;
+  auto issue = [&](int buf) {
+    unsigned char* sb = conv_smem + buf * STAGE_BYTES;
+    const bool live = i_kt < nk;
+#pragma unroll
+    for (int q = 0; q < LPT; ++q) {
+      const T* g = (live && w_base[q]) ? w_base[q] + (size_t)i_kt * KSUB * (1024 / sizeof(T)) : zeros;
+      glds16(g, sb + (q * 4 + wid) * 1024);
+    }
+    ++i_kt;
+  };
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) issue(s);
+
+  // ---- 3. per-lane patch addressing: pixel of every subtile, tap (0,0) ----
+  int h00[WM_T];
+#pragma unroll
+  for (int i = 0; i < WM_T; ++i) {
+    const int pix = (wm * WM_T + i) * 16 + l15;
+    h00[i] = (pix / TW) * HW_ + (pix % TW);
+  }
+  floatx4 acc[WN_T][WM_T];
+#pragma unroll
+  for (int j = 0; j < WN_T; ++j)
+#pragma unroll
+    for (int i = 0; i < WM_T; ++i) acc[j][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int rd_off = (4 * l15 + (lq ^ swz_g(l15))) * 16;
+  int kt = 0;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int tap_off = (tap / 3) * HW_ + (tap % 3);
+    int hrow[WM_T], hsw[WM_T];  // byte offset of the pixel row, swizzle term
 #pragma unroll
     for (int i = 0; i < WM_T; ++i) {
-      const int m = m_w0 + i * 16 + l15;
-      if (m >= p.M) continue;
-      floatx4 v = acc[j][i] + bias;
-      if (p.relu) {
+      const int h = h00[i] + tap_off;
+      hrow[i] = h << (nch_log + 4);
+      hsw[i] = h & swz;
+    }
+    for (int cs = 0; cs < steps_per_tap; ++cs, ++kt) {
+      wait_vmcnt<(STAGES - 2) * LPT>();
+      __builtin_amdgcn_s_barrier();
+      issue((kt + STAGES - 1) % STAGES);
+      const unsigned char* sb = conv_smem + (kt % STAGES) * STAGE_BYTES + rd_off;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-      }
-      if (p.res) {
-        const typename E::out4 rv = *reinterpret_cast<const typename E::out4*>(static_cast<const T*>(p.res) + (size_t)m * p.res_ld + n);
+      for (int j = 0; j < KSUB; ++j) {
+        const int ch = (cs * KSUB + j) * 4 + lq;  // this lane's 16-byte chunk index inside the pixel
+        frag_t a[WN_T], b[WM_T];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-      }
-      if (sg.dst_planar) {
+        for (int i = 0; i < WM_T; ++i) b[i] = *reinterpret_cast<const frag_t*>(patch + hrow[i] + ((ch ^ hsw[i]) << 4));
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < sg.n_count) sg.dst_planar[(size_t)(n + r) * p.M + m] = v[r];
-      } else {
-        typedef typename E::out4 out4;
-        out4 hv;
+        for (int n = 0; n < WN_T; ++n) a[n] = *reinterpret_cast<const frag_t*>(sb + (((wn * WN_T + n) * KSUB + j) << 10));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hv[r] = (T)v[r];
-        T* dst = static_cast<T*>(sg.dst);
-        if (sg.up2) {
-          const int oy = m / p.Wo, ox = m - oy * p.Wo;
-          const size_t row = (size_t)(2 * oy) * (2 * p.Wo) + 2 * ox;
-          T* d = dst + row * sg.dst_ld + n;
-          *reinterpret_cast<out4*>(d) = hv;
-          *reinterpret_cast<out4*>(d + sg.dst_ld) = hv;
-          *reinterpret_cast<out4*>(d + (size_t)(2 * p.Wo) * sg.dst_ld) = hv;
-          *reinterpret_cast<out4*>(d + (size_t)(2 * p.Wo + 1) * sg.dst_ld) = hv;
-        } else {
-          *reinterpret_cast<out4*>(dst + (size_t)m * sg.dst_ld + n) = hv;
-        }
+        for (int n = 0; n < WN_T; ++n)
+#pragma unroll
+          for (int i = 0; i < WM_T; ++i) acc[n][i] = E::mma(a[n], b[i], acc[n][i]);
       }
     }
   }
+  wait_vmcnt<0>();
+
+  int m_of[WM_T];
+#pragma unroll
+  for (int i = 0; i < WM_T; ++i) {
+    const int pix = (wm * WM_T + i) * 16 + l15;
+    const int oy = ty0 + pix / TW, ox = tx0 + pix % TW;
+    m_of[i] = (oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
+  }
+  conv_epilogue<T, WM_T, WN_T>(p, sg, acc, m_of, nb0 + wn * (WN_T * 16), lq);
 }
 
 // ---------------------------------------------------------------------------------------------- launch side
@@ -255,7 +416,8 @@ struct CfgInfo {
   int bm, bn, bk, stages;
   const char* name;
   void (*fn)(const ConvParams);
-  size_t smem;
+  size_t smem;         // im2col kernel: total dynamic LDS; halo kernel: weight ring only (the patch is added per op)
+  int th, tw;          // halo kernel: spatial tile (0 = im2col kernel)
 };
 
 template <int BM, int BN, int BK, int WM, int WN, int ST>
@@ -265,7 +427,10 @@ constexpr size_t smem_of() {
 
 #define CFG(T, TN, BM, BN, BK, WM, WN, ST)                                                         \
   {BM, BN, BK, ST, "conv_glds<" TN "," #BM "," #BN "," #BK "," #WM "," #WN "," #ST ">",            \
-   conv_glds<T, BM, BN, BK, WM, WN, ST>, smem_of<BM, BN, BK, WM, WN, ST>()}
+   conv_glds<T, BM, BN, BK, WM, WN, ST>, smem_of<BM, BN, BK, WM, WN, ST>(), 0, 0}
+#define HALO(T, TN, TH, TW, BN, BK, WM, WN, ST)                                                     \
+  {(TH) * (TW), BN, BK, ST, "conv3x3_halo<" TN "," #TH "x" #TW "," #BN "," #BK "," #WM "," #WN "," #ST ">", \
+   conv3x3_halo<T, TH, TW, BN, BK, WM, WN, ST>, (size_t)ST * ((((BN) / 16) * ((BK) / 32) + 3) / 4) * 4 * 1024, TH, TW}
 
 // [dtype][config]; BK is in fp16-equivalent k (KSUB = BK/32 fragment blocks): a K-step covers BK channels in fp16
 // and BK/2 channels in fp32.
@@ -280,6 +445,14 @@ const CfgInfo kCfg[2][kCfgCount] = {
         CFG(half_t, "f16", 128, 32, 32, 4, 1, 4),   // kCfg128x32k32
         CFG(half_t, "f16", 128, 16, 64, 4, 1, 3),   // kCfg128x16k64
         CFG(half_t, "f16", 32, 64, 64, 1, 4, 4),    // kCfg32x64k64
+        CFG(half_t, "f16", 32, 64, 64, 1, 4, 8),    // kCfg32x64k64s8  (deep pipeline for latency-bound small grids)
+        CFG(half_t, "f16", 64, 64, 64, 2, 2, 6),    // kCfg64x64k64s6
+        HALO(half_t, "f16", 8, 8, 64, 64, 2, 2, 4),   // kCfgHalo8x8n64
+        HALO(half_t, "f16", 8, 8, 32, 64, 4, 1, 4),   // kCfgHalo8x8n32
+        HALO(half_t, "f16", 8, 16, 64, 64, 2, 2, 4),  // kCfgHalo8x16n64
+        HALO(half_t, "f16", 8, 16, 32, 64, 4, 1, 4),  // kCfgHalo8x16n32
+        HALO(half_t, "f16", 8, 8, 64, 32, 2, 2, 4),   // kCfgHalo8x8n64k32
+        HALO(half_t, "f16", 8, 16, 32, 32, 4, 1, 4),  // kCfgHalo8x16n32k32
     },
     {
         CFG(float, "f32", 64, 64, 64, 2, 2, 4),
@@ -291,11 +464,27 @@ const CfgInfo kCfg[2][kCfgCount] = {
         CFG(float, "f32", 128, 32, 32, 4, 1, 4),
         CFG(float, "f32", 128, 16, 64, 4, 1, 3),
         CFG(float, "f32", 32, 64, 64, 1, 4, 4),
+        CFG(float, "f32", 32, 64, 64, 1, 4, 8),
+        CFG(float, "f32", 64, 64, 64, 2, 2, 6),
+        HALO(float, "f32", 8, 8, 64, 64, 2, 2, 4),
+        HALO(float, "f32", 8, 8, 32, 64, 4, 1, 4),
+        HALO(float, "f32", 8, 16, 64, 64, 2, 2, 4),
+        HALO(float, "f32", 8, 16, 32, 64, 4, 1, 4),
+        HALO(float, "f32", 8, 8, 64, 32, 2, 2, 4),
+        HALO(float, "f32", 8, 16, 32, 32, 4, 1, 4),
     },
 };
 #undef CFG
+#undef HALO
 
 inline int kstep_of(const ConvParams& p, const CfgInfo& c) { return (c.bk / 32) * (p.dtype == kF32 ? 16 : 32); }
+inline size_t esize(const ConvParams& p) { return p.dtype == kF32 ? 4 : 2; }
+inline size_t smem_for(const ConvParams& p, const CfgInfo& c) {
+  if (!c.th) return c.smem;
+  const size_t patch = (size_t)(c.th + 2) * (c.tw + 2) * p.Cin * esize(p);
+  return c.smem + ((patch + 1023) & ~(size_t)1023);
+}
+constexpr size_t kMaxLds = 160 * 1024;
 
 int n_tiles(const ConvParams& p, int bn) {
   int t = 0;
@@ -308,8 +497,8 @@ int n_tiles(const ConvParams& p, int bn) {
 hipError_t conv_init() {
   for (int d = 0; d < 2; ++d)
     for (int c = 0; c < kCfgCount; ++c) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kCfg[d][c].fn),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCfg[d][c].smem);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kCfg[d][c].fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(kCfg[d][c].th ? kMaxLds : kCfg[d][c].smem));
       if (e != hipSuccess) return e;
     }
   return hipSuccess;
@@ -319,6 +508,10 @@ bool conv_config_valid(const ConvParams& p, int cfg) {
   if (cfg < 0 || cfg >= kCfgCount) return false;
   const CfgInfo& c = kCfg[p.dtype][cfg];
   if (p.Cin % kstep_of(p, c)) return false;
+  if (c.th) {  // halo kernel: 3x3, stride 1, pad 1, power-of-two chunk count, patch + ring must fit the CU's LDS
+    const int nch = p.Cin / (p.dtype == kF32 ? 4 : 8);
+    if (p.ksize != 3 || p.stride != 1 || p.pad != 1 || (nch & (nch - 1)) || smem_for(p, c) > kMaxLds) return false;
+  }
   int min_npad = 1 << 30;
   for (int s = 0; s < p.nseg; ++s) {
     const int np = (p.seg[s].n_count + 15) & ~15;
@@ -331,7 +524,8 @@ ConvLaunch conv_plan_with(const ConvParams& p, int cfg) {
   const CfgInfo& c = kCfg[p.dtype][cfg];
   ConvLaunch l;
   l.cfg = (ConvConfig)cfg;
-  l.grid = dim3((p.M + c.bm - 1) / c.bm, n_tiles(p, c.bn), 1);
+  if (c.th) l.grid = dim3(((p.Ho + c.th - 1) / c.th) * ((p.Wo + c.tw - 1) / c.tw), n_tiles(p, c.bn), 1);
+  else l.grid = dim3((p.M + c.bm - 1) / c.bm, n_tiles(p, c.bn), 1);
   l.block = dim3(256, 1, 1);
   l.kernel_name = c.name;
   return l;
@@ -370,7 +564,7 @@ hipError_t conv_launch(const ConvParams& pin, const ConvLaunch& l, hipStream_t s
     p.seg[s].tile0 = t;
     t += (((p.seg[s].n_count + 15) & ~15) + c.bn - 1) / c.bn;
   }
-  hipLaunchKernelGGL(c.fn, l.grid, l.block, c.smem, stream, p);
+  hipLaunchKernelGGL(c.fn, l.grid, l.block, smem_for(p, c), stream, p);
   return hipGetLastError();
 }
 

@@ -47,7 +47,9 @@ struct ConvParams {
 // tile configurations of the conv kernel: block tile = BM pixels x BN output channels, K-step BK
 enum ConvConfig : int {
   kCfg64x64k64 = 0, kCfg64x64k32, kCfg128x64k64, kCfg128x64k32, kCfg128x128k64,
-  kCfg128x32k64, kCfg128x32k32, kCfg128x16k64, kCfg32x64k64, kCfgCount
+  kCfg128x32k64, kCfg128x32k32, kCfg128x16k64, kCfg32x64k64, kCfg32x64k64s8, kCfg64x64k64s6,
+  kCfgHalo8x8n64, kCfgHalo8x8n32, kCfgHalo8x16n64, kCfgHalo8x16n32, kCfgHalo8x8n64k32, kCfgHalo8x16n32k32,
+  kCfgCount
 };
 struct ConvLaunch {
   ConvConfig cfg;
