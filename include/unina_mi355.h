@@ -152,6 +152,10 @@ int unina_debug_read_buffer(unina_engine_t *e, const char *name, float *host_out
  * masks done, scan done, output done. */
 int unina_debug_post_stamps(unina_engine_t *e, long long *out8);
 
+/* Debug: one launch of conv op `op_index` with in-kernel s_memtime stamps of a mid-grid workgroup:
+ * out5 = start, prologue issued, first operands usable, K loop done, stores drained (shader-clock ticks). */
+int unina_debug_conv_stamps(unina_engine_t *e, int op_index, long long *out5, hipStream_t stream);
+
 /* Library/build identification: "unina_mi355 <version> gfx950". */
 const char *unina_version(void);
 

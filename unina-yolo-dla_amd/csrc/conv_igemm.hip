@@ -46,6 +46,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ void stamp(const ConvParams& p, int k) {
+  if (p.stamps && blockIdx.x == (gridDim.x >> 1) && blockIdx.y == 0 && threadIdx.x == 0) {
+    p.stamps[k] = __builtin_amdgcn_s_memtime();
+    if (k == 0 || k == 4) p.stamps[5 + (k >> 2)] = wall_clock64();  // 100 MHz reference: effective shader clock
+  }
+}
+
 // Element-type traits. A 1-KiB fragment block is always 16 rows x 4 chunks of 16 bytes:
 //   fp16: chunk = 8 k  -> block = 32 k, one v_mfma_f32_16x16x32_f16 per (A block, B block)
 //   fp32: chunk = 4 k  -> block = 16 k, four v_mfma_f32_16x16x4_f32 (exact fp32 products and accumulation);
@@ -71,21 +78,38 @@ template <> struct Elem<float> {
 };
 
 
-// Shared epilogue: bias, ReLU, residual (after the ReLU: model.py:72-73), then one of: NHWC store, NHWC store of the
-// 2x2 nearest-upsampled block (model.py:145-147), planar fp32 store (head outputs). m_of[i] is the output pixel
-// (row-major index into Ho x Wo) of this lane's column of pixel-subtile i, or -1 if it lies outside the image.
-template <typename T, int WM_T, int WN_T>
+// ---- epilogue ------------------------------------------------------------------------------------------------
+// bias, ReLU, residual (after the ReLU: model.py:72-73) are applied in registers (one rounding). Then:
+//  * NHWC outputs: the workgroup's BM x BN tile is staged through LDS ([pixel][BN] rows, 16-byte row padding against
+//    bank conflicts) and written back as FULL contiguous rows, 16 bytes per lane -- an accumulator fragment only
+//    holds 4 channels of a pixel per lane, and storing those directly costs 16 partial 32-byte line writes per
+//    wave-instruction (measured: up to 13 k cycles per workgroup). The folded nearest-x2 Upsample (model.py:145-147)
+//    writes each row to its 2x2 block.
+//  * planar fp32 head outputs: lane = pixel already gives 64-byte contiguous runs per channel: stored directly.
+// pix_to_m(pl) maps a workgroup-local pixel to the row-major output pixel index, or -1 outside the image.
+template <typename T, int BM, int BN, int WM_T, int WN_T, typename PixToM>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg& sg, floatx4 (&acc)[WN_T][WM_T],
-                                              const int (&m_of)[WM_T], int n_w0, int lq) {
+                                              int wm, int wn, int nb0, int l15, int lq, PixToM pix_to_m,
+                                              unsigned char* stage) {
   typedef Elem<T> E;
+  typedef typename E::out4 out4;
+  constexpr int ESZ = sizeof(T);
+  constexpr int ROWB = BN * ESZ + 16;          // padded LDS row (bytes)
+  constexpr int CPR = BN * ESZ / 16;           // 16-byte chunks per pixel row
+  constexpr int EPC = 16 / ESZ;                // elements per chunk
+  const int n_w0 = wn * (WN_T * 16);           // tile-local first channel of this wave
+  const bool planar = sg.dst_planar != nullptr;
+  if (!planar) __syncthreads();                // every wave is done reading the operand buffers: reuse them
 #pragma unroll
   for (int j = 0; j < WN_T; ++j) {
-    const int n = n_w0 + j * 16 + lq * 4;  // first of this lane's 4 consecutive channels (slice-relative)
+    const int nl = n_w0 + j * 16 + lq * 4;     // tile-local channel of this lane's 4 values
+    const int n = nb0 + nl;                    // slice-relative
     if (n >= sg.n_count) continue;
     const floatx4 bias = *reinterpret_cast<const floatx4*>(sg.bias + n);
 #pragma unroll
     for (int i = 0; i < WM_T; ++i) {
-      const int m = m_of[i];
+      const int pl = (wm * WM_T + i) * 16 + l15;
+      const int m = pix_to_m(pl);
       if (m < 0) continue;
       floatx4 v = acc[j][i] + bias;
       if (p.relu) {
@@ -93,32 +117,41 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg
         for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
       }
       if (p.res) {
-        const typename E::out4 rv = *reinterpret_cast<const typename E::out4*>(static_cast<const T*>(p.res) + (size_t)m * p.res_ld + n);
+        const out4 rv = *reinterpret_cast<const out4*>(static_cast<const T*>(p.res) + (size_t)m * p.res_ld + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
       }
-      if (sg.dst_planar) {
+      if (planar) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (n + r < sg.n_count) sg.dst_planar[(size_t)(n + r) * p.M + m] = v[r];
       } else {
-        typedef typename E::out4 out4;
         out4 hv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) hv[r] = (T)v[r];
-        T* dst = static_cast<T*>(sg.dst);
-        if (sg.up2) {
-          const int oy = m / p.Wo, ox = m - oy * p.Wo;
-          const size_t row = (size_t)(2 * oy) * (2 * p.Wo) + 2 * ox;
-          T* d = dst + row * sg.dst_ld + n;
-          *reinterpret_cast<out4*>(d) = hv;
-          *reinterpret_cast<out4*>(d + sg.dst_ld) = hv;
-          *reinterpret_cast<out4*>(d + (size_t)(2 * p.Wo) * sg.dst_ld) = hv;
-          *reinterpret_cast<out4*>(d + (size_t)(2 * p.Wo + 1) * sg.dst_ld) = hv;
-        } else {
-          *reinterpret_cast<out4*>(dst + (size_t)m * sg.dst_ld + n) = hv;
-        }
+        *reinterpret_cast<out4*>(stage + pl * ROWB + nl * ESZ) = hv;
       }
+    }
+  }
+  if (planar) return;
+  __syncthreads();
+  typedef float vec16 __attribute__((ext_vector_type(4)));  // 16 opaque bytes
+  T* dst = static_cast<T*>(sg.dst);
+  for (int c = threadIdx.x; c < BM * CPR; c += 256) {
+    const int pl = c / CPR, ch = c - pl * CPR;
+    const int n = nb0 + ch * EPC;
+    const int m = pix_to_m(pl);
+    if (m < 0 || n >= sg.n_count) continue;
+    const vec16 v = *reinterpret_cast<const vec16*>(stage + pl * ROWB + ch * 16);
+    if (sg.up2) {
+      const int oy = m / p.Wo, ox = m - oy * p.Wo;
+      T* d = dst + ((size_t)(2 * oy) * (2 * p.Wo) + 2 * ox) * sg.dst_ld + n;
+      *reinterpret_cast<vec16*>(d) = v;
+      *reinterpret_cast<vec16*>(d + sg.dst_ld) = v;
+      *reinterpret_cast<vec16*>(d + (size_t)(2 * p.Wo) * sg.dst_ld) = v;
+      *reinterpret_cast<vec16*>(d + (size_t)(2 * p.Wo + 1) * sg.dst_ld) = v;
+    } else {
+      *reinterpret_cast<vec16*>(dst + (size_t)m * sg.dst_ld + n) = v;
     }
   }
 }
@@ -228,39 +261,65 @@ __global__ __launch_bounds__(256) void conv_glds(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < WM_T; ++i) acc[j][i] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: STAGES-1 K-steps in flight (steps past the end are all-zero dummies: counts stay uniform) ----
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s) issue(s);
-
+  // ---- software pipeline ----------------------------------------------------------------------------------
+  // LDS-DMA ring: STAGES buffers, stage kt lives in buffer kt % STAGES; steps past the end are all-zero dummies so
+  // that every wave issues the same number of DMA instructions per step (uniform vmcnt arithmetic).
+  // Register pipeline: the fragments of step kt+1 are read from LDS into the OTHER register set while the MFMAs of
+  // step kt issue, so LDS latency overlaps matrix work (the compiler alone serialises read -> lgkmcnt(0) -> MFMA).
+  // Iteration kt: wait until stage kt+1 has landed (<= (STAGES-3)*LPT DMA ops may remain in flight), barrier,
+  // refill buffer (kt-1) % STAGES -- its fragments were consumed by the MFMAs every wave finished before this
+  // barrier --, read stage kt+1, run the MFMAs of stage kt.
+  static_assert(STAGES >= 3, "ring depth");
+  struct Frags {
+    frag_t a[KSUB][WN_T], b[KSUB][WM_T];
+  };
   const int rd_off = (4 * l15 + (lq ^ swz_g(l15))) * 16;  // this lane's fragment slot inside any block
-  for (int kt = 0; kt < nk; ++kt) {
-    wait_vmcnt<(STAGES - 2) * LPT>();   // this wave's loads of step kt have landed
-    __builtin_amdgcn_s_barrier();       // ... and everyone's; everyone is also done reading buffer (kt-1)%STAGES
-    issue((kt + STAGES - 1) % STAGES);  // refill the buffer freed by step kt-1
+  auto read_frags = [&](Frags& f, int kt) {
     const unsigned char* sb = conv_smem + (kt % STAGES) * STAGE_BYTES + rd_off;
 #pragma unroll
     for (int j = 0; j < KSUB; ++j) {
-      frag_t a[WN_T], b[WM_T];
 #pragma unroll
-      for (int i = 0; i < WM_T; ++i) b[i] = *reinterpret_cast<const frag_t*>(sb + (((wm * WM_T + i) * KSUB + j) << 10));
+      for (int i = 0; i < WM_T; ++i) f.b[j][i] = *reinterpret_cast<const frag_t*>(sb + (((wm * WM_T + i) * KSUB + j) << 10));
 #pragma unroll
-      for (int n = 0; n < WN_T; ++n) a[n] = *reinterpret_cast<const frag_t*>(sb + ((ABLK + (wn * WN_T + n) * KSUB + j) << 10));
+      for (int n = 0; n < WN_T; ++n) f.a[j][n] = *reinterpret_cast<const frag_t*>(sb + ((ABLK + (wn * WN_T + n) * KSUB + j) << 10));
+    }
+  };
+  auto mma_frags = [&](const Frags& f) {
+#pragma unroll
+    for (int j = 0; j < KSUB; ++j)
 #pragma unroll
       for (int n = 0; n < WN_T; ++n)
 #pragma unroll
-        for (int i = 0; i < WM_T; ++i) acc[n][i] = E::mma(a[n], b[i], acc[n][i]);
-    }
+        for (int i = 0; i < WM_T; ++i) acc[n][i] = E::mma(f.a[j][n], f.b[j][i], acc[n][i]);
+  };
+  stamp(p, 0);
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) issue(s);
+  stamp(p, 1);
+  Frags fa, fb;
+  wait_vmcnt<(STAGES - 2) * LPT>();  // stage 0 landed
+  __builtin_amdgcn_s_barrier();
+  read_frags(fa, 0);
+  stamp(p, 2);
+  // No conditionals inside: a branch around the reads makes hipcc fall back to s_waitcnt lgkmcnt(0) before the MFMAs.
+  // Steps past the end read / multiply all-zero dummy stages (they add exactly 0), so an odd step count is simply
+  // rounded up.
+  auto step = [&](int kt, Frags& cur, Frags& nxt) {
+    wait_vmcnt<(STAGES - 3) * LPT>();
+    __builtin_amdgcn_s_barrier();
+    issue((kt + STAGES - 1) % STAGES);
+    read_frags(nxt, kt + 1);
+    mma_frags(cur);
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(kt, fa, fb);
+    step(kt + 1, fb, fa);
   }
   wait_vmcnt<0>();  // drain the dummy tail before the wave retires
 
   // ---- epilogue ----
-  int m_of[WM_T];
-#pragma unroll
-  for (int i = 0; i < WM_T; ++i) {
-    const int m = m_blk + (wm * WM_T + i) * 16 + l15;
-    m_of[i] = m < p.M ? m : -1;
-  }
-  conv_epilogue<T, WM_T, WN_T>(p, sg, acc, m_of, nb0 + wn * (WN_T * 16), lq);
+  conv_epilogue<T, BM, BN, WM_T, WN_T>(p, sg, acc, wm, wn, nb0, l15, lq,
+                                       [&](int pl) { const int m = m_blk + pl; return m < p.M ? m : -1; }, conv_smem);
 }
 
 
@@ -308,6 +367,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
   const T* zeros = reinterpret_cast<const T*>(p.zeros);
 
   // ---- 1. patch DMA: slot s (16 B) of the image = pixel s / nch, slot-in-pixel s % nch ----
+  stamp(p, 0);
   {
     const int nslots = NPIX * nch;
     const T* src = static_cast<const T*>(p.src) + sg.src_coff;
@@ -352,6 +412,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
   };
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) issue(s);
+  stamp(p, 1);
 
   // ---- 3. per-lane patch addressing: pixel of every subtile, tap (0,0) ----
   int h00[WM_T];
@@ -366,10 +427,17 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < WM_T; ++i) acc[j][i] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+  // ---- software pipeline (see conv_glds): weights ring + register double buffer; B fragments come from the patch ----
+  static_assert(STAGES >= 3, "ring depth");
+  struct Frags {
+    frag_t a[KSUB][WN_T], b[KSUB][WM_T];
+  };
   const int rd_off = (4 * l15 + (lq ^ swz_g(l15))) * 16;
-  int kt = 0;
-  for (int tap = 0; tap < 9; ++tap) {
-    const int tap_off = (tap / 3) * HW_ + (tap % 3);
+  auto read_frags = [&](Frags& f, int kt) {
+    const int tap_raw = kt / steps_per_tap, cs = kt - tap_raw * steps_per_tap;  // wave-uniform
+    const int tap = tap_raw < 9 ? tap_raw : 8;                                 // dummy steps past the end stay inside the patch
+    const int tap_off = (tap / 3) * HW_ + (tap - (tap / 3) * 3);
+    const unsigned char* sb = conv_smem + (kt % STAGES) * STAGE_BYTES + rd_off;
     int hrow[WM_T], hsw[WM_T];  // byte offset of the pixel row, swizzle term
 #pragma unroll
     for (int i = 0; i < WM_T; ++i) {
@@ -377,36 +445,53 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
       hrow[i] = h << (nch_log + 4);
       hsw[i] = h & swz;
     }
-    for (int cs = 0; cs < steps_per_tap; ++cs, ++kt) {
-      wait_vmcnt<(STAGES - 2) * LPT>();
-      __builtin_amdgcn_s_barrier();
-      issue((kt + STAGES - 1) % STAGES);
-      const unsigned char* sb = conv_smem + (kt % STAGES) * STAGE_BYTES + rd_off;
 #pragma unroll
-      for (int j = 0; j < KSUB; ++j) {
-        const int ch = (cs * KSUB + j) * 4 + lq;  // this lane's 16-byte chunk index inside the pixel
-        frag_t a[WN_T], b[WM_T];
+    for (int j = 0; j < KSUB; ++j) {
+      const int ch = (cs * KSUB + j) * 4 + lq;  // this lane's 16-byte chunk index inside the pixel
 #pragma unroll
-        for (int i = 0; i < WM_T; ++i) b[i] = *reinterpret_cast<const frag_t*>(patch + hrow[i] + ((ch ^ hsw[i]) << 4));
+      for (int i = 0; i < WM_T; ++i) f.b[j][i] = *reinterpret_cast<const frag_t*>(patch + hrow[i] + ((ch ^ hsw[i]) << 4));
 #pragma unroll
-        for (int n = 0; n < WN_T; ++n) a[n] = *reinterpret_cast<const frag_t*>(sb + (((wn * WN_T + n) * KSUB + j) << 10));
-#pragma unroll
-        for (int n = 0; n < WN_T; ++n)
-#pragma unroll
-          for (int i = 0; i < WM_T; ++i) acc[n][i] = E::mma(a[n], b[i], acc[n][i]);
-      }
+      for (int n = 0; n < WN_T; ++n) f.a[j][n] = *reinterpret_cast<const frag_t*>(sb + (((wn * WN_T + n) * KSUB + j) << 10));
     }
+  };
+  auto mma_frags = [&](const Frags& f) {
+#pragma unroll
+    for (int j = 0; j < KSUB; ++j)
+#pragma unroll
+      for (int n = 0; n < WN_T; ++n)
+#pragma unroll
+        for (int i = 0; i < WM_T; ++i) acc[n][i] = E::mma(f.a[j][n], f.b[j][i], acc[n][i]);
+  };
+  Frags fa, fb;
+  wait_vmcnt<(STAGES - 2) * LPT>();  // patch + stage 0 landed
+  __builtin_amdgcn_s_barrier();
+  read_frags(fa, 0);
+  stamp(p, 2);
+  // No conditionals inside: a branch around the reads makes hipcc fall back to s_waitcnt lgkmcnt(0) before the MFMAs.
+  // Steps past the end read / multiply all-zero dummy stages (they add exactly 0), so an odd step count is simply
+  // rounded up.
+  auto step = [&](int kt, Frags& cur, Frags& nxt) {
+    wait_vmcnt<(STAGES - 3) * LPT>();
+    __builtin_amdgcn_s_barrier();
+    issue((kt + STAGES - 1) % STAGES);
+    read_frags(nxt, kt + 1);
+    mma_frags(cur);
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(kt, fa, fb);
+    step(kt + 1, fb, fa);
   }
   wait_vmcnt<0>();
+  stamp(p, 3);
 
-  int m_of[WM_T];
-#pragma unroll
-  for (int i = 0; i < WM_T; ++i) {
-    const int pix = (wm * WM_T + i) * 16 + l15;
-    const int oy = ty0 + pix / TW, ox = tx0 + pix % TW;
-    m_of[i] = (oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
-  }
-  conv_epilogue<T, WM_T, WN_T>(p, sg, acc, m_of, nb0 + wn * (WN_T * 16), lq);
+  conv_epilogue<T, BM, BN, WM_T, WN_T>(p, sg, acc, wm, wn, nb0, l15, lq,
+                                       [&](int pl) {
+                                         const int oy = ty0 + pl / TW, ox = tx0 + pl % TW;
+                                         return (oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
+                                       },
+                                       conv_smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp(p, 4);
 }
 
 // ---------------------------------------------------------------------------------------------- launch side
@@ -420,9 +505,12 @@ struct CfgInfo {
   int th, tw;          // halo kernel: spatial tile (0 = im2col kernel)
 };
 
+constexpr size_t stage_bytes(int bm, int bn) { return (size_t)bm * (bn * 4 + 16); }  // epilogue staging tile (fp32 worst case)
+constexpr size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
 template <int BM, int BN, int BK, int WM, int WN, int ST>
 constexpr size_t smem_of() {
-  return (size_t)ST * (((BM / 16 + BN / 16) * (BK / 32) + 3) / 4) * 4 * 1024;
+  return max_sz((size_t)ST * (((BM / 16 + BN / 16) * (BK / 32) + 3) / 4) * 4 * 1024, stage_bytes(BM, BN));
 }
 
 #define CFG(T, TN, BM, BN, BK, WM, WN, ST)                                                         \
@@ -438,12 +526,12 @@ const CfgInfo kCfg[2][kCfgCount] = {
     {
         CFG(half_t, "f16", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
         CFG(half_t, "f16", 64, 64, 32, 2, 2, 4),    // kCfg64x64k32
-        CFG(half_t, "f16", 128, 64, 64, 2, 2, 3),   // kCfg128x64k64
+        CFG(half_t, "f16", 128, 64, 64, 2, 2, 4),   // kCfg128x64k64
         CFG(half_t, "f16", 128, 64, 32, 2, 2, 4),   // kCfg128x64k32
-        CFG(half_t, "f16", 128, 128, 64, 2, 2, 3),  // kCfg128x128k64
-        CFG(half_t, "f16", 128, 32, 64, 4, 1, 3),   // kCfg128x32k64
+        CFG(half_t, "f16", 128, 128, 64, 2, 2, 4),  // kCfg128x128k64
+        CFG(half_t, "f16", 128, 32, 64, 4, 1, 4),   // kCfg128x32k64
         CFG(half_t, "f16", 128, 32, 32, 4, 1, 4),   // kCfg128x32k32
-        CFG(half_t, "f16", 128, 16, 64, 4, 1, 3),   // kCfg128x16k64
+        CFG(half_t, "f16", 128, 16, 64, 4, 1, 4),   // kCfg128x16k64
         CFG(half_t, "f16", 32, 64, 64, 1, 4, 4),    // kCfg32x64k64
         CFG(half_t, "f16", 32, 64, 64, 1, 4, 8),    // kCfg32x64k64s8  (deep pipeline for latency-bound small grids)
         CFG(half_t, "f16", 64, 64, 64, 2, 2, 6),    // kCfg64x64k64s6
@@ -453,16 +541,27 @@ const CfgInfo kCfg[2][kCfgCount] = {
         HALO(half_t, "f16", 8, 16, 32, 64, 4, 1, 4),  // kCfgHalo8x16n32
         HALO(half_t, "f16", 8, 8, 64, 32, 2, 2, 4),   // kCfgHalo8x8n64k32
         HALO(half_t, "f16", 8, 16, 32, 32, 4, 1, 4),  // kCfgHalo8x16n32k32
+        HALO(half_t, "f16", 16, 16, 64, 64, 2, 2, 4), // kCfgHalo16x16n64   (wave tile 128 px x 32 ch)
+        HALO(half_t, "f16", 16, 16, 32, 64, 4, 1, 4), // kCfgHalo16x16n32   (wave tile 64 px x 32 ch)
+        HALO(half_t, "f16", 8, 16, 64, 64, 4, 1, 4),  // kCfgHalo8x16n64w41 (wave tile 32 px x 64 ch)
+        HALO(half_t, "f16", 8, 8, 64, 64, 4, 1, 4),   // kCfgHalo8x8n64w41  (wave tile 16 px x 64 ch)
+        HALO(half_t, "f16", 8, 8, 32, 128, 4, 1, 4),  // kCfgHalo8x8n32k128   (K-step 128 channels)
+        HALO(half_t, "f16", 8, 8, 32, 256, 4, 1, 4),  // kCfgHalo8x8n32k256
+        HALO(half_t, "f16", 8, 8, 64, 128, 2, 2, 4),  // kCfgHalo8x8n64k128
+        HALO(half_t, "f16", 8, 16, 32, 128, 4, 1, 4), // kCfgHalo8x16n32k128
+        HALO(half_t, "f16", 8, 16, 64, 128, 2, 2, 4), // kCfgHalo8x16n64k128
+        CFG(half_t, "f16", 32, 64, 128, 1, 4, 4),     // kCfg32x64k128
+        CFG(half_t, "f16", 64, 64, 128, 2, 2, 4),     // kCfg64x64k128
     },
     {
         CFG(float, "f32", 64, 64, 64, 2, 2, 4),
         CFG(float, "f32", 64, 64, 32, 2, 2, 4),
-        CFG(float, "f32", 128, 64, 64, 2, 2, 3),
+        CFG(float, "f32", 128, 64, 64, 2, 2, 4),
         CFG(float, "f32", 128, 64, 32, 2, 2, 4),
-        CFG(float, "f32", 128, 128, 64, 2, 2, 3),
-        CFG(float, "f32", 128, 32, 64, 4, 1, 3),
+        CFG(float, "f32", 128, 128, 64, 2, 2, 4),
+        CFG(float, "f32", 128, 32, 64, 4, 1, 4),
         CFG(float, "f32", 128, 32, 32, 4, 1, 4),
-        CFG(float, "f32", 128, 16, 64, 4, 1, 3),
+        CFG(float, "f32", 128, 16, 64, 4, 1, 4),
         CFG(float, "f32", 32, 64, 64, 1, 4, 4),
         CFG(float, "f32", 32, 64, 64, 1, 4, 8),
         CFG(float, "f32", 64, 64, 64, 2, 2, 6),
@@ -472,6 +571,17 @@ const CfgInfo kCfg[2][kCfgCount] = {
         HALO(float, "f32", 8, 16, 32, 64, 4, 1, 4),
         HALO(float, "f32", 8, 8, 64, 32, 2, 2, 4),
         HALO(float, "f32", 8, 16, 32, 32, 4, 1, 4),
+        HALO(float, "f32", 16, 16, 64, 64, 2, 2, 4),
+        HALO(float, "f32", 16, 16, 32, 64, 4, 1, 4),
+        HALO(float, "f32", 8, 16, 64, 64, 4, 1, 4),
+        HALO(float, "f32", 8, 8, 64, 64, 4, 1, 4),
+        HALO(float, "f32", 8, 8, 32, 128, 4, 1, 4),
+        HALO(float, "f32", 8, 8, 32, 256, 4, 1, 4),
+        HALO(float, "f32", 8, 8, 64, 128, 2, 2, 4),
+        HALO(float, "f32", 8, 16, 32, 128, 4, 1, 4),
+        HALO(float, "f32", 8, 16, 64, 128, 2, 2, 4),
+        CFG(float, "f32", 32, 64, 128, 1, 4, 4),
+        CFG(float, "f32", 64, 64, 128, 2, 2, 4),
     },
 };
 #undef CFG
@@ -482,7 +592,7 @@ inline size_t esize(const ConvParams& p) { return p.dtype == kF32 ? 4 : 2; }
 inline size_t smem_for(const ConvParams& p, const CfgInfo& c) {
   if (!c.th) return c.smem;
   const size_t patch = (size_t)(c.th + 2) * (c.tw + 2) * p.Cin * esize(p);
-  return c.smem + ((patch + 1023) & ~(size_t)1023);
+  return max_sz(c.smem + ((patch + 1023) & ~(size_t)1023), stage_bytes(c.bm, c.bn));
 }
 constexpr size_t kMaxLds = 160 * 1024;
 

@@ -166,7 +166,8 @@ int plan(unina_engine* e) {
           cs.dst_ld = 0;
           out_bytes += 4.0 * sd.n_count * p.M;
         } else {
-          if (db.d.dtype != act_dtype || sd.n_count % 4) return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: NHWC slice needs n %% 4 == 0", i);
+          if (db.d.dtype != act_dtype || sd.n_count % 8 || sd.dst_coff % 8 || db.d.c % 8)
+            return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: NHWC slice needs channel counts/offsets that are multiples of 8", i);
           cs.dst = static_cast<char*>(db.ptr) + (size_t)sd.dst_coff * esz;
           cs.dst_planar = nullptr;
           cs.dst_ld = (int)db.d.c;
@@ -636,6 +637,26 @@ int unina_debug_post_stamps(unina_engine_t* e, long long* out8) {
   HIPCHK(e, hipSetDevice(e->device));
   HIPCHK(e, hipDeviceSynchronize());
   HIPCHK(e, hipMemcpy(out8, e->d_result->pad_stamps, sizeof(long long) * 8, hipMemcpyDeviceToHost));
+  return UNINA_OK;
+}
+
+// Debug: runs conv op `op_index` once with in-kernel s_memtime stamps on (one workgroup in the middle of the grid):
+// out5 = shader-clock ticks at start / prologue issued / first data usable / K loop done / stores drained.
+int unina_debug_conv_stamps(unina_engine_t* e, int op_index, long long* out5, hipStream_t stream) {
+  if (!e || !out5 || op_index < 0 || op_index >= (int)e->ops.size()) return UNINA_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (e->plan_dirty) {
+    int rc = plan(e);
+    if (rc != UNINA_OK) return rc;
+  }
+  if (e->ops[op_index].d.kind != kOpConv) return fail(e, UNINA_ERR_ARG, "op %d is not a convolution", op_index);
+  ConvParams p = e->ops[op_index].cp;
+  if (const char* dm = getenv("UNINA_CONV_DEBUG_MODE")) p.debug_mode = atoi(dm);
+  p.stamps = reinterpret_cast<long long*>(e->d_result->pad_stamps);
+  HIPCHK(e, hipMemsetAsync(p.stamps, 0, sizeof(long long) * 8, stream));
+  HIPCHK(e, conv_launch(p, e->ops[op_index].cl, stream));
+  HIPCHK(e, hipStreamSynchronize(stream));
+  HIPCHK(e, hipMemcpy(out5, p.stamps, sizeof(long long) * 7, hipMemcpyDeviceToHost));  // 5 shader-clock stamps + 2 at 100 MHz
   return UNINA_OK;
 }
 

@@ -42,6 +42,8 @@ struct ConvParams {
   ConvSeg seg[2];
   const void* zeros;   // >= 16 bytes of zeros in HBM: source of out-of-image taps / tile tails
   int force_cfg;       // >= 0: use this tile configuration (autotuner / tests); -1: heuristic
+  int debug_mode;      // debug ablations (results invalid): 1 = no loads inside the K loop, 2 = no LDS reads/MFMA, 3 = MFMA without LDS reads
+  long long* stamps;   // debug: s_memtime stamps of workgroup (0,0) (nullptr = off): start, prologue issued, first data, loop end, end
 };
 
 // tile configurations of the conv kernel: block tile = BM pixels x BN output channels, K-step BK
@@ -49,6 +51,9 @@ enum ConvConfig : int {
   kCfg64x64k64 = 0, kCfg64x64k32, kCfg128x64k64, kCfg128x64k32, kCfg128x128k64,
   kCfg128x32k64, kCfg128x32k32, kCfg128x16k64, kCfg32x64k64, kCfg32x64k64s8, kCfg64x64k64s6,
   kCfgHalo8x8n64, kCfgHalo8x8n32, kCfgHalo8x16n64, kCfgHalo8x16n32, kCfgHalo8x8n64k32, kCfgHalo8x16n32k32,
+  kCfgHalo16x16n64, kCfgHalo16x16n32, kCfgHalo8x16n64w41, kCfgHalo8x8n64w41,
+  kCfgHalo8x8n32k128, kCfgHalo8x8n32k256, kCfgHalo8x8n64k128, kCfgHalo8x16n32k128, kCfgHalo8x16n64k128,
+  kCfg32x64k128, kCfg64x64k128,
   kCfgCount
 };
 struct ConvLaunch {

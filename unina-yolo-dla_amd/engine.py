@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "unina_load_engine", "unina_unload_engine", "unina_engine_input_dims", "unina_set_tensor_address",
     "unina_tensor_address", "unina_enqueue", "unina_infer", "unina_infer_async", "unina_postprocess_async",
     "unina_last_error", "unina_op_count", "unina_get_op_info", "unina_profile_ops", "unina_debug_read_buffer",
-    "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune", "unina_debug_post_stamps",
+    "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune", "unina_debug_post_stamps", "unina_debug_conv_stamps",
     "init_postprocess_resources", "cleanup_postprocess_resources", "reset_detection_counter", "get_detection_count",
     "decode_yolo_head", "run_gpu_nms", "copy_valid_detections_to_host",
 ]
@@ -82,6 +82,7 @@ def load_library() -> C.CDLL:
     L.unina_set_op_config.argtypes = [vp, ci, ci]
     L.unina_autotune.argtypes = [vp, ci, vp]
     L.unina_debug_post_stamps.argtypes = [vp, C.POINTER(C.c_longlong)]
+    L.unina_debug_conv_stamps.argtypes = [vp, ci, C.POINTER(C.c_longlong), vp]
     # gpu_postprocess.h drop-in symbols
     L.reset_detection_counter.argtypes = [vp]
     L.get_detection_count.argtypes = [C.POINTER(ci), vp]
@@ -273,6 +274,12 @@ class Engine:
         buf = (C.c_longlong * 8)()
         self._check(self.L.unina_debug_post_stamps(self.h, buf))
         return [int(v) for v in buf][:7]
+
+    def conv_stamps(self, op_index: int, stream=None) -> List[int]:
+        """In-kernel phase stamps (shader-clock ticks) of one launch of conv op `op_index` (debug)."""
+        buf = (C.c_longlong * 7)()
+        self._check(self.L.unina_debug_conv_stamps(self.h, op_index, buf, _stream_ptr(stream)))
+        return [int(v) for v in buf]
 
     def conv_configs(self) -> List[str]:
         return [self.L.unina_conv_config_name(i).decode() for i in range(self.L.unina_conv_config_count())]
