@@ -31,7 +31,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np  # noqa: E402
 
 FLOPS_PER_FRAME = {640: 35_664_691_200, 1280: 142_658_764_800}   # SURVEY.md section 8d (2 x MACs, conv only)
-PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}                                     # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "i8": 5000.0}   # dense; int8 = 2x the fp16 matrix rate (MI355X_MICROARCH.md)                                     # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 N_FRAMES = 16            # distinct synthetic frames cycled through
 IN_FLIGHT = int(os.environ.get("UNINA_IN_FLIGHT", "2"))   # engine handles per GPU = frames in flight
@@ -47,8 +47,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--latency-frames", type=int, default=300)
-    ap.add_argument("--precision", choices=["fp16", "fp32"], default="fp16",
+    ap.add_argument("--precision", choices=["fp16", "fp32", "int8"], default="fp16",
                     help="fp16 = BASELINE configs[1] (headline); fp32 = native fp32-MFMA mode that meets the strict tolerance")
+    ap.add_argument("--calib-frames", type=int, default=64)
     ap.add_argument("--streams", type=int, default=0, help="parallel graph paths per engine (0 = library default)")
     ap.add_argument("--tune-cache", default=os.environ.get("UNINA_TUNE_CACHE", ""), help="tactic cache file (JSON)")
     args = ap.parse_args()
@@ -77,8 +78,12 @@ def main():
     sd = u.synth.make_state_dict(7, g)
     fd, path = tempfile.mkstemp(suffix=f".rank{rank}.une")
     os.close(fd)
-    prec = export.FP32 if args.precision == "fp32" else export.FP16
-    export.export_engine(sd, path, g, prec)
+    prec = {"fp32": export.FP32, "int8": export.INT8}.get(args.precision, export.FP16)
+    amax = None
+    if prec == export.INT8:   # BASELINE configs[2]: own calibrator over 64 synthetic frames (seeds 5000..5063)
+        from unina_yolo_dla_amd.engine import calibrate_amax
+        amax = calibrate_amax(sd, g, (u.rng.frame(5000 + i, S, S) for i in range(args.calib_frames)), device=local)
+    export.export_engine(sd, path, g, prec, amax)
     engines = [Engine(path, device=local) for _ in range(IN_FLIGHT)]
     os.unlink(path)
     streams = [torch.cuda.Stream(device=dev) for _ in range(IN_FLIGHT)]
@@ -140,7 +145,7 @@ def main():
 
         # ---- roofline of the dominant kernel: live HIP-event timing of every op on the launch stream ----
         ops = e0.profile_ops(iters=20)
-        dname = "f32" if args.precision == "fp32" else "f16"
+        dname = {"fp32": "f32", "int8": "i8"}.get(args.precision, "f16")
         by_kernel = {}
         for o in ops:
             k = by_kernel.setdefault(o["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))

@@ -1,8 +1,9 @@
-"""Test-only emulator of the ENGINE's arithmetic: executes the exporter's fused op table with torch CPU fp32
-math, rounding to fp16 exactly where the HIP kernels do (folded weights, every NHWC buffer write). It checks two
-things independently of the kernels: (1) the op table (fusions, concat slices, residual/upsample folding) computes
-graph (A); (2) the fp16 engine's deviation from the fp32 oracle is the fp16 FORMAT's rounding noise, not a kernel
-error -- the GPU must match this emulator far more tightly than it matches fp32."""
+"""Test-only emulator of the ENGINE's arithmetic: executes the exporter's fused op table with torch CPU math,
+rounding exactly where the HIP kernels do (folded fp16 weights, every NHWC buffer write; int8 engines: integer dot
+products, per-channel float multiplier, round-half-even requantisation). It checks, independently of the kernels:
+(1) the op table (fusions, concat slices, residual/upsample folding, int8 pass) computes graph (A); (2) the fp16
+engine's deviation from the fp32 oracle is the fp16 FORMAT's rounding noise, not a kernel error; (3) the int8
+engine's integer arithmetic bit for bit."""
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -11,24 +12,39 @@ from unina_yolo_dla_amd import export
 
 
 def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = True):
-    """x: [1,3,H,W] fp32. Returns ({output name: [C,H,W] fp32}, {buffer name: [C,H,W] fp32})."""
-    fp32_engine = builder.precision == export.FP32
-    q = (lambda t: t.half().float()) if (fp16 and not fp32_engine) else (lambda t: t)
-    wdt = "<f4" if fp32_engine else "<f2"
+    """x: [1,3,H,W] fp32. Returns ({output name: [C,H,W] fp32}, {buffer name: [C,H,W] fp32}).
+    int8 buffers are returned as their integer codes (multiply by the buffer scale to dequantise)."""
+    prec = builder.precision
+    wdt = {export.FP16: "<f2", export.FP32: "<f4", export.INT8: "<f2"}[prec]
     blob = bytes(builder.blob)
-    bufs = {}
-    for i, (name, h, w, c, dtype, flags) in enumerate(builder.buffers):
-        bufs[i] = torch.zeros((c, h, w), dtype=torch.float32)
+    bdtype = [b[4] for b in builder.buffers]
+    bscale = [b[6] for b in builder.buffers]
+    bufs = {i: torch.zeros((c, h, w), dtype=torch.float64 if prec == export.INT8 else torch.float32)
+            for i, (name, h, w, c, *_rest) in enumerate(builder.buffers)}
     img = next(i for i, b in enumerate(builder.buffers) if b[5] & export.BUF_INPUT)
-    bufs[img] = torch.from_numpy(np.ascontiguousarray(x[0]))
-    for op in builder.ops:
+    bufs[img] = torch.from_numpy(np.ascontiguousarray(x[0])).to(bufs[img].dtype)
+
+    def store(dst_buf, y):
+        """round y (real values) the way a kernel writing into buffer `dst_buf` does"""
+        d = bdtype[dst_buf]
+        if d == export.BUF_I8:
+            return torch.clamp(torch.round(y.float() * np.float32(1.0 / bscale[dst_buf])), -127, 127).to(y.dtype)
+        if d == export.BUF_F16 and fp16:
+            return y.half().to(y.dtype)
+        return y.float().to(y.dtype)
+
+    def real(buf_idx, t):
+        """real values held by (a slice of) buffer buf_idx"""
+        return t * bscale[buf_idx] if bdtype[buf_idx] == export.BUF_I8 else t
+
+    for oi, op in enumerate(builder.ops):
         src = bufs[op.src_buf]
         if op.kind == export.OP_STEM:
             s = op.segs[0]
             w = torch.from_numpy(np.frombuffer(blob, dtype="<f4", count=s.n_count * 27, offset=s.w_off).reshape(s.n_count, 3, 3, 3).copy())
             b = torch.from_numpy(np.frombuffer(blob, dtype="<f4", count=s.n_count, offset=s.b_off).copy())
-            y = F.relu(F.conv2d(src[None], w, b, stride=2, padding=1))[0]
-            bufs[s.dst.buf][s.dst.coff:s.dst.coff + s.n_count] = q(y)
+            y = F.relu(F.conv2d(src[None].float(), w, b, stride=2, padding=1))[0].to(src.dtype)
+            bufs[s.dst.buf][s.dst.coff:s.dst.coff + s.n_count] = store(s.dst.buf, y)
         elif op.kind == export.OP_SPPF_POOL:
             s = op.segs[0]
             c = op.cin
@@ -36,27 +52,50 @@ def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = Tr
             for i in range(1, 4):
                 t = F.max_pool2d(t, 5, 1, 2)
                 src[s.src_coff + i * c:s.src_coff + (i + 1) * c] = t[0]
+        elif op.kind == export.OP_QUANT:
+            s = op.segs[0]
+            bufs[s.dst.buf][s.dst.coff:s.dst.coff + s.n_count] = store(s.dst.buf, src[:s.n_count])
         elif op.kind == export.OP_CONV:
             k = op.k
+            int8 = prec == export.INT8 and builder.op_int8[oi]
             for s in op.segs:
-                w = np.frombuffer(blob, dtype=wdt, count=s.n_pad * k * k * op.cin, offset=s.w_off)
-                w = export.unpack_weights(w, s.n_pad, k * k * op.cin)
-                w = torch.from_numpy(w.reshape(s.n_pad, k, k, op.cin)[:s.n_count].astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+                K = k * k * op.cin
+                xin = src[s.src_coff:s.src_coff + op.cin][None]
                 b = torch.from_numpy(np.frombuffer(blob, dtype="<f4", count=s.n_count, offset=s.b_off).copy())
-                y = F.conv2d(src[s.src_coff:s.src_coff + op.cin][None], w, b, stride=op.s, padding=k // 2)[0]
+                if int8:
+                    w = np.frombuffer(blob, dtype="i1", count=s.n_pad * K, offset=s.w_off)
+                    w = export.unpack_weights(w, s.n_pad, K).reshape(s.n_pad, k, k, op.cin)[:s.n_count]
+                    w = torch.from_numpy(w.astype(np.float64)).permute(0, 3, 1, 2).contiguous()
+                    mult = torch.from_numpy(np.frombuffer(blob, dtype="<f4", count=s.n_count, offset=s.m_off).copy())
+                    acc = F.conv2d(xin.double(), w, None, stride=op.s, padding=k // 2)[0]          # exact integers
+                    y = (acc.float() * mult[:, None, None] + b[:, None, None]).double()              # fp32, as the kernel
+                else:
+                    w = np.frombuffer(blob, dtype=wdt, count=s.n_pad * K, offset=s.w_off)
+                    w = export.unpack_weights(w, s.n_pad, K).reshape(s.n_pad, k, k, op.cin)[:s.n_count]
+                    w = torch.from_numpy(w.astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+                    y = F.conv2d(real(op.src_buf, xin).float(), w, b, stride=op.s, padding=k // 2)[0].to(src.dtype)
                 if op.relu:
                     y = F.relu(y)
                 if op.res is not None:
-                    y = y + bufs[op.res.buf][op.res.coff:op.res.coff + s.n_count]
+                    r = bufs[op.res.buf][op.res.coff:op.res.coff + s.n_count]
+                    y = (y.float() + real(op.res.buf, r).float()).to(y.dtype)
                 if s.flags & export.SEG_PLANAR_F32:
-                    bufs[s.dst.buf][s.dst.coff:s.dst.coff + s.n_count] = y
+                    bufs[s.dst.buf][s.dst.coff:s.dst.coff + s.n_count] = y.float().to(y.dtype)
                     continue
-                y = q(y)
+                y = store(s.dst.buf, y)
                 if s.flags & export.SEG_UP2:
                     y = y.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
                 bufs[s.dst.buf][s.dst.coff:s.dst.coff + s.n_count] = y
         else:
             raise NotImplementedError(op.kind)
-    named = {builder.buffers[i][0]: t.numpy() for i, t in bufs.items()}
+    named = {builder.buffers[i][0]: t.float().numpy() for i, t in bufs.items()}
     outs = {n: named[n] for n in ("p2_cls", "p2_reg", "p3_cls", "p3_reg", "p4_cls", "p4_reg")}
     return outs, named
+
+
+def dequantised(builder: "export.EngineBuilder", named: dict) -> dict:
+    """{buffer name: real-valued ndarray} (int8 buffers multiplied by their scale)."""
+    out = {}
+    for name, h, w, c, dtype, flags, scale in builder.buffers:
+        out[name] = named[name] * scale if dtype == export.BUF_I8 else named[name]
+    return out

@@ -263,6 +263,60 @@ def test_fp32_engine_mini64_buffers(pkg, sd7, oracle_mod, oracle_sd7, torch_cuda
         e.close()
 
 
+# ---- INT8 engine (BASELINE config 3): per-tensor symmetric scales, own calibrator, reference carve-outs ----
+def test_int8_engine_matches_integer_emulation_and_reports_drift(pkg, sd7, oracle_mod, oracle_sd7, torch_cuda):
+    """(1) exactness: the HIP int8 path (v_mfma_i32_16x16x64_i8, fp32 per-channel multiplier, round-half-even
+    requantisation) against the torch-CPU integer emulation of the same op table at 128x128 -- int8 buffers must
+    agree code for code up to rare +-1 flips from fp32 FMA contraction; (2) calibrated drift vs the fp32 oracle at
+    640x640 (the reference pins no quantised result: parity unpinned)."""
+    from emulate import run_op_table, dequantised
+    from unina_yolo_dla_amd import export
+    from unina_yolo_dla_amd.engine import Engine, calibrate_amax
+    g = pkg.graph.Graph(in_h=128, in_w=128)
+    frames = [pkg.rng.frame(5000 + i, 128, 128) for i in range(4)]
+    amax = calibrate_amax(sd7, g, frames)
+    b8 = export.EngineBuilder(sd7, g, export.INT8, amax)
+    e = Engine.from_state_dict(sd7, g, precision=export.INT8, amax=amax)
+    try:
+        x = pkg.rng.frame(1234, 128, 128)
+        heads = e.forward(torch_cuda.from_numpy(x).cuda())
+        emu, named = run_op_table(b8, x)
+        real = dequantised(b8, named)
+        for bname in ("backbone.stage1_conv", "backbone.stage2_conv", "neck.cat_fpn1", "neck.cat_pan2", "p3_out", "p2_fused.q8"):
+            i = [bb[0] for bb in b8.buffers].index(bname)
+            scale = b8.buffers[i][6] if b8.buffers[i][4] == export.BUF_I8 else 1e-3
+            diff = np.abs(e.read_buffer(bname) - real[bname]) / scale
+            assert float((diff > 0.5).mean()) < 0.02 and diff.max() <= 2.5, (bname, float((diff > 0.5).mean()), float(diff.max()))
+        for n in pkg.graph.OUTPUT_NAMES:
+            assert float(np.sqrt(((heads[n] - emu[n]) ** 2).mean())) < 0.02, n
+    finally:
+        e.close()
+    # ---- drift at the benchmark size ----
+    frames = [pkg.rng.frame(5000 + i, 640, 640) for i in range(8)]
+    amax = calibrate_amax(sd7, None, frames)
+    e = Engine.from_state_dict(sd7, precision=export.INT8, amax=amax)
+    try:
+        x = pkg.rng.frame(1234, 640, 640)
+        got = e.infer(torch_cuda.from_numpy(x).cuda(), 0.5, 0.45, 0.1)
+        heads = {k: v[0].cpu().numpy() for k, v in e.outputs.items()}
+        o = oracle_mod.forward(oracle_sd7, x)
+        want, _ = oracle_mod.postprocess([o[n] for n in pkg.graph.OUTPUT_NAMES], 0.5, 0.45, 0.1)
+        for n in pkg.graph.OUTPUT_NAMES:
+            err = float(np.sqrt(((heads[n] - o[n]) ** 2).mean()))
+            assert err < 0.12 * max(float(o[n].std()), 0.3), (n, err)
+        from detcmp import iou_matrix
+        m = iou_matrix(got, want)
+        m = np.where(got["class_id"][:, None] == want["class_id"][None, :], m, 0.0)
+        j = m.argmax(1)
+        matched = m.max(1) > 0.5
+        print("INT8 drift: dets", len(got), "vs", len(want), "matched", int(matched.sum()),
+              "median IoU %.4f" % np.median(m.max(1)[matched]),
+              "median |dscore| %.4f" % np.median(np.abs(got["confidence"] - want["confidence"][j])[matched]))
+        assert matched.sum() >= 0.75 * len(want) and np.median(m.max(1)[matched]) > 0.9
+    finally:
+        e.close()
+
+
 def test_determinism_and_rebinding(pkg, eng640, torch_cuda):
     xs = [_frame(pkg, torch_cuda, s, 640) for s in (1, 2)]
     first = [eng640.infer(x).tobytes() for x in xs]

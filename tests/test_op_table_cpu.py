@@ -39,3 +39,31 @@ def test_lite_p2_op_table(pkg, oracle_mod):
     osd.close()
     for n in pkg.graph.OUTPUT_NAMES:
         np.testing.assert_allclose(outs[n], ref[n], atol=1.5e-2, rtol=0, err_msg=n)
+
+
+def test_int8_pass_structure_and_drift(pkg, sd7, oracle_mod, oracle_sd7):
+    """INT8 engine table on CPU: the reference's FP16 carve-outs are honoured (train.py:779), the buffer typing is
+    consistent, and the emulated integer arithmetic stays within PTQ-typical drift of the fp32 oracle."""
+    from unina_yolo_dla_amd import export
+    from emulate import run_op_table
+    g = pkg.graph.Graph(in_h=64, in_w=64)
+    b16 = export.EngineBuilder(sd7, g)
+    amax = export.calibrate(run_op_table(b16, pkg.rng.frame(5000 + i, 64, 64))[1] for i in range(4))
+    b8 = export.EngineBuilder(sd7, g, export.INT8, amax)
+    for op, q in zip(b8.ops, b8.op_int8):
+        if op.kind != export.OP_CONV:
+            continue
+        carve = any(sg.module.startswith(c) for sg in op.segs for c in export.INT8_CARVE_OUT)
+        final = any(sg.module.endswith(".2") for sg in op.segs)
+        assert q == (not carve and not final and op.cin % 64 == 0), op.name
+        src_dt = b8.buffers[op.src_buf][4]
+        assert src_dt == (export.BUF_I8 if q else export.BUF_F16), op.name        # int8 ops read int8, fp16 ops fp16
+    assert sum(b8.op_int8) == 40 and sum(o.kind == export.OP_QUANT for o in b8.ops) == 1
+    x = pkg.rng.frame(1234, 64, 64)
+    o8, _ = run_op_table(b8, x)
+    ref = oracle_mod.forward(oracle_sd7, x)
+    for n in pkg.graph.OUTPUT_NAMES:
+        err = float(np.sqrt(((o8[n] - ref[n]) ** 2).mean()))
+        assert err < 0.12 * max(float(ref[n].std()), 0.3), (n, err)                 # measured ~5 % of the logit std
+    with np.testing.assert_raises(ValueError):
+        export.EngineBuilder(sd7, g, export.INT8)                                    # no calibration -> refuse

@@ -57,46 +57,62 @@ __device__ __forceinline__ void stamp(const ConvParams& p, int k) {
 //   fp16: chunk = 8 k  -> block = 32 k, one v_mfma_f32_16x16x32_f16 per (A block, B block)
 //   fp32: chunk = 4 k  -> block = 16 k, four v_mfma_f32_16x16x4_f32 (exact fp32 products and accumulation);
 //         MFMA e takes element e of every lane's chunk, i.e. k = {4*lq + e}: A and B use the same k permutation.
+//   int8: chunk = 16 k -> block = 64 k, one v_mfma_i32_16x16x64_i8 (exact int32 accumulation)
+typedef int intx4 __attribute__((ext_vector_type(4)));
 template <typename T> struct Elem;
 template <> struct Elem<half_t> {
   static constexpr int kChunk = 8, kBlockK = 32;
   typedef half8 frag;
-  typedef half4 out4;
-  static __device__ __forceinline__ floatx4 mma(const frag& a, const frag& b, floatx4 c) {
+  typedef floatx4 acc_t;
+  static __device__ __forceinline__ acc_t mma(const frag& a, const frag& b, acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
   }
+  static __device__ __forceinline__ floatx4 to_float(const acc_t& c) { return c; }
 };
 template <> struct Elem<float> {
   static constexpr int kChunk = 4, kBlockK = 16;
   typedef floatx4_t frag;
-  typedef floatx4_t out4;
-  static __device__ __forceinline__ floatx4 mma(const frag& a, const frag& b, floatx4 c) {
+  typedef floatx4 acc_t;
+  static __device__ __forceinline__ acc_t mma(const frag& a, const frag& b, acc_t c) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
     return c;
+  }
+  static __device__ __forceinline__ floatx4 to_float(const acc_t& c) { return c; }
+};
+template <> struct Elem<signed char> {
+  static constexpr int kChunk = 16, kBlockK = 64;
+  typedef intx4 frag;
+  typedef intx4 acc_t;
+  static __device__ __forceinline__ acc_t mma(const frag& a, const frag& b, acc_t c) {
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ floatx4 to_float(const acc_t& c) {
+    return floatx4{(float)c[0], (float)c[1], (float)c[2], (float)c[3]};
   }
 };
 
 
 // ---- epilogue ------------------------------------------------------------------------------------------------
-// bias, ReLU, residual (after the ReLU: model.py:72-73) are applied in registers (one rounding). Then:
+// y = act( acc * mult[n] + bias[n] ) (+ residual, after the ReLU: model.py:72-73), all in fp32 registers:
+//   fp16 / fp32 engines : mult == nullptr (BatchNorm is folded into the weights)
+//   int8 convs          : acc is the exact int32 dot product, mult[n] = s_in * s_w * gamma/sqrt(var+eps)
+// The output type is a property of the DESTINATION buffer (per slice, run time): fp16, fp32 or int8 with
+// q = clamp(rne(y / s_out), -127, 127). Then:
 //  * NHWC outputs: the workgroup's BM x BN tile is staged through LDS ([pixel][BN] rows, 16-byte row padding against
 //    bank conflicts) and written back as FULL contiguous rows, 16 bytes per lane -- an accumulator fragment only
-//    holds 4 channels of a pixel per lane, and storing those directly costs 16 partial 32-byte line writes per
-//    wave-instruction (measured: up to 13 k cycles per workgroup). The folded nearest-x2 Upsample (model.py:145-147)
-//    writes each row to its 2x2 block.
+//    holds 4 channels of a pixel per lane. The folded nearest-x2 Upsample (model.py:145-147) writes each row to its
+//    2x2 block.
 //  * planar fp32 head outputs: lane = pixel already gives 64-byte contiguous runs per channel: stored directly.
 // pix_to_m(pl) maps a workgroup-local pixel to the row-major output pixel index, or -1 outside the image.
 template <typename T, int BM, int BN, int WM_T, int WN_T, typename PixToM>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg& sg, floatx4 (&acc)[WN_T][WM_T],
-                                              int wm, int wn, int nb0, int l15, int lq, PixToM pix_to_m,
-                                              unsigned char* stage) {
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg& sg,
+                                              typename Elem<T>::acc_t (&acc)[WN_T][WM_T], int wm, int wn, int nb0,
+                                              int l15, int lq, PixToM pix_to_m, unsigned char* stage) {
   typedef Elem<T> E;
-  typedef typename E::out4 out4;
-  constexpr int ESZ = sizeof(T);
-  constexpr int ROWB = BN * ESZ + 16;          // padded LDS row (bytes)
-  constexpr int CPR = BN * ESZ / 16;           // 16-byte chunks per pixel row
-  constexpr int EPC = 16 / ESZ;                // elements per chunk
+  const int od = sg.out_dtype;
+  const int esz = od == kF32 ? 4 : (od == kF16 ? 2 : 1);
+  const int rowb = BN * esz + 16;              // padded LDS row (bytes)
   const int n_w0 = wn * (WN_T * 16);           // tile-local first channel of this wave
   const bool planar = sg.dst_planar != nullptr;
   if (!planar) __syncthreads();                // every wave is done reading the operand buffers: reuse them
@@ -106,52 +122,78 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg
     const int n = nb0 + nl;                    // slice-relative
     if (n >= sg.n_count) continue;
     const floatx4 bias = *reinterpret_cast<const floatx4*>(sg.bias + n);
+    floatx4 mult = {1.f, 1.f, 1.f, 1.f};
+    if (sg.mult) mult = *reinterpret_cast<const floatx4*>(sg.mult + n);
 #pragma unroll
     for (int i = 0; i < WM_T; ++i) {
       const int pl = (wm * WM_T + i) * 16 + l15;
       const int m = pix_to_m(pl);
       if (m < 0) continue;
-      floatx4 v = acc[j][i] + bias;
+      floatx4 v = E::to_float(acc[j][i]);
+      if (sg.mult) v = v * mult;
+      v = v + bias;
       if (p.relu) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
       }
       if (p.res) {
-        const out4 rv = *reinterpret_cast<const out4*>(static_cast<const T*>(p.res) + (size_t)m * p.res_ld + n);
+        const size_t ro = (size_t)m * p.res_ld + n;
+        if (p.res_dtype == kF16) {
+          const half4 rv = *reinterpret_cast<const half4*>(static_cast<const half_t*>(p.res) + ro);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        } else if (p.res_dtype == kF32) {
+          v = v + *reinterpret_cast<const floatx4*>(static_cast<const float*>(p.res) + ro);
+        } else {
+          const int rv = *reinterpret_cast<const int*>(static_cast<const signed char*>(p.res) + ro);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)(signed char)(rv >> (8 * r)) * p.res_scale;
+        }
       }
       if (planar) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (n + r < sg.n_count) sg.dst_planar[(size_t)(n + r) * p.M + m] = v[r];
-      } else {
-        out4 hv;
+      } else if (od == kF16) {
+        half4 hv;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hv[r] = (T)v[r];
-        *reinterpret_cast<out4*>(stage + pl * ROWB + nl * ESZ) = hv;
+        for (int r = 0; r < 4; ++r) hv[r] = (half_t)v[r];
+        *reinterpret_cast<half4*>(stage + pl * rowb + nl * 2) = hv;
+      } else if (od == kF32) {
+        *reinterpret_cast<floatx4*>(stage + pl * rowb + nl * 4) = v;
+      } else {
+        unsigned int q = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t = __builtin_rintf(v[r] * sg.out_inv_scale);  // round half to even
+          t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
+          q |= ((unsigned int)(int)t & 0xFFu) << (8 * r);
+        }
+        *reinterpret_cast<unsigned int*>(stage + pl * rowb + nl) = q;
       }
     }
   }
   if (planar) return;
   __syncthreads();
   typedef float vec16 __attribute__((ext_vector_type(4)));  // 16 opaque bytes
-  T* dst = static_cast<T*>(sg.dst);
-  for (int c = threadIdx.x; c < BM * CPR; c += 256) {
-    const int pl = c / CPR, ch = c - pl * CPR;
-    const int n = nb0 + ch * EPC;
+  unsigned char* dst = static_cast<unsigned char*>(sg.dst);
+  const int cpr = BN * esz / 16, epc = 16 / esz;  // 16-byte chunks per pixel row, elements per chunk
+  for (int c = threadIdx.x; c < BM * cpr; c += 256) {
+    const int pl = c / cpr, ch = c - pl * cpr;
+    const int n = nb0 + ch * epc;
     const int m = pix_to_m(pl);
     if (m < 0 || n >= sg.n_count) continue;
-    const vec16 v = *reinterpret_cast<const vec16*>(stage + pl * ROWB + ch * 16);
+    const vec16 v = *reinterpret_cast<const vec16*>(stage + pl * rowb + ch * 16);
     if (sg.up2) {
       const int oy = m / p.Wo, ox = m - oy * p.Wo;
-      T* d = dst + ((size_t)(2 * oy) * (2 * p.Wo) + 2 * ox) * sg.dst_ld + n;
+      unsigned char* d = dst + (((size_t)(2 * oy) * (2 * p.Wo) + 2 * ox) * sg.dst_ld + n) * esz;
+      const size_t px = (size_t)sg.dst_ld * esz, row = (size_t)(2 * p.Wo) * px;
       *reinterpret_cast<vec16*>(d) = v;
-      *reinterpret_cast<vec16*>(d + sg.dst_ld) = v;
-      *reinterpret_cast<vec16*>(d + (size_t)(2 * p.Wo) * sg.dst_ld) = v;
-      *reinterpret_cast<vec16*>(d + (size_t)(2 * p.Wo + 1) * sg.dst_ld) = v;
+      *reinterpret_cast<vec16*>(d + px) = v;
+      *reinterpret_cast<vec16*>(d + row) = v;
+      *reinterpret_cast<vec16*>(d + row + px) = v;
     } else {
-      *reinterpret_cast<vec16*>(dst + (size_t)m * sg.dst_ld + n) = v;
+      *reinterpret_cast<vec16*>(dst + ((size_t)m * sg.dst_ld + n) * esz) = v;
     }
   }
 }
@@ -255,11 +297,11 @@ __global__ __launch_bounds__(256) void conv_glds(const ConvParams p) {
     }
   };
 
-  floatx4 acc[WN_T][WM_T];
+  typename E::acc_t acc[WN_T][WM_T];
 #pragma unroll
   for (int j = 0; j < WN_T; ++j)
 #pragma unroll
-    for (int i = 0; i < WM_T; ++i) acc[j][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < WM_T; ++i) acc[j][i] = typename E::acc_t{0, 0, 0, 0};
 
   // ---- software pipeline ----------------------------------------------------------------------------------
   // LDS-DMA ring: STAGES buffers, stage kt lives in buffer kt % STAGES; steps past the end are all-zero dummies so
@@ -421,11 +463,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
     const int pix = (wm * WM_T + i) * 16 + l15;
     h00[i] = (pix / TW) * HW_ + (pix % TW);
   }
-  floatx4 acc[WN_T][WM_T];
+  typename E::acc_t acc[WN_T][WM_T];
 #pragma unroll
   for (int j = 0; j < WN_T; ++j)
 #pragma unroll
-    for (int i = 0; i < WM_T; ++i) acc[j][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < WM_T; ++i) acc[j][i] = typename E::acc_t{0, 0, 0, 0};
 
   // ---- software pipeline (see conv_glds): weights ring + register double buffer; B fragments come from the patch ----
   static_assert(STAGES >= 3, "ring depth");
@@ -522,7 +564,7 @@ constexpr size_t smem_of() {
 
 // [dtype][config]; BK is in fp16-equivalent k (KSUB = BK/32 fragment blocks): a K-step covers BK channels in fp16
 // and BK/2 channels in fp32.
-const CfgInfo kCfg[2][kCfgCount] = {
+const CfgInfo kCfg[3][kCfgCount] = {
     {
         CFG(half_t, "f16", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
         CFG(half_t, "f16", 64, 64, 32, 2, 2, 4),    // kCfg64x64k32
@@ -583,12 +625,43 @@ const CfgInfo kCfg[2][kCfgCount] = {
         CFG(float, "f32", 32, 64, 128, 1, 4, 4),
         CFG(float, "f32", 64, 64, 128, 2, 2, 4),
     },
+    {
+        CFG(signed char, "i8", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
+        CFG(signed char, "i8", 64, 64, 32, 2, 2, 4),    // kCfg64x64k32
+        CFG(signed char, "i8", 128, 64, 64, 2, 2, 4),   // kCfg128x64k64
+        CFG(signed char, "i8", 128, 64, 32, 2, 2, 4),   // kCfg128x64k32
+        CFG(signed char, "i8", 128, 128, 64, 2, 2, 4),  // kCfg128x128k64
+        CFG(signed char, "i8", 128, 32, 64, 4, 1, 4),   // kCfg128x32k64
+        CFG(signed char, "i8", 128, 32, 32, 4, 1, 4),   // kCfg128x32k32
+        CFG(signed char, "i8", 128, 16, 64, 4, 1, 4),   // kCfg128x16k64
+        CFG(signed char, "i8", 32, 64, 64, 1, 4, 4),    // kCfg32x64k64
+        CFG(signed char, "i8", 32, 64, 64, 1, 4, 8),    // kCfg32x64k64s8  (deep pipeline for latency-bound small grids)
+        CFG(signed char, "i8", 64, 64, 64, 2, 2, 6),    // kCfg64x64k64s6
+        HALO(signed char, "i8", 8, 8, 64, 64, 2, 2, 4),   // kCfgHalo8x8n64
+        HALO(signed char, "i8", 8, 8, 32, 64, 4, 1, 4),   // kCfgHalo8x8n32
+        HALO(signed char, "i8", 8, 16, 64, 64, 2, 2, 4),  // kCfgHalo8x16n64
+        HALO(signed char, "i8", 8, 16, 32, 64, 4, 1, 4),  // kCfgHalo8x16n32
+        HALO(signed char, "i8", 8, 8, 64, 32, 2, 2, 4),   // kCfgHalo8x8n64k32
+        HALO(signed char, "i8", 8, 16, 32, 32, 4, 1, 4),  // kCfgHalo8x16n32k32
+        HALO(signed char, "i8", 16, 16, 64, 64, 2, 2, 4), // kCfgHalo16x16n64   (wave tile 128 px x 32 ch)
+        HALO(signed char, "i8", 16, 16, 32, 64, 4, 1, 4), // kCfgHalo16x16n32   (wave tile 64 px x 32 ch)
+        HALO(signed char, "i8", 8, 16, 64, 64, 4, 1, 4),  // kCfgHalo8x16n64w41 (wave tile 32 px x 64 ch)
+        HALO(signed char, "i8", 8, 8, 64, 64, 4, 1, 4),   // kCfgHalo8x8n64w41  (wave tile 16 px x 64 ch)
+        HALO(signed char, "i8", 8, 8, 32, 128, 4, 1, 4),  // kCfgHalo8x8n32k128   (K-step 128 channels)
+        HALO(signed char, "i8", 8, 8, 32, 256, 4, 1, 4),  // kCfgHalo8x8n32k256
+        HALO(signed char, "i8", 8, 8, 64, 128, 2, 2, 4),  // kCfgHalo8x8n64k128
+        HALO(signed char, "i8", 8, 16, 32, 128, 4, 1, 4), // kCfgHalo8x16n32k128
+        HALO(signed char, "i8", 8, 16, 64, 128, 2, 2, 4), // kCfgHalo8x16n64k128
+        CFG(signed char, "i8", 32, 64, 128, 1, 4, 4),     // kCfg32x64k128
+        CFG(signed char, "i8", 64, 64, 128, 2, 2, 4),     // kCfg64x64k128
+    },
 };
 #undef CFG
 #undef HALO
 
-inline int kstep_of(const ConvParams& p, const CfgInfo& c) { return (c.bk / 32) * (p.dtype == kF32 ? 16 : 32); }
-inline size_t esize(const ConvParams& p) { return p.dtype == kF32 ? 4 : 2; }
+inline int block_k(int dtype) { return dtype == kF32 ? 16 : (dtype == kI8 ? 64 : 32); }
+inline int kstep_of(const ConvParams& p, const CfgInfo& c) { return (c.bk / 32) * block_k(p.dtype); }
+inline size_t esize(const ConvParams& p) { return p.dtype == kF32 ? 4 : (p.dtype == kI8 ? 1 : 2); }
 inline size_t smem_for(const ConvParams& p, const CfgInfo& c) {
   if (!c.th) return c.smem;
   const size_t patch = (size_t)(c.th + 2) * (c.tw + 2) * p.Cin * esize(p);
@@ -605,7 +678,7 @@ int n_tiles(const ConvParams& p, int bn) {
 }  // namespace
 
 hipError_t conv_init() {
-  for (int d = 0; d < 2; ++d)
+  for (int d = 0; d < 3; ++d)
     for (int c = 0; c < kCfgCount; ++c) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kCfg[d][c].fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(kCfg[d][c].th ? kMaxLds : kCfg[d][c].smem));
@@ -619,7 +692,7 @@ bool conv_config_valid(const ConvParams& p, int cfg) {
   const CfgInfo& c = kCfg[p.dtype][cfg];
   if (p.Cin % kstep_of(p, c)) return false;
   if (c.th) {  // halo kernel: 3x3, stride 1, pad 1, power-of-two chunk count, patch + ring must fit the CU's LDS
-    const int nch = p.Cin / (p.dtype == kF32 ? 4 : 8);
+    const int nch = (int)(p.Cin * esize(p) / 16);
     if (p.ksize != 3 || p.stride != 1 || p.pad != 1 || (nch & (nch - 1)) || smem_for(p, c) > kMaxLds) return false;
   }
   int min_npad = 1 << 30;
@@ -645,7 +718,7 @@ ConvLaunch conv_plan_with(const ConvParams& p, int cfg) {
 ConvLaunch conv_plan(const ConvParams& p) {
   const int override_cfg = p.force_cfg;
   if (override_cfg >= 0 && conv_config_valid(p, override_cfg)) return conv_plan_with(p, override_cfg);
-  const bool k64 = (p.Cin % (p.dtype == kF32 ? 32 : 64)) == 0;
+  const bool k64 = (p.Cin % (2 * block_k(p.dtype))) == 0;
   int min_npad = 1 << 30;
   for (int s = 0; s < p.nseg; ++s) {
     const int np = (p.seg[s].n_count + 15) & ~15;
@@ -679,7 +752,7 @@ hipError_t conv_launch(const ConvParams& pin, const ConvLaunch& l, hipStream_t s
 }
 
 const char* conv_config_name(int cfg, int dtype) {
-  return (cfg >= 0 && cfg < kCfgCount && (dtype == kF16 || dtype == kF32)) ? kCfg[dtype][cfg].name : "?";
+  return (cfg >= 0 && cfg < kCfgCount && dtype >= 0 && dtype < 3) ? kCfg[dtype][cfg].name : "?";
 }
 
 }  // namespace unina

@@ -37,6 +37,7 @@ struct PlannedOp {
   ConvLaunch cl;
   StemParams sp;
   PoolParams pp;
+  QuantParams qp;
   unina_op_info info;
 };
 
@@ -101,8 +102,14 @@ int fail(unina_engine* e, int code, const char* fmt, ...) {
 
 size_t buffer_bytes(const BufferDesc& d) {
   const size_t n = (size_t)d.h * d.w * d.c;
-  return d.dtype == kBufF16Nhwc ? n * 2 : n * 4;
+  return d.dtype == kBufF16Nhwc ? n * 2 : (d.dtype == kBufI8Nhwc ? n : n * 4);
 }
+
+// element type of an NHWC activation buffer (-1: not an activation buffer)
+int act_dtype_of(uint32_t buf_dtype) {
+  return buf_dtype == kBufF16Nhwc ? kF16 : (buf_dtype == kBufF32Nhwc ? kF32 : (buf_dtype == kBufI8Nhwc ? kI8 : -1));
+}
+size_t dtype_size(int dt) { return dt == kF32 ? 4 : (dt == kI8 ? 1 : 2); }
 
 int engine_dtype(const unina_engine* e);
 
@@ -115,12 +122,11 @@ void drop_graph(unina_engine* e) {
 
 int engine_dtype(const unina_engine* e) { return e->h.precision == kFp32 ? kF32 : kF16; }
 
-// (Re)computes kernel parameters from the current buffer addresses.
+// (Re)computes kernel parameters from the current buffer addresses. Element types are properties of the BUFFERS
+// (fp16 / fp32 / int8 NHWC): a conv runs in the type of its source buffer and converts to the type of each
+// destination buffer in its epilogue, so fp16, fp32 and mixed int8/fp16 engines share one planner.
 int plan(unina_engine* e) {
   const char* blob = static_cast<const char*>(e->d_blob);
-  const int dt = engine_dtype(e);
-  const size_t esz = dt == kF32 ? 4 : 2;
-  const uint32_t act_dtype = dt == kF32 ? kBufF32Nhwc : kBufF16Nhwc;
   for (size_t i = 0; i < e->ops.size(); ++i) {
     PlannedOp& op = e->ops[i];
     const OpDesc& d = op.d;
@@ -132,8 +138,10 @@ int plan(unina_engine* e) {
     if (d.kind == kOpConv) {
       ConvParams& p = op.cp;
       memset(&p, 0, sizeof p);
+      const int dt = act_dtype_of(src.d.dtype);
+      if (dt < 0) return fail(e, UNINA_ERR_FORMAT, "op %zu: source is not an activation buffer", i);
+      const size_t esz = dtype_size(dt);
       p.dtype = dt;
-      if (src.d.dtype != act_dtype) return fail(e, UNINA_ERR_FORMAT, "op %zu: source buffer dtype does not match the engine precision", i);
       p.src = src.ptr;
       p.src_ld = (int)src.d.c;
       p.H = (int)d.in_h; p.W = (int)d.in_w; p.Cin = (int)d.cin;
@@ -142,8 +150,12 @@ int plan(unina_engine* e) {
       p.relu = (int)d.relu;
       if (d.res_buf >= 0) {
         const Buffer& rb = e->bufs[d.res_buf];
-        p.res = static_cast<const char*>(rb.ptr) + (size_t)d.res_coff * esz;
+        const int rdt = act_dtype_of(rb.d.dtype);
+        if (rdt < 0) return fail(e, UNINA_ERR_FORMAT, "op %zu: residual is not an activation buffer", i);
+        p.res = static_cast<const char*>(rb.ptr) + (size_t)d.res_coff * dtype_size(rdt);
         p.res_ld = (int)rb.d.c;
+        p.res_dtype = rdt;
+        p.res_scale = rb.d.scale;
       }
       p.nseg = (int)d.nseg;
       p.zeros = e->d_zeros;
@@ -156,6 +168,8 @@ int plan(unina_engine* e) {
         ConvSeg& cs = p.seg[s];
         cs.w = blob + sd.w_off;
         cs.bias = reinterpret_cast<const float*>(blob + sd.b_off);
+        cs.mult = sd.m_off ? reinterpret_cast<const float*>(blob + sd.m_off) : nullptr;
+        if (dt == kI8 && !cs.mult) return fail(e, UNINA_ERR_FORMAT, "op %zu: int8 conv without multipliers", i);
         cs.src_coff = (int)sd.src_coff;
         cs.n_count = (int)sd.n_count;
         cs.up2 = (sd.flags & kSegUp2) ? 1 : 0;
@@ -164,18 +178,24 @@ int plan(unina_engine* e) {
           cs.dst_planar = static_cast<float*>(db.ptr);
           cs.dst = nullptr;
           cs.dst_ld = 0;
+          cs.out_dtype = kF32;
           out_bytes += 4.0 * sd.n_count * p.M;
         } else {
-          if (db.d.dtype != act_dtype || sd.n_count % 8 || sd.dst_coff % 8 || db.d.c % 8)
-            return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: NHWC slice needs channel counts/offsets that are multiples of 8", i);
-          cs.dst = static_cast<char*>(db.ptr) + (size_t)sd.dst_coff * esz;
+          const int odt = act_dtype_of(db.d.dtype);
+          const uint32_t al = odt == kI8 ? 16 : 8;   // a 16-byte store chunk must not straddle the slice
+          if (odt < 0 || sd.n_count % al || sd.dst_coff % al || db.d.c % al)
+            return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: NHWC slice needs channel counts/offsets that are multiples of %u", i, al);
+          cs.dst = static_cast<char*>(db.ptr) + (size_t)sd.dst_coff * dtype_size(odt);
           cs.dst_planar = nullptr;
           cs.dst_ld = (int)db.d.c;
-          out_bytes += (double)esz * sd.n_count * p.M * (cs.up2 ? 4 : 1);
+          cs.out_dtype = odt;
+          cs.out_inv_scale = odt == kI8 ? 1.0f / db.d.scale : 1.0f;
+          out_bytes += (double)dtype_size(odt) * sd.n_count * p.M * (cs.up2 ? 4 : 1);
         }
         ntot += (int)sd.n_count;
       }
-      if (p.Cin % 32 || p.src_ld % 8) return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu (%s): Cin %% 32 != 0", i, d.name);
+      const int kb = dt == kF32 ? 16 : (dt == kI8 ? 64 : 32);
+      if (p.Cin % kb || (p.src_ld * esz) % 16) return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu (%s): Cin %% %d != 0", i, d.name, kb);
       if (p.force_cfg >= 0 && !conv_config_valid(p, p.force_cfg)) p.force_cfg = -1;
       op.cl = conv_plan(p);
       const int K = p.ksize * p.ksize * p.Cin;
@@ -184,7 +204,7 @@ int plan(unina_engine* e) {
       // algorithmic bytes: each distinct input element once, weights once, outputs once, residual once
       const bool shared_src = p.nseg == 1 || d.seg[0].src_coff == d.seg[1].src_coff;
       info.bytes = (double)esz * p.H * p.W * p.Cin * (shared_src ? 1 : p.nseg) + (double)esz * ntot * K + 4.0 * ntot + out_bytes +
-                   (p.res ? (double)esz * p.M * ntot : 0.0);
+                   (p.res ? (double)dtype_size(p.res_dtype) * p.M * ntot : 0.0);
       snprintf(info.kernel, sizeof info.kernel, "%s", op.cl.kernel_name);
       info.grid = (int)(op.cl.grid.x * op.cl.grid.y);
       info.block = (int)op.cl.block.x;
@@ -192,27 +212,44 @@ int plan(unina_engine* e) {
       const SegDesc& sd = d.seg[0];
       const Buffer& db = e->bufs[sd.dst_buf];
       StemParams& p = op.sp;
-      p.dtype = dt;
+      const int odt = act_dtype_of(db.d.dtype);
+      if (odt != kF16 && odt != kF32) return fail(e, UNINA_ERR_UNSUPPORTED, "stem output must be fp16 or fp32");
+      p.dtype = odt;
       p.src = static_cast<const float*>(src.ptr);
       p.w = reinterpret_cast<const float*>(blob + sd.w_off);
       p.bias = reinterpret_cast<const float*>(blob + sd.b_off);
-      p.dst = static_cast<char*>(db.ptr) + (size_t)sd.dst_coff * esz;
+      p.dst = static_cast<char*>(db.ptr) + (size_t)sd.dst_coff * dtype_size(odt);
       p.H = (int)d.in_h; p.W = (int)d.in_w; p.Ho = (int)d.out_h; p.Wo = (int)d.out_w;
       p.Co = (int)sd.n_count; p.dst_ld = (int)db.d.c;
       info.m = p.Ho * p.Wo; info.n = p.Co; info.k = 27;
       info.flops = 2.0 * info.m * info.n * 27;
-      info.bytes = 4.0 * 3 * p.H * p.W + (double)esz * info.m * p.Co;
-      snprintf(info.kernel, sizeof info.kernel, "stem_conv_kernel<%s,%d>", dt == kF32 ? "f32" : "f16", p.Co);
+      info.bytes = 4.0 * 3 * p.H * p.W + (double)dtype_size(odt) * info.m * p.Co;
+      snprintf(info.kernel, sizeof info.kernel, "stem_conv_kernel<%s,%d>", odt == kF32 ? "f32" : "f16", p.Co);
       info.grid = (info.m + 255) / 256;
       info.block = 256;
     } else if (d.kind == kOpSppfPool) {
       PoolParams& p = op.pp;
+      const int dt = act_dtype_of(src.d.dtype);
+      if (dt < 0) return fail(e, UNINA_ERR_FORMAT, "op %zu: pool on a non-activation buffer", i);
       p.dtype = dt;
       p.buf = src.ptr;
       p.H = (int)d.in_h; p.W = (int)d.in_w; p.C = (int)d.cin; p.ld = (int)src.d.c; p.coff = (int)d.seg[0].src_coff;
-      info.bytes = (double)esz * p.H * p.W * p.C * 4;
-      snprintf(info.kernel, sizeof info.kernel, "sppf_pool_kernel<%s,32>", dt == kF32 ? "f32" : "f16");
+      info.bytes = (double)dtype_size(dt) * p.H * p.W * p.C * 4;
+      snprintf(info.kernel, sizeof info.kernel, "sppf_pool_kernel<%s,32>", dt == kF32 ? "f32" : (dt == kI8 ? "i8" : "f16"));
       info.grid = p.H * (p.C / 32);
+      info.block = 256;
+    } else if (d.kind == kOpQuant) {
+      const Buffer& db = e->bufs[d.seg[0].dst_buf];
+      if (src.d.dtype != kBufF16Nhwc || db.d.dtype != kBufI8Nhwc || src.d.c != db.d.c || src.d.h != db.d.h || src.d.w != db.d.w)
+        return fail(e, UNINA_ERR_FORMAT, "op %zu: QUANT needs an fp16 source and an int8 twin of the same shape", i);
+      QuantParams& p = op.qp;
+      p.src = static_cast<const half_t*>(src.ptr);
+      p.dst = static_cast<signed char*>(db.ptr);
+      p.n = (size_t)src.d.h * src.d.w * src.d.c;
+      p.inv_scale = 1.0f / db.d.scale;
+      info.bytes = 3.0 * p.n;
+      snprintf(info.kernel, sizeof info.kernel, "quant_f16_i8_kernel");
+      info.grid = (int)((p.n / 16 + 255) / 256);
       info.block = 256;
     } else {
       return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: kind %u not executable", i, d.kind);
@@ -229,6 +266,7 @@ hipError_t launch_op(unina_engine* e, size_t i, hipStream_t s) {
     case kOpConv: return conv_launch(op.cp, op.cl, s);
     case kOpStem: return stem_launch(op.sp, s);
     case kOpSppfPool: return sppf_pool_launch(op.pp, s);
+    case kOpQuant: return quant_launch(op.qp, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -431,7 +469,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   if (fread(&e->h, sizeof e->h, 1, f) != 1) return bail(UNINA_ERR_FORMAT, "truncated header");
   if (memcmp(e->h.magic, kMagic, 8)) return bail(UNINA_ERR_FORMAT, "bad magic (not a UNINAENG file)");
   if (e->h.version != kVersion) return bail(UNINA_ERR_FORMAT, "unsupported engine file version");
-  if (e->h.precision != kFp16 && e->h.precision != kFp32) return bail(UNINA_ERR_UNSUPPORTED, "this build executes fp16 and fp32 engines (no int8 yet)");
+  if (e->h.precision != kFp16 && e->h.precision != kFp32 && e->h.precision != kInt8) return bail(UNINA_ERR_UNSUPPORTED, "unknown engine precision");
   if (e->h.n_heads != 3 || e->h.n_buffers == 0 || e->h.n_buffers > 4096 || e->h.n_ops == 0 || e->h.n_ops > 4096)
     return bail(UNINA_ERR_FORMAT, "implausible table sizes");
   e->bufs.resize(e->h.n_buffers);
@@ -454,7 +492,9 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
       const SegDesc& sd = o.d.seg[s];
       if (sd.dst_buf >= e->h.n_buffers) return bail(UNINA_ERR_FORMAT, "op table: bad destination buffer");
       if (o.d.kind == kOpConv) {
-        const uint64_t wbytes = (uint64_t)sd.n_pad * o.d.ksize * o.d.ksize * o.d.cin * (e->h.precision == kFp32 ? 4 : 2);
+        const uint32_t sdt = e->bufs[o.d.src_buf].d.dtype;
+        const uint64_t wbytes = (uint64_t)sd.n_pad * o.d.ksize * o.d.ksize * o.d.cin * (sdt == kBufF32Nhwc ? 4 : (sdt == kBufI8Nhwc ? 1 : 2));
+        if (sd.m_off && (sd.m_off + (uint64_t)sd.n_pad * 4 > e->h.blob_bytes || sd.m_off % 16)) return bail(UNINA_ERR_FORMAT, "op table: multiplier offset outside blob");
         if (sd.w_off + wbytes > e->h.blob_bytes || sd.b_off + (uint64_t)sd.n_pad * 4 > e->h.blob_bytes || sd.w_off % 16 || sd.b_off % 16)
           return bail(UNINA_ERR_FORMAT, "op table: weight offset outside blob");
         const BufferDesc& sb = e->bufs[o.d.src_buf].d;
@@ -776,7 +816,13 @@ int unina_debug_read_buffer(unina_engine_t* e, const char* name, float* host_out
   if (w) *w = (int)b.d.w;
   if (capacity < n) return fail(e, UNINA_ERR_ARG, "buffer '%s' needs %zu floats", name, n);  // dims are still reported
   HIPCHK(e, hipDeviceSynchronize());
-  if (b.d.dtype == kBufF32Nhwc) {
+  if (b.d.dtype == kBufI8Nhwc) {  // returned as real values (code * scale)
+    std::vector<signed char> tmp(n);
+    HIPCHK(e, hipMemcpy(tmp.data(), b.ptr, n, hipMemcpyDeviceToHost));
+    const size_t hw = (size_t)b.d.h * b.d.w;
+    for (size_t p = 0; p < hw; ++p)
+      for (size_t ch = 0; ch < b.d.c; ++ch) host_out[ch * hw + p] = (float)tmp[p * b.d.c + ch] * b.d.scale;
+  } else if (b.d.dtype == kBufF32Nhwc) {
     std::vector<float> tmp(n);
     HIPCHK(e, hipMemcpy(tmp.data(), b.ptr, n * 4, hipMemcpyDeviceToHost));
     const size_t hw = (size_t)b.d.h * b.d.w;

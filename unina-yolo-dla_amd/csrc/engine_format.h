@@ -9,12 +9,12 @@
 namespace unina {
 
 constexpr char kMagic[8] = {'U', 'N', 'I', 'N', 'A', 'E', 'N', 'G'};
-constexpr uint32_t kVersion = 2;  // 2: conv weights stored as swizzled 1-KiB fragment blocks
+constexpr uint32_t kVersion = 3;  // 2: packed fragment-block weights; 3: buffer scales, per-channel multipliers, QUANT op (int8)
 
 enum Precision : uint32_t { kFp16 = 0, kInt8 = 1, kFp32 = 2 };
 enum BufDtype : uint32_t { kBufF16Nhwc = 0, kBufF32Planar = 1, kBufF32NchwInput = 2, kBufI8Nhwc = 3, kBufF32Nhwc = 4 };
 enum BufFlags : uint32_t { kBufInput = 1, kBufOutput = 2 };
-enum OpKind : uint32_t { kOpConv = 1, kOpStem = 2, kOpSppfPool = 3, kOpUpsample = 4 };
+enum OpKind : uint32_t { kOpConv = 1, kOpStem = 2, kOpSppfPool = 3, kOpUpsample = 4, kOpQuant = 5 };
 enum SegFlags : uint32_t { kSegUp2 = 1, kSegPlanarF32 = 2 };
 
 #pragma pack(push, 1)
@@ -37,7 +37,8 @@ struct BufferDesc {          // 64 bytes
   uint32_t h, w, c;
   uint32_t dtype;
   uint32_t flags;
-  char name[44];
+  char name[40];
+  float scale;               // int8 buffers: real value = code * scale (per-tensor symmetric); 1.0 otherwise
 };
 static_assert(sizeof(BufferDesc) == 64, "BufferDesc");
 
@@ -50,8 +51,9 @@ struct SegDesc {             // 64 bytes: one slice of an op's output-channel (N
   uint64_t w_off;            // blob offset: conv: fp16 fragment blocks [n_pad/16][K/32][64][8], K = (kh,kw,cin) (export.py pack_weights);
                              //              stem: fp32 [n][27] ordered (c,kh,kw)
   uint64_t b_off;            // blob offset: fp32 [n_pad] folded bias
-  float w_scale, out_scale;  // int8 engines only
-  uint8_t reserved[16];
+  float w_scale, out_scale;  // int8 engines only (informational; the kernels use m_off / the buffer scale)
+  uint64_t m_off;            // int8 convs: blob offset of fp32 [n_pad] multipliers s_in*s_w*bn_scale; 0 = none
+  uint8_t reserved[8];
 };
 static_assert(sizeof(SegDesc) == 64, "SegDesc");
 

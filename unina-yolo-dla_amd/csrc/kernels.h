@@ -8,7 +8,7 @@
 namespace unina {
 
 typedef _Float16 half_t;
-enum DType : int { kF16 = 0, kF32 = 1 };   // element type of activations + weights of an engine (accumulation is always fp32)
+enum DType : int { kF16 = 0, kF32 = 1, kI8 = 2 };   // element types (accumulation: fp32 for f16/f32 inputs, int32 for int8)
 
 // ------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution  D[cout][pixel] = sum_k W[cout][k] * X[pixel][k]   (+bias, ReLU, +residual)
@@ -26,10 +26,13 @@ struct ConvSeg {
   int dst_ld;          // channels per pixel of the destination buffer
   int up2;             // 1: write every output pixel to its 2x2 block of a (2Ho x 2Wo) destination
   int tile0;           // first N-tile (blockIdx.y) that belongs to this slice
+  int out_dtype;       // DType of dst (property of the destination buffer)
+  float out_inv_scale; // int8 destinations: 1 / s_out
+  const float* mult;   // int8 convs: per-channel s_in*s_w*bn_scale applied to the int32 accumulator; nullptr otherwise
 };
 
 struct ConvParams {
-  int dtype;           // DType of src / weights / dst / res
+  int dtype;           // DType of src and weights (kernel instantiation)
   const void* src;
   int src_ld;          // channels per pixel of the source buffer
   int H, W, Cin;       // input spatial size, input channels of each slice
@@ -38,6 +41,8 @@ struct ConvParams {
   int relu;
   const void* res;     // residual (added after ReLU), channel offset applied; nullptr = none
   int res_ld;
+  int res_dtype;       // DType of the residual buffer
+  float res_scale;     // int8 residual: s_res
   int nseg;
   ConvSeg seg[2];
   const void* zeros;   // >= 16 bytes of zeros in HBM: source of out-of-image taps / tile tails
@@ -91,6 +96,15 @@ struct PoolParams {
   int H, W, C, ld, coff;
 };
 hipError_t sppf_pool_launch(const PoolParams& p, hipStream_t stream, dim3* grid_out = nullptr, dim3* block_out = nullptr);
+
+// fp16 -> int8 re-quantisation of a whole NHWC buffer (int8 engines: tensors with both fp16 and int8 consumers)
+struct QuantParams {
+  const half_t* src;
+  signed char* dst;
+  size_t n;            // elements (multiple of 16)
+  float inv_scale;
+};
+hipError_t quant_launch(const QuantParams& p, hipStream_t stream);
 
 // Standalone nearest x2 upsample into a channel slice (the graph folds this into the producer conv; kept for
 // op tables that cannot fold it and for tests).

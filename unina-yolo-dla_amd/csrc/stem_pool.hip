@@ -99,6 +99,12 @@ template <> struct PoolVec<float> {
   static __device__ __forceinline__ float lowest() { return -3.402823466e38f; }
 };
 
+template <> struct PoolVec<signed char> {
+  static constexpr int V = 16;
+  typedef signed char vec __attribute__((ext_vector_type(16)));
+  static __device__ __forceinline__ signed char lowest() { return -128; }
+};
+
 template <typename T, int CH>  // CH channels per block (multiple of the 16-byte vector width)
 __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolParams p) {
   typedef PoolVec<T> PV;
@@ -162,13 +168,42 @@ hipError_t sppf_pool_launch(const PoolParams& p, hipStream_t stream, dim3* grid_
   constexpr int CH = 32;
   if (p.C % CH) return hipErrorInvalidValue;
   dim3 grid(p.H, p.C / CH), block(256);
-  const size_t esz = p.dtype == kF32 ? 4 : 2;
+  const size_t esz = p.dtype == kF32 ? 4 : (p.dtype == kI8 ? 1 : 2);
   const size_t smem = (size_t)3 * p.W * CH * esz;
   if (smem > 64 * 1024) return hipErrorInvalidValue;
   if (grid_out) *grid_out = grid;
   if (block_out) *block_out = block;
   if (p.dtype == kF32) sppf_pool_kernel<float, CH><<<grid, block, smem, stream>>>(p);
+  else if (p.dtype == kI8) sppf_pool_kernel<signed char, CH><<<grid, block, smem, stream>>>(p);  // one scale per buffer: max commutes with it
   else sppf_pool_kernel<half_t, CH><<<grid, block, smem, stream>>>(p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- quantise
+__global__ __launch_bounds__(256) void quant_f16_i8_kernel(const QuantParams p) {
+  typedef signed char c16 __attribute__((ext_vector_type(16)));
+  const size_t nvec = p.n / 16;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nvec; t += (size_t)gridDim.x * blockDim.x) {
+    const half8 a = *reinterpret_cast<const half8*>(p.src + t * 16);
+    const half8 b = *reinterpret_cast<const half8*>(p.src + t * 16 + 8);
+    c16 q;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float x = __builtin_rintf((float)a[i] * p.inv_scale), y = __builtin_rintf((float)b[i] * p.inv_scale);
+      x = x > 127.f ? 127.f : (x < -127.f ? -127.f : x);
+      y = y > 127.f ? 127.f : (y < -127.f ? -127.f : y);
+      q[i] = (signed char)(int)x;
+      q[i + 8] = (signed char)(int)y;
+    }
+    *reinterpret_cast<c16*>(p.dst + t * 16) = q;
+  }
+}
+
+hipError_t quant_launch(const QuantParams& p, hipStream_t stream) {
+  if (p.n % 16) return hipErrorInvalidValue;
+  size_t blocks = (p.n / 16 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  quant_f16_i8_kernel<<<(int)blocks, 256, 0, stream>>>(p);
   return hipGetLastError();
 }
 

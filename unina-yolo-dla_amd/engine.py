@@ -135,17 +135,19 @@ class Engine:
     # -- construction helpers -------------------------------------------------------------------------
     @classmethod
     def from_state_dict(cls, sd: Dict[str, np.ndarray], graph: Optional[Graph] = None, device: int = 0,
-                        path: Optional[str] = None, precision: int = _export.FP16) -> "Engine":
-        """export_trt.py's role + load: folds/fuses `sd` into an engine file (temporary unless `path`) and loads it."""
+                        path: Optional[str] = None, precision: int = _export.FP16,
+                        amax: Optional[Dict[str, float]] = None) -> "Engine":
+        """export_trt.py's role + load: folds/fuses `sd` into an engine file (temporary unless `path`) and loads it.
+        INT8 needs `amax` (calibrate_amax below)."""
         if path is None:
             fd, tmp = tempfile.mkstemp(suffix=".une")
             os.close(fd)
             try:
-                _export.export_engine(sd, tmp, graph, precision)
+                _export.export_engine(sd, tmp, graph, precision, amax)
                 return cls(tmp, device)
             finally:
                 os.unlink(tmp)
-        _export.export_engine(sd, path, graph, precision)
+        _export.export_engine(sd, path, graph, precision, amax)
         return cls(path, device)
 
     def _check(self, rc: int):
@@ -302,3 +304,22 @@ class Engine:
         self._check(self.L.unina_debug_read_buffer(self.h, name.encode(), out.ctypes.data, out.size, C.byref(c),
                                                    C.byref(h), C.byref(w)))
         return out.reshape(c.value, h.value, w.value)
+
+
+def calibrate_amax(sd: Dict[str, np.ndarray], graph: Optional[Graph], frames, device: int = 0,
+                   percentile: Optional[float] = None) -> Dict[str, float]:
+    """INT8 calibration on the GPU (the role of qat.py:171-220 `calibrate_model`, 30 batches in train.py:809): runs the
+    fp16 engine over `frames` (iterable of [1,3,H,W] fp32 ndarrays) and records, per activation buffer, the
+    (percentile of the) absolute maximum. Feed the result to from_state_dict(..., precision=INT8, amax=...)."""
+    torch = _torch()
+    b = _export.EngineBuilder(sd, graph)
+    names = [n for (n, _h, _w, _c, dtype, _f, _s) in b.buffers if dtype == _export.BUF_F16]
+    eng = Engine.from_state_dict(sd, graph, device)
+    try:
+        def per_frame():
+            for x in frames:
+                eng.forward(torch.from_numpy(np.ascontiguousarray(x)).cuda(device))
+                yield {n: eng.read_buffer(n) for n in names}
+        return _export.calibrate(per_frame(), percentile)
+    finally:
+        eng.close()

@@ -29,17 +29,17 @@ import numpy as np
 from .graph import Graph, OUTPUT_NAMES, STRIDES
 
 MAGIC = b"UNINAENG"
-VERSION = 2
+VERSION = 3
 FP16, INT8, FP32 = 0, 1, 2
 BUF_F16, BUF_F32_PLANAR, BUF_F32_NCHW_IN, BUF_I8, BUF_F32_NHWC = 0, 1, 2, 3, 4
 BUF_INPUT, BUF_OUTPUT = 1, 2
-OP_CONV, OP_STEM, OP_SPPF_POOL, OP_UPSAMPLE = 1, 2, 3, 4
+OP_CONV, OP_STEM, OP_SPPF_POOL, OP_UPSAMPLE, OP_QUANT = 1, 2, 3, 4, 5
 SEG_UP2, SEG_PLANAR_F32 = 1, 2
 BN_EPS = 1e-5
 
 _HDR = struct.Struct("<8sII3II2II3IQQ56x")
-_BUF = struct.Struct("<3III44s")
-_SEG = struct.Struct("<6IQQff16x")
+_BUF = struct.Struct("<3III40sf")
+_SEG = struct.Struct("<6IQQffQ8x")
 _OP_HEAD = struct.Struct("<4I2I2iI4If")
 assert _HDR.size == 128 and _BUF.size == 64 and _SEG.size == 64 and _OP_HEAD.size == 56
 
@@ -61,6 +61,13 @@ class Seg:
     w_off: int = 0
     b_off: int = 0
     n_pad: int = 0
+    # raw parameters (filled by the emitters, serialised by EngineBuilder._finalize)
+    w_raw: Optional[np.ndarray] = None      # [n, K] fp64, K = (kh,kw,cin), UNFOLDED conv weight
+    fold: Optional[np.ndarray] = None       # [n] fp64: gamma/sqrt(var+eps) (1 for convs without BN)
+    bias: Optional[np.ndarray] = None       # [n] fp64: beta - mean*fold (or the conv bias)
+    bn: bool = True
+    m_off: int = 0                          # int8 convs: blob offset of the per-channel multiplier
+    w_scale: float = 1.0
 
 
 @dataclass
@@ -109,38 +116,62 @@ def unpack_weights(packed: np.ndarray, n_pad: int, K: int) -> np.ndarray:
     return np.ascontiguousarray(out.transpose(0, 2, 1, 3, 4)).reshape(n_pad, K)
 
 
-def fold_bn(sd: Dict[str, np.ndarray], module: str):
-    """ConvBlock -> (W' [O,C,k,k] fp64, b' [O] fp64)."""
+def bn_terms(sd: Dict[str, np.ndarray], module: str):
+    """ConvBlock -> (W [O,C,k,k] fp64 unfolded, f [O] = gamma/sqrt(var+eps), b' [O] = beta - mean*f)."""
     w = sd[f"{module}.conv.weight"].astype(np.float64)
     g = sd[f"{module}.bn.weight"].astype(np.float64)
     b = sd[f"{module}.bn.bias"].astype(np.float64)
     m = sd[f"{module}.bn.running_mean"].astype(np.float64)
     v = sd[f"{module}.bn.running_var"].astype(np.float64)
     f = g / np.sqrt(v + BN_EPS)
-    return w * f[:, None, None, None], b - m * f
+    return w, f, b - m * f
+
+
+def fold_bn(sd: Dict[str, np.ndarray], module: str):
+    """ConvBlock -> (W' [O,C,k,k] fp64, b' [O] fp64)."""
+    w, f, b = bn_terms(sd, module)
+    return w * f[:, None, None, None], b
+
+
+# FP16 carve-outs of the reference's QAT recipe (train.py:779, qat.py:700-753): module-path prefixes kept in float
+INT8_CARVE_OUT = ("backbone.stem", "backbone.stage1_conv", "head_p2")
+
+
+def quantize_sym(x: np.ndarray, scale: float) -> np.ndarray:
+    """Per-tensor symmetric int8: clamp(round_half_even(x / scale), -127, 127)   (qat.py:91-126: num_bits=8, axis=None)."""
+    return np.clip(np.rint(x / scale), -127, 127).astype(np.int8)
 
 
 class EngineBuilder:
-    def __init__(self, sd: Dict[str, np.ndarray], graph: Optional[Graph] = None, precision: int = FP16):
-        """precision: FP16 (fp16 weights + activations, v_mfma_f32_16x16x32_f16) or FP32 (fp32 everywhere,
-        v_mfma_f32_16x16x4_f32: meets the north-star tolerance outright at 1/16 of the fp16 matrix rate)."""
-        if precision not in (FP16, FP32):
-            raise NotImplementedError("precision must be FP16 or FP32 (INT8: not built yet)")
+    def __init__(self, sd: Dict[str, np.ndarray], graph: Optional[Graph] = None, precision: int = FP16,
+                 amax: Optional[Dict[str, float]] = None):
+        """precision: FP16 (fp16 weights + activations, v_mfma_f32_16x16x32_f16), FP32 (fp32 everywhere,
+        v_mfma_f32_16x16x4_f32: meets the north-star tolerance outright at 1/16 of the fp16 matrix rate), or INT8
+        (per-tensor symmetric int8 activations AND weights as in qat.py:91-126, v_mfma_i32_16x16x64_i8, with the
+        reference's FP16 carve-outs; needs `amax`: buffer name -> calibrated |activation| maximum, see calibrate())."""
+        if precision not in (FP16, FP32, INT8):
+            raise NotImplementedError("precision must be FP16, FP32 or INT8")
+        if precision == INT8 and amax is None:
+            raise ValueError("INT8 needs calibrated activation ranges (amax): run export.calibrate() first")
         self.sd = sd
         self.precision = precision
+        self.amax = amax
         self.wdtype = np.float32 if precision == FP32 else np.float16
         self.act_dtype = BUF_F32_NHWC if precision == FP32 else BUF_F16
         self.g = graph or Graph()
         if self.g.base_channels % 32:
             raise NotImplementedError("engine kernels need Cin % 32 == 0 beyond the stem (base_channels multiple of 32)")
-        self.buffers: List[Tuple[str, int, int, int, int, int]] = []   # name,h,w,c,dtype,flags
+        self.buffers: List[list] = []   # [name, h, w, c, dtype, flags, scale]
         self.ops: List[Op] = []
         self.blob = bytearray()
         self._lower()
+        if precision == INT8:
+            self._quantize_pass()
+        self._finalize()
 
     # ---- tables -------------------------------------------------------------------------------
     def buf(self, name: str, h: int, w: int, c: int, dtype: Optional[int] = None, flags: int = 0) -> int:
-        self.buffers.append((name, h, w, c, self.act_dtype if dtype is None else dtype, flags))
+        self.buffers.append([name, h, w, c, self.act_dtype if dtype is None else dtype, flags, 1.0])
         return len(self.buffers) - 1
 
     def view(self, name: str, h: int, w: int, c: int) -> View:
@@ -166,23 +197,21 @@ class EngineBuilder:
         op = Op(OP_CONV, "+".join(m for m, *_ in items), src_buf, cin, k, s, int(relu), res, (ih, iw), (oh, ow))
         for module, src_coff, dst, flags in items:
             if bn:
-                w, b = fold_bn(self.sd, module)
+                w, f, b = bn_terms(self.sd, module)
             else:
                 w = self.sd[f"{module}.weight"].astype(np.float64)
                 b = self.sd[f"{module}.bias"].astype(np.float64)
+                f = np.ones_like(b)
             n = w.shape[0]
             assert w.shape[1] == cin and w.shape[2] == k, (module, w.shape, cin, k)
-            n_pad = -(-n // 16) * 16
-            wk = np.zeros((n_pad, k, k, cin), dtype=self.wdtype)
-            wk[:n] = np.transpose(w, (0, 2, 3, 1)).astype(self.wdtype)      # [O][kh][kw][C]: K = (kh,kw,cin)
-            bk = np.zeros((n_pad,), dtype=np.float32)
-            bk[:n] = b.astype(np.float32)
             dh, dw = self._hw(dst.buf)
             want = (2 * oh, 2 * ow) if flags & SEG_UP2 else (oh, ow)
             assert (dh, dw) == want, (module, (dh, dw), want)
             assert dst.c == n, (module, dst.c, n)
-            op.segs.append(Seg(module, src_coff, n, dst, flags,
-                               self._blob_add(pack_weights(wk.reshape(n_pad, k * k * cin))), self._blob_add(bk), n_pad))
+            seg = Seg(module, src_coff, n, dst, flags, n_pad=-(-n // 16) * 16)
+            seg.w_raw = np.transpose(w, (0, 2, 3, 1)).reshape(n, k * k * cin)      # [O][(kh,kw,C)]
+            seg.fold, seg.bias, seg.bn = f, b, bn
+            op.segs.append(seg)
         self.ops.append(op)
 
     def c3k2(self, name: str, src: View, dst: View, n: int):
@@ -240,9 +269,9 @@ class EngineBuilder:
         stem = self.view("backbone.stem", H // 2, W // 2, c1)
         w, b = fold_bn(self.sd, "backbone.stem")
         op = Op(OP_STEM, "backbone.stem", images, 3, 3, 2, 1, None, (H, W), (H // 2, W // 2))
-        op.segs.append(Seg("backbone.stem", 0, c1, stem, 0,
-                           self._blob_add(w.astype(np.float32).reshape(c1, 27)),      # [O][(c,kh,kw)] fp32
-                           self._blob_add(b.astype(np.float32)), c1))
+        seg = Seg("backbone.stem", 0, c1, stem, 0, n_pad=c1)
+        seg.w_raw, seg.fold, seg.bias = w.reshape(c1, 27), np.ones(c1), b      # stem: folded fp32 [O][(c,kh,kw)]
+        op.segs.append(seg)
         self.ops.append(op)
         s1 = self.view("backbone.stage1_conv", H // 4, W // 4, c2)
         self.conv([("backbone.stage1_conv", 0, s1, 0)], stem.buf, c1, 3, 2)
@@ -285,23 +314,115 @@ class EngineBuilder:
         self.head("head_p3", p3_out, outs["p3_cls"], outs["p3_reg"])
         self.head("head_p4", p4_out, outs["p4_cls"], outs["p4_reg"])
 
+    # ---- INT8 pass (generic over the op table) ----------------------------------------------------
+    def _quantize_pass(self):
+        """Decides, per op, int8 or fp16 execution and, per buffer, int8 or fp16 storage.
+
+        * an op runs in int8 iff it is a BN conv of a module outside the reference's FP16 carve-outs
+          (train.py:779) whose Cin is a multiple of the int8 MFMA block (64). The head's output convs are plain
+          nn.Conv2d in the reference's QAT graph (qat.py:416,421: unquantised) -> fp16.
+        * a buffer is int8 iff every op that reads it as an INPUT is int8 (the SPPF pool is type-agnostic); a
+          buffer with mixed readers stays fp16 and gets an int8 twin filled by one QUANT op.
+        * scales: activations s = amax/127 per BUFFER (a concat buffer has one scale: its consumer conv has one
+          input quantizer, qat.py:245-248); weights s_w = max|W|/127 per conv on the UNFOLDED weight (BN stays a
+          float per-channel multiplier, qat.py:225-260)."""
+        def seg_q(seg):
+            return seg.bn and not any(seg.module.startswith(c) for c in INT8_CARVE_OUT)
+        self.op_int8 = [op.kind == OP_CONV and op.cin % 64 == 0 and all(seg_q(sg) for sg in op.segs) for op in self.ops]
+        nbuf = len(self.buffers)
+        readers = {b: [] for b in range(nbuf)}
+        for i, op in enumerate(self.ops):
+            if op.kind == OP_CONV:
+                readers[op.src_buf].append(i)
+        new_ops: List[Op] = []
+        twin_of: Dict[int, int] = {}
+        for b in range(nbuf):
+            name, h, w, c, dtype, flags, _ = self.buffers[b]
+            if dtype != BUF_F16 or not readers[b]:
+                continue
+            qs = [self.op_int8[i] for i in readers[b]]
+            if all(qs):
+                self.buffers[b][4] = BUF_I8
+                self.buffers[b][6] = self._scale_of(name)
+            elif any(qs):                                   # mixed readers: int8 twin
+                t = self.buf(name + ".q8", h, w, c, BUF_I8)
+                self.buffers[t][6] = self._scale_of(name)
+                twin_of[b] = t
+        # re-point int8 readers to the twins and schedule the QUANT ops after the last writer of the original
+        for b, t in twin_of.items():
+            for i in readers[b]:
+                if self.op_int8[i]:
+                    self.ops[i].src_buf = t
+        last_writer = {}
+        for i, op in enumerate(self.ops):
+            for sg in op.segs:
+                if sg.dst.buf in twin_of:
+                    last_writer[sg.dst.buf] = i
+        out_ops, out_q = [], []
+        for i, op in enumerate(self.ops):
+            out_ops.append(op)
+            out_q.append(self.op_int8[i])
+            for b, t in twin_of.items():
+                if last_writer.get(b) == i:
+                    name, h, w, c = self.buffers[b][:4]
+                    q = Op(OP_QUANT, f"quant({name})", b, c, 1, 1, 0, None, (h, w), (h, w))
+                    q.segs.append(Seg("quant", 0, c, View(t, 0, c)))
+                    out_ops.append(q)
+                    out_q.append(False)
+        self.ops, self.op_int8 = out_ops, out_q
+
+    def _scale_of(self, buffer_name: str) -> float:
+        if buffer_name not in self.amax:
+            raise KeyError(f"no calibrated range for buffer '{buffer_name}'")
+        return max(float(self.amax[buffer_name]), 1e-8) / 127.0
+
+    # ---- blob -----------------------------------------------------------------------------------
+    def _finalize(self):
+        for i, op in enumerate(self.ops):
+            if op.kind == OP_STEM:
+                sg = op.segs[0]
+                sg.w_off = self._blob_add(sg.w_raw.astype(np.float32))
+                sg.b_off = self._blob_add(sg.bias.astype(np.float32))
+            if op.kind != OP_CONV:
+                continue
+            int8 = self.precision == INT8 and self.op_int8[i]
+            in_scale = self.buffers[op.src_buf][6]
+            for sg in op.segs:
+                K = sg.w_raw.shape[1]
+                bk = np.zeros((sg.n_pad,), dtype=np.float32)
+                bk[:sg.n_count] = sg.bias.astype(np.float32)
+                if int8:
+                    sg.w_scale = max(float(np.abs(sg.w_raw).max()), 1e-12) / 127.0
+                    wk = np.zeros((sg.n_pad, K), dtype=np.int8)
+                    wk[:sg.n_count] = quantize_sym(sg.w_raw, sg.w_scale)
+                    mk = np.zeros((sg.n_pad,), dtype=np.float32)
+                    mk[:sg.n_count] = (in_scale * sg.w_scale * sg.fold).astype(np.float32)
+                    sg.w_off = self._blob_add(pack_weights(wk))
+                    sg.m_off = self._blob_add(mk)
+                else:
+                    wk = np.zeros((sg.n_pad, K), dtype=self.wdtype)
+                    wk[:sg.n_count] = (sg.w_raw * sg.fold[:, None]).astype(self.wdtype)
+                    sg.w_off = self._blob_add(pack_weights(wk))
+                sg.b_off = self._blob_add(bk)
+
     # ---- serialisation --------------------------------------------------------------------------
     def tobytes(self) -> bytes:
         g = self.g
         out = bytearray()
         out += _HDR.pack(MAGIC, VERSION, self.precision, 3, g.in_h, g.in_w, g.num_classes, len(self.buffers), len(self.ops),
                          3, *STRIDES, len(self.blob), g.macs())
-        for name, h, w, c, dtype, flags in self.buffers:
-            out += _BUF.pack(h, w, c, dtype, flags, name.encode()[:43])
+        for name, h, w, c, dtype, flags, scale in self.buffers:
+            out += _BUF.pack(h, w, c, dtype, flags, name.encode()[:39], scale)
         for op in self.ops:
             rec = bytearray(_OP_HEAD.pack(op.kind, op.k, op.s, op.relu, op.src_buf, op.cin,
                                           op.res.buf if op.res else -1, op.res.coff if op.res else 0,
-                                          len(op.segs), op.in_hw[0], op.in_hw[1], op.out_hw[0], op.out_hw[1], 1.0))
+                                          len(op.segs), op.in_hw[0], op.in_hw[1], op.out_hw[0], op.out_hw[1],
+                                          float(self.buffers[op.src_buf][6])))
             for i in range(2):
                 if i < len(op.segs):
                     s = op.segs[i]
                     rec += _SEG.pack(s.src_coff, s.n_count, s.n_pad, s.dst.buf, s.dst.coff, s.flags,
-                                     s.w_off, s.b_off, 1.0, 1.0)
+                                     s.w_off, s.b_off, s.w_scale, float(self.buffers[s.dst.buf][6]), s.m_off)
                 else:
                     rec += b"\0" * _SEG.size
             rec += op.name.encode()[:71].ljust(72, b"\0")
@@ -315,10 +436,25 @@ class EngineBuilder:
             f.write(self.tobytes())
 
 
+def calibrate(named_buffers_per_frame, percentile: Optional[float] = None) -> Dict[str, float]:
+    """The build's own activation calibrator (the reference's lives in NVIDIA pytorch-quantization, qat.py:129-220,
+    which is not available: parity unpinned). Input: an iterable of {buffer name: ndarray} (one dict per
+    calibration frame, e.g. Engine.read_buffer() of an fp16/fp32 engine, or tests/emulate.py on CPU). Output:
+    {buffer name: amax}; amax = max |x| over all frames, or, with `percentile` (e.g. 99.99), the max over frames of
+    that percentile of |x| (a histogram-style clip of outliers)."""
+    amax: Dict[str, float] = {}
+    for named in named_buffers_per_frame:
+        for name, arr in named.items():
+            a = np.abs(np.asarray(arr, dtype=np.float32))
+            v = float(a.max()) if percentile is None else float(np.percentile(a, percentile))
+            amax[name] = max(amax.get(name, 0.0), v)
+    return amax
+
+
 def export_engine(sd: Dict[str, np.ndarray], path: str, graph: Optional[Graph] = None,
-                  precision: int = FP16) -> EngineBuilder:
+                  precision: int = FP16, amax: Optional[Dict[str, float]] = None) -> EngineBuilder:
     """state_dict (reference key names) -> engine file. Returns the builder (op table for inspection)."""
-    b = EngineBuilder(sd, graph, precision)
+    b = EngineBuilder(sd, graph, precision, amax)
     b.save(path)
     return b
 
