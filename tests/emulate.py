@@ -68,7 +68,8 @@ def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = Tr
                     w = torch.from_numpy(w.astype(np.float64)).permute(0, 3, 1, 2).contiguous()
                     mult = torch.from_numpy(np.frombuffer(blob, dtype="<f4", count=s.n_count, offset=s.m_off).copy())
                     acc = F.conv2d(xin.double(), w, None, stride=op.s, padding=k // 2)[0]          # exact integers
-                    y = (acc.float() * mult[:, None, None] + b[:, None, None]).double()              # fp32, as the kernel
+                    # kernel: fmaf(acc, mult, bias) -> one fp32 rounding; the product is exact in fp64 (|acc| < 2^26)
+                    y = (acc * mult.double()[:, None, None] + b.double()[:, None, None]).float().double()
                 else:
                     w = np.frombuffer(blob, dtype=wdt, count=s.n_pad * K, offset=s.w_off)
                     w = export.unpack_weights(w, s.n_pad, K).reshape(s.n_pad, k, k, op.cin)[:s.n_count]
@@ -78,7 +79,10 @@ def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = Tr
                     y = F.relu(y)
                 if op.res is not None:
                     r = bufs[op.res.buf][op.res.coff:op.res.coff + s.n_count]
-                    y = (y.float() + real(op.res.buf, r).float()).to(y.dtype)
+                    if bdtype[op.res.buf] == export.BUF_I8:      # kernel: fmaf(code, s_res, y)
+                        y = (y.double() + r.double() * float(np.float32(bscale[op.res.buf]))).float().to(y.dtype)
+                    else:
+                        y = (y.float() + r.float()).to(y.dtype)
                 if s.flags & export.SEG_PLANAR_F32:
                     bufs[s.dst.buf][s.dst.coff:s.dst.coff + s.n_count] = y.float().to(y.dtype)
                     continue

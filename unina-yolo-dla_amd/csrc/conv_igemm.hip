@@ -130,8 +130,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg
       const int m = pix_to_m(pl);
       if (m < 0) continue;
       floatx4 v = E::to_float(acc[j][i]);
-      if (sg.mult) v = v * mult;
-      v = v + bias;
+      if (sg.mult) {  // one rounding: fma(acc, mult, bias) -- the integer emulation in tests/emulate.py does the same
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], mult[r], bias[r]);
+      } else {
+        v = v + bias;
+      }
       if (p.relu) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
@@ -147,7 +151,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg
         } else {
           const int rv = *reinterpret_cast<const int*>(static_cast<const signed char*>(p.res) + ro);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)(signed char)(rv >> (8 * r)) * p.res_scale;
+          for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf((float)(signed char)(rv >> (8 * r)), p.res_scale, v[r]);
         }
       }
       if (planar) {
