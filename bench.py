@@ -33,6 +33,7 @@ import numpy as np  # noqa: E402
 FLOPS_PER_FRAME = {640: 35_664_691_200, 1280: 142_658_764_800}   # SURVEY.md section 8d (2 x MACs, conv only)
 PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "i8": 5000.0}   # dense; int8 = 2x the fp16 matrix rate (MI355X_MICROARCH.md)                                     # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")   # tools/pmc_traffic.sh (rocprofv3 --pmc passes)
 N_FRAMES = 16            # distinct synthetic frames cycled through
 IN_FLIGHT = int(os.environ.get("UNINA_IN_FLIGHT", "2"))   # engine handles per GPU = frames in flight
 GATHER_EVERY = 16        # frames per RCCL all-gather of detection slots
@@ -158,7 +159,8 @@ def main():
             "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 3),
             "flops_per_launch": dom["flops"] / dom["launches"],
             "achieved": round(achieved_tf, 2), "peak": PEAK_TFLOPS[dname], "unit": "TFLOP/s",
-            "frac": round(achieved_tf / PEAK_TFLOPS[dname], 4), "traffic": None,
+            "frac": round(achieved_tf / PEAK_TFLOPS[dname], 4), "traffic": pmc_traffic(dom_name),
+            "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
             "algorithmic_gbs": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
             "sum_of_ops_ms": round(total_ms, 4),
             "whole_frame_tflops": round(fps / world * FLOPS_PER_FRAME.get(S, 0) / 1e12, 2),
@@ -190,6 +192,28 @@ def main():
         dist.destroy_process_group()
     if line is not None:
         print(json.dumps(line))
+
+
+def mangled(kernel: str) -> str:
+    """display name 'conv_glds<f16,32,64,64,1,4,4>' -> the Itanium-mangled symbol rocprofv3 reports."""
+    import re
+    m = re.match(r"(\w+)<(\w+),(.*)>", kernel)
+    if not m:
+        return kernel
+    fn, ty, rest = m.groups()
+    code = {"f16": "DF16_", "f32": "f", "i8": "a"}[ty]
+    nums = [n for part in rest.split(",") for n in part.split("x")]
+    return f"_ZN5unina{len(fn)}{fn}I{code}" + "".join(f"Li{n}E" for n in nums) + "EEvNS_10ConvParamsE"
+
+
+def pmc_traffic(kernel: str):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary (FETCH_SIZE x2 + WRITE_SIZE,
+    MI355X_MICROARCH.md HBM section), or None."""
+    try:
+        with open(PMC_TRAFFIC) as f:
+            return json.load(f).get(mangled(kernel), {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(u, sd, S, conf, budget_s):

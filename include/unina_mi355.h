@@ -176,6 +176,29 @@ hipError_t run_gpu_nms(GpuDetection *d_detections, int num_detections, float iou
 hipError_t copy_valid_detections_to_host(const GpuDetection *d_detections, GpuDetection *h_detections,
                                          int num_detections, int *out_valid_count, hipStream_t stream);
 
+/* ------------------------------------------------------------------ pre-process C API (cuda_preprocess.h:50-112)
+ * The step right before the engine in processGpuBuffer (perception_node.cpp:601-604): camera buffer -> fp32 RGB
+ * planar "images" tensor. Same names, argument order and error behaviour as the reference (allocators and the
+ * stream factory return NULL on failure, cuda_preprocess.cu:395-428); arithmetic per cuda_preprocess.cu:99-253. */
+typedef struct {
+  float mean_r, mean_g, mean_b;
+  float std_r, std_g, std_b;
+} NormParams; /* cuda_preprocess.h:38-45 */
+
+NormParams create_norm_params_imagenet(void);
+NormParams create_norm_params(float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b);
+hipError_t preprocess_bgra_resize(const uint8_t *d_input, float *d_output, int src_width, int src_height,
+                                  int src_pitch, int dst_width, int dst_height, NormParams params,
+                                  hipStream_t stream);
+hipError_t preprocess_bgra(const uint8_t *d_input, float *d_output, int width, int height, int pitch,
+                           NormParams params, hipStream_t stream);
+hipError_t preprocess_nv12(const uint8_t *d_y_plane, const uint8_t *d_uv_plane, float *d_output, int width,
+                           int height, int y_pitch, int uv_pitch, NormParams params, hipStream_t stream);
+float *allocate_preprocess_buffer(int width, int height);
+void free_preprocess_buffer(float *d_buffer);
+hipStream_t create_preprocess_stream(void);
+void destroy_preprocess_stream(hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

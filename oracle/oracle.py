@@ -18,7 +18,8 @@ _REF_PATH = os.path.join(_HERE, "_ref", "libref_postprocess.so")
 
 
 def build(force: bool = False) -> None:
-    srcs = [os.path.join(_HERE, f) for f in ("unina_oracle.c", "postprocess_oracle.c", "unina_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("unina_oracle.c", "postprocess_oracle.c", "preprocess_oracle.c",
+                                             "unina_oracle.h", "Makefile")]
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if stale:
@@ -173,3 +174,40 @@ def ref_postprocess(heads, conf_thr=0.5, iou_thr=0.45, conformal_q=0.1, strides=
     k = R.ref_postprocess(ptrs, gw, gh, st, arrs[0].shape[0], conf_thr, iou_thr, conformal_q, out.ctypes.data,
                           len(out), C.byref(ncand))
     return out[:k].copy(), ncand.value
+
+
+class Norm(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("mean_r", "mean_g", "mean_b", "std_r", "std_g", "std_b")]
+
+
+IMAGENET = (0.485, 0.456, 0.406, 0.229, 0.224, 0.225)
+
+
+def preprocess_bgra(img: np.ndarray, norm=IMAGENET, dst_hw=None) -> np.ndarray:
+    """img: [H, pitch_bytes] or [H, W, 4] uint8 BGRA. Returns [3, h, w] fp32 (cuda_preprocess.cu:99-128 / :144-204)."""
+    L = lib()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape[0], img.shape[1] if img.ndim == 3 else img.shape[1] // 4
+    pitch = img.strides[0]
+    n = Norm(*norm)
+    if dst_hw is None:
+        out = np.empty((3, h, w), dtype=np.float32)
+        L.uo_preprocess_bgra(img.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), w, h, pitch, C.byref(n))
+    else:
+        dh, dw = dst_hw
+        out = np.empty((3, dh, dw), dtype=np.float32)
+        L.uo_preprocess_bgra_resize(img.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), w, h, pitch, dw, dh, C.byref(n))
+    return out
+
+
+def preprocess_nv12(y: np.ndarray, uv: np.ndarray, norm=IMAGENET) -> np.ndarray:
+    """y: [H, W] uint8, uv: [H/2, W] uint8 interleaved U,V (cuda_preprocess.cu:212-253)."""
+    L = lib()
+    y = np.ascontiguousarray(y, dtype=np.uint8)
+    uv = np.ascontiguousarray(uv, dtype=np.uint8)
+    h, w = y.shape
+    out = np.empty((3, h, w), dtype=np.float32)
+    n = Norm(*norm)
+    L.uo_preprocess_nv12(y.ctypes.data_as(C.c_void_p), uv.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), w, h,
+                         y.strides[0], uv.strides[0], C.byref(n))
+    return out

@@ -154,7 +154,8 @@ def main():
     with open(os.path.join(GOLD, "small_object_metric_example.json"), "w") as f:
         json.dump({"source": "unina_yolo_dla/data_loader.py:427-436",
                    "image_size": 640, "small_threshold_px": 15, "iou_threshold": 0.5,
-                   "preds": [[0.51, 0.51, 0.012, 0.022, 0.95, 0]], "targets": [[0, 0.5, 0.5, 0.01, 0.02]],
+                   "preds": [[0.51, 0.51, 0.012, 0.022, 0.95, 0]],
+                   "targets": [[0, 0.5, 0.5, 0.01, 0.02], [1, 0.2, 0.3, 0.05, 0.08]],
                    "expected": {"tp": 0, "fp": 1, "fn": 1, "iou": 0.0243}}, f, indent=1)
     print("done")
 

@@ -24,7 +24,10 @@ def _declared_functions():
     names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{]*\)\s*;", text)
     return sorted(set(n for n in names if n.startswith("unina_") or n in (
         "init_postprocess_resources", "cleanup_postprocess_resources", "reset_detection_counter",
-        "get_detection_count", "decode_yolo_head", "run_gpu_nms", "copy_valid_detections_to_host")))
+        "get_detection_count", "decode_yolo_head", "run_gpu_nms", "copy_valid_detections_to_host",
+        "create_norm_params_imagenet", "create_norm_params", "preprocess_bgra_resize", "preprocess_bgra",
+        "preprocess_nv12", "allocate_preprocess_buffer", "free_preprocess_buffer", "create_preprocess_stream",
+        "destroy_preprocess_stream")))
 
 
 def test_header_and_library_agree(lib):

@@ -4,6 +4,6 @@ Host-side mirror of the reference interfaces for that path only:
 graph (model.py) -> export (export_trt.py role) -> engine (TensorRTEngine +
 gpu_postprocess.h roles behind the C ABI in include/unina_mi355.h).
 """
-from . import gather, graph, rng, statedict, synth  # noqa: F401
+from . import gather, graph, metrics, rng, statedict, synth  # noqa: F401
 
-__all__ = ["gather", "graph", "rng", "statedict", "synth"]
+__all__ = ["gather", "graph", "metrics", "rng", "statedict", "synth"]

@@ -22,6 +22,7 @@ UNITS = {
     "conv_igemm.hip": [],
     "stem_pool.hip": [],
     "postprocess.hip": ["-ffp-contract=off"],   # box arithmetic must round like the reference's scalar code
+    "preprocess.hip": ["-ffp-contract=off"],    # normalisation arithmetic rounds as written (oracle/preprocess_oracle.c)
     "engine.hip": [],
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result"]

@@ -33,6 +33,10 @@ class OpInfo(C.Structure):
                 ("k", C.c_int), ("flops", C.c_double), ("bytes", C.c_double), ("grid", C.c_int), ("block", C.c_int)]
 
 
+class NormParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("mean_r", "mean_g", "mean_b", "std_r", "std_g", "std_b")]
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -45,6 +49,8 @@ ABI_SYMBOLS = [
     "unina_tensor_address", "unina_enqueue", "unina_infer", "unina_infer_async", "unina_postprocess_async",
     "unina_last_error", "unina_op_count", "unina_get_op_info", "unina_profile_ops", "unina_debug_read_buffer",
     "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune", "unina_debug_post_stamps", "unina_debug_conv_stamps",
+    "create_norm_params_imagenet", "create_norm_params", "preprocess_bgra_resize", "preprocess_bgra", "preprocess_nv12",
+    "allocate_preprocess_buffer", "free_preprocess_buffer", "create_preprocess_stream", "destroy_preprocess_stream",
     "init_postprocess_resources", "cleanup_postprocess_resources", "reset_detection_counter", "get_detection_count",
     "decode_yolo_head", "run_gpu_nms", "copy_valid_detections_to_host",
 ]
@@ -83,6 +89,18 @@ def load_library() -> C.CDLL:
     L.unina_autotune.argtypes = [vp, ci, vp]
     L.unina_debug_post_stamps.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.unina_debug_conv_stamps.argtypes = [vp, ci, C.POINTER(C.c_longlong), vp]
+    # cuda_preprocess.h drop-in symbols
+    L.create_norm_params_imagenet.restype = NormParams
+    L.create_norm_params.restype = NormParams
+    L.create_norm_params.argtypes = [cf] * 6
+    L.preprocess_bgra_resize.argtypes = [vp, vp, ci, ci, ci, ci, ci, NormParams, vp]
+    L.preprocess_bgra.argtypes = [vp, vp, ci, ci, ci, NormParams, vp]
+    L.preprocess_nv12.argtypes = [vp, vp, vp, ci, ci, ci, ci, NormParams, vp]
+    L.allocate_preprocess_buffer.restype = vp
+    L.allocate_preprocess_buffer.argtypes = [ci, ci]
+    L.free_preprocess_buffer.argtypes = [vp]
+    L.create_preprocess_stream.restype = vp
+    L.destroy_preprocess_stream.argtypes = [vp]
     # gpu_postprocess.h drop-in symbols
     L.reset_detection_counter.argtypes = [vp]
     L.get_detection_count.argtypes = [C.POINTER(ci), vp]
