@@ -20,8 +20,8 @@ for i in want_ops:
         rows = []
         for _ in range(7):
             st = e.conv_stamps(i)
-            rows.append([st[k + 1] - st[k] for k in range(4)] + [(st[4] - st[0]) / max(1, st[6] - st[5]) * 0.1])
+            rows.append([st[k + 1] - st[k] for k in range(4)] + [(st[4] - st[0]) / max(1, st[6] - st[5]) * 0.1, st[0] - st[7]])
         med = np.median(np.array(rows), axis=0)
-        print(f"   {name:38s} {ms * 1e3:6.2f} us | ticks: issue {med[0]:6.0f}  first-data {med[1]:6.0f}  loop {med[2]:7.0f}  epilogue {med[3]:6.0f}  (total {med[:4].sum():7.0f})  clock {med[4]:.2f} GHz")
+        print(f"   {name:38s} {ms * 1e3:6.2f} us | ticks: issue {med[0]:6.0f}  first-data {med[1]:6.0f}  loop {med[2]:7.0f}  epilogue {med[3]:6.0f}  (total {med[:4].sum():7.0f})  clock {med[4]:.2f} GHz  setup {med[5]:5.0f}")
     e.set_op_config(i, -1)
 e.close()

@@ -44,6 +44,28 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// "At most n stages of LPT DMA instructions each may still be in flight" for a run-time (wave-uniform) n: the
+// s_waitcnt immediate must be a constant, so the pipeline head / tail dispatch over the few possible values.
+template <int LPT>
+__device__ __forceinline__ void wait_stages(int n) {
+  constexpr int kMax = 63;  // vmcnt is a 6-bit field
+  switch (n) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<(LPT < kMax ? LPT : kMax)>(); break;
+    case 2: wait_vmcnt<(2 * LPT < kMax ? 2 * LPT : kMax)>(); break;
+    case 3: wait_vmcnt<(3 * LPT < kMax ? 3 * LPT : kMax)>(); break;
+    case 4: wait_vmcnt<(4 * LPT < kMax ? 4 * LPT : kMax)>(); break;
+    case 5: wait_vmcnt<(5 * LPT < kMax ? 5 * LPT : kMax)>(); break;
+    default: wait_vmcnt<(6 * LPT < kMax ? 6 * LPT : kMax)>(); break;  // n >= 6: STAGES <= 8 keeps at most 6 behind the head
+  }
+}
+
+// x / d for 0 <= x, x * d < 2^32, with magic = ceil(2^32 / d) (0 encodes d == 1): one v_mul_hi_u32 instead of the
+// ~40-instruction software integer division.
+__device__ __forceinline__ int fast_div(int x, unsigned magic) {
+  return magic ? (int)__umulhi((unsigned)x, magic) : x;
+}
+
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 
 // Workgroup -> (M-tile bx, N-tile by). The grid is launched 1-D and re-mapped so that the 8 XCDs (which receive
@@ -55,8 +77,12 @@ __device__ __forceinline__ void tile_of_block(const ConvParams& p, int* bx, int*
   const int nwg = gridDim.x, orig = blockIdx.x;
   const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
   const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  *by = v / p.grid_m;
+  *by = fast_div(v, p.gm_magic);
   *bx = v - *by * p.grid_m;
+}
+
+__device__ __forceinline__ void stamp_entry(const ConvParams& p, long long t) {
+  if (p.stamps && blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0) p.stamps[7] = t;
 }
 
 __device__ __forceinline__ void stamp(const ConvParams& p, int k) {
@@ -118,10 +144,27 @@ template <> struct Elem<signed char> {
 //    2x2 block.
 //  * planar fp32 head outputs: lane = pixel already gives 64-byte contiguous runs per channel: stored directly.
 // pix_to_m(pl) maps a workgroup-local pixel to the row-major output pixel index, or -1 outside the image.
+// Per-lane bias / multiplier registers, loaded BEFORE the K loop so their global-load latency is hidden behind it.
+template <int WN_T>
+struct EpiConsts {
+  floatx4 bias[WN_T], mult[WN_T];
+};
+template <int WN_T>
+__device__ __forceinline__ void load_epi_consts(const ConvSeg& sg, int n_first, int lq, EpiConsts<WN_T>& c) {
+#pragma unroll
+  for (int j = 0; j < WN_T; ++j) {
+    const int n = n_first + j * 16 + lq * 4;
+    const bool ok = n < sg.n_count;  // bias/mult arrays are n_pad long (multiple of 16): n + 3 stays inside when ok
+    c.bias[j] = ok ? *reinterpret_cast<const floatx4*>(sg.bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+    c.mult[j] = (ok && sg.mult) ? *reinterpret_cast<const floatx4*>(sg.mult + n) : floatx4{1.f, 1.f, 1.f, 1.f};
+  }
+}
+
 template <typename T, int BM, int BN, int WM_T, int WN_T, typename PixToM>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg& sg,
-                                              typename Elem<T>::acc_t (&acc)[WN_T][WM_T], int wm, int wn, int nb0,
-                                              int l15, int lq, PixToM pix_to_m, unsigned char* stage) {
+                                              typename Elem<T>::acc_t (&acc)[WN_T][WM_T], const EpiConsts<WN_T>& ec,
+                                              int wm, int wn, int nb0, int l15, int lq, PixToM pix_to_m,
+                                              unsigned char* stage) {
   typedef Elem<T> E;
   const int od = sg.out_dtype;
   const int esz = od == kF32 ? 4 : (od == kF16 ? 2 : 1);
@@ -134,9 +177,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg
     const int nl = n_w0 + j * 16 + lq * 4;     // tile-local channel of this lane's 4 values
     const int n = nb0 + nl;                    // slice-relative
     if (n >= sg.n_count) continue;
-    const floatx4 bias = *reinterpret_cast<const floatx4*>(sg.bias + n);
-    floatx4 mult = {1.f, 1.f, 1.f, 1.f};
-    if (sg.mult) mult = *reinterpret_cast<const floatx4*>(sg.mult + n);
+    const floatx4 bias = ec.bias[j], mult = ec.mult[j];
 #pragma unroll
     for (int i = 0; i < WM_T; ++i) {
       const int pl = (wm * WM_T + i) * 16 + l15;
@@ -233,6 +274,7 @@ __global__ __launch_bounds__(256) void conv_glds(const ConvParams p) {
   constexpr int STAGE_BYTES = LPT * 4 * 1024;
   static_assert(WM_T >= 1 && WN_T >= 1 && KSUB >= 1, "tile");
 
+  const long long t_entry = p.stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wid % WAVES_M, wn = wid / WAVES_M;
@@ -253,6 +295,7 @@ __global__ __launch_bounds__(256) void conv_glds(const ConvParams p) {
   const int ld_row = lane >> 2;                                  // row (pixel / channel) this lane fetches
   const int ld_chunk = (lane & 3) ^ swz_g(ld_row);              // 8-element k-chunk this lane fetches
   int a_iy0[LPT], a_ix0[LPT];                                    // input coords of tap (0,0), or big negative if row invalid
+  int a_off0[LPT];                                               // element offset of tap (0,0) from a_base (may be negative)
   const T* a_base[LPT];                                          // src + channel offset of this lane's chunk
   const T* w_base[LPT];                                          // weight block address for k block 0 (nullptr = zero rows)
   int kind[LPT];                                                 // 0 activation, 1 weight, 2 padding
@@ -260,6 +303,7 @@ __global__ __launch_bounds__(256) void conv_glds(const ConvParams p) {
   for (int q = 0; q < LPT; ++q) {
     const int b = q * 4 + wid;
     a_iy0[q] = a_ix0[q] = -(1 << 20);
+    a_off0[q] = 0;
     a_base[q] = nullptr;
     w_base[q] = nullptr;
     if (b < ABLK) {
@@ -267,9 +311,10 @@ __global__ __launch_bounds__(256) void conv_glds(const ConvParams p) {
       const int i = b / KSUB, j = b - i * KSUB;
       const int m = m_blk + i * 16 + ld_row;
       if (m < p.M) {
-        const int oy = m / p.Wo, ox = m - oy * p.Wo;
+        const int oy = fast_div(m, p.wo_magic), ox = m - oy * p.Wo;
         a_iy0[q] = oy * p.stride - p.pad;
         a_ix0[q] = ox * p.stride - p.pad;
+        a_off0[q] = (a_iy0[q] * p.W + a_ix0[q]) * p.src_ld;
       }
       a_base[q] = static_cast<const T*>(p.src) + sg.src_coff + j * E::kBlockK + ld_chunk * E::kChunk;
     } else if (b < NBLK) {
@@ -283,28 +328,25 @@ __global__ __launch_bounds__(256) void conv_glds(const ConvParams p) {
     }
   }
 
-  // K-step iterator for the NEXT stage to issue
-  int i_kh = 0, i_kw = 0, i_c0 = 0, i_k32 = 0, i_kt = 0;
+  // K-step iterator for the NEXT stage to issue (all wave-uniform): tap (kh,kw), first channel c0, weight k block
+  int i_kh = 0, i_kw = 0, i_c0 = 0, i_k32 = 0;
   const int nk = p.ksize * p.ksize * (p.Cin / KSTEP);
   const T* zeros = reinterpret_cast<const T*>(p.zeros);
 
   auto issue = [&](int buf) {
     unsigned char* sb = conv_smem + buf * STAGE_BYTES;
-    const bool live = i_kt < nk;
+    const int tap_off = (i_kh * p.W + i_kw) * p.src_ld + i_c0;   // scalar: the same for every pixel of the tile
 #pragma unroll
     for (int q = 0; q < LPT; ++q) {
       const T* g = zeros;
-      if (live) {
-        if (kind[q] == 0) {
-          const int iy = a_iy0[q] + i_kh, ix = a_ix0[q] + i_kw;
-          if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) g = a_base[q] + (size_t)(iy * p.W + ix) * p.src_ld + i_c0;
-        } else if (kind[q] == 1) {
-          if (w_base[q]) g = w_base[q] + (size_t)i_k32 * (1024 / sizeof(T));
-        }
+      if (kind[q] == 0) {
+        const bool ok = (unsigned)(a_iy0[q] + i_kh) < (unsigned)p.H && (unsigned)(a_ix0[q] + i_kw) < (unsigned)p.W;
+        if (ok) g = a_base[q] + (a_off0[q] + tap_off);
+      } else if (kind[q] == 1) {
+        if (w_base[q]) g = w_base[q] + (size_t)i_k32 * (1024 / sizeof(T));
       }
       glds16(g, sb + (q * 4 + wid) * 1024);
     }
-    ++i_kt;
     i_c0 += KSTEP;
     i_k32 += KSUB;
     if (i_c0 >= p.Cin) {
@@ -323,13 +365,14 @@ __global__ __launch_bounds__(256) void conv_glds(const ConvParams p) {
     for (int i = 0; i < WM_T; ++i) acc[j][i] = typename E::acc_t{0, 0, 0, 0};
 
   // ---- software pipeline ----------------------------------------------------------------------------------
-  // LDS-DMA ring: STAGES buffers, stage kt lives in buffer kt % STAGES; steps past the end are all-zero dummies so
-  // that every wave issues the same number of DMA instructions per step (uniform vmcnt arithmetic).
+  // LDS-DMA ring: STAGES buffers, stage kt lives in buffer kt % STAGES, up to STAGES-1 steps in flight; every wave
+  // issues exactly LPT DMA instructions per stage, so "stage X has landed" is a counted s_waitcnt vmcnt.
   // Register pipeline: the fragments of step kt+1 are read from LDS into the OTHER register set while the MFMAs of
   // step kt issue, so LDS latency overlaps matrix work (the compiler alone serialises read -> lgkmcnt(0) -> MFMA).
-  // Iteration kt: wait until stage kt+1 has landed (<= (STAGES-3)*LPT DMA ops may remain in flight), barrier,
-  // refill buffer (kt-1) % STAGES -- its fragments were consumed by the MFMAs every wave finished before this
-  // barrier --, read stage kt+1, run the MFMAs of stage kt.
+  // Step kt: wait until stage kt+1 has landed, barrier, refill buffer (kt-1) % STAGES -- its fragments were consumed
+  // by MFMAs every wave finished before this barrier --, read stage kt+1, run the MFMAs of stage kt.
+  // The steady-state loop has no conditionals (a branch around the reads makes hipcc fall back to lgkmcnt(0) before
+  // the MFMAs); head and tail, where fewer stages are in flight, use run-time counts.
   static_assert(STAGES >= 3, "ring depth");
   struct Frags {
     frag_t a[KSUB][WN_T], b[KSUB][WM_T];
@@ -353,33 +396,56 @@ __global__ __launch_bounds__(256) void conv_glds(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < WM_T; ++i) acc[n][i] = E::mma(f.a[j][n], f.b[j][i], acc[n][i]);
   };
+  stamp_entry(p, t_entry);
   stamp(p, 0);
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s) issue(s);
+  const int n_pro = nk < STAGES - 1 ? nk : STAGES - 1;
+  for (int s = 0; s < n_pro; ++s) issue(s);
   stamp(p, 1);
+  EpiConsts<WN_T> ec;
+  load_epi_consts<WN_T>(sg, nb0 + wn * (WN_T * 16), lq, ec);
   Frags fa, fb;
-  wait_vmcnt<(STAGES - 2) * LPT>();  // stage 0 landed
+  wait_stages<LPT>(n_pro - 1);  // stage 0 landed (the epilogue-constant loads above only make this stricter)
   __builtin_amdgcn_s_barrier();
   read_frags(fa, 0);
   stamp(p, 2);
-  // No conditionals inside: a branch around the reads makes hipcc fall back to s_waitcnt lgkmcnt(0) before the MFMAs.
-  // Steps past the end read / multiply all-zero dummy stages (they add exactly 0), so an odd step count is simply
-  // rounded up.
-  auto step = [&](int kt, Frags& cur, Frags& nxt) {
+  int kt = 0;
+  for (; kt + STAGES < nk; kt += 2) {  // steady state: two steps, every stage they touch exists
     wait_vmcnt<(STAGES - 3) * LPT>();
     __builtin_amdgcn_s_barrier();
     issue((kt + STAGES - 1) % STAGES);
-    read_frags(nxt, kt + 1);
-    mma_frags(cur);
-  };
-  for (int kt = 0; kt < nk; kt += 2) {
-    step(kt, fa, fb);
-    step(kt + 1, fb, fa);
+    read_frags(fb, kt + 1);
+    mma_frags(fa);
+    wait_vmcnt<(STAGES - 3) * LPT>();
+    __builtin_amdgcn_s_barrier();
+    issue((kt + STAGES) % STAGES);
+    read_frags(fa, kt + 2);
+    mma_frags(fb);
+  }
+  bool cur_a = true;
+  for (; kt < nk; ++kt) {  // tail: run-time counts, nothing is issued past the last stage
+    if (kt + 1 < nk) {
+      const int issued = kt + STAGES - 1 < nk ? kt + STAGES - 1 : nk;
+      wait_stages<LPT>(issued - (kt + 2));
+      __builtin_amdgcn_s_barrier();
+      if (kt + STAGES - 1 < nk) issue((kt + STAGES - 1) % STAGES);
+      if (cur_a) {
+        read_frags(fb, kt + 1);
+        mma_frags(fa);
+      } else {
+        read_frags(fa, kt + 1);
+        mma_frags(fb);
+      }
+    } else if (cur_a) {
+      mma_frags(fa);
+    } else {
+      mma_frags(fb);
+    }
+    cur_a = !cur_a;
   }
   wait_vmcnt<0>();  // drain the dummy tail before the wave retires
 
   // ---- epilogue ----
-  conv_epilogue<T, BM, BN, WM_T, WN_T>(p, sg, acc, wm, wn, nb0, l15, lq,
+  conv_epilogue<T, BM, BN, WM_T, WN_T>(p, sg, acc, ec, wm, wn, nb0, l15, lq,
                                        [&](int pl) { const int m = m_blk + pl; return m < p.M ? m : -1; }, conv_smem);
 }
 
@@ -409,6 +475,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
   constexpr int RING_BYTES = STAGES * STAGE_BYTES;
   static_assert(WM_T >= 1 && WN_T >= 1 && (TW == 8 || TW == 16), "tile");
 
+  const long long t_entry = p.stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wid % WAVES_M, wn = wid / WAVES_M;
@@ -430,6 +497,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
   const T* zeros = reinterpret_cast<const T*>(p.zeros);
 
   // ---- 1. patch DMA: slot s (16 B) of the image = pixel s / nch, slot-in-pixel s % nch ----
+  stamp_entry(p, t_entry);
   stamp(p, 0);
   {
     const int nslots = NPIX * nch;
@@ -465,16 +533,15 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
   int i_kt = 0;
   auto issue = [&](int buf) {
     unsigned char* sb = conv_smem + buf * STAGE_BYTES;
-    const bool live = i_kt < nk;
 #pragma unroll
     for (int q = 0; q < LPT; ++q) {
-      const T* g = (live && w_base[q]) ? w_base[q] + (size_t)i_kt * KSUB * (1024 / sizeof(T)) : zeros;
+      const T* g = w_base[q] ? w_base[q] + (size_t)i_kt * KSUB * (1024 / sizeof(T)) : zeros;
       glds16(g, sb + (q * 4 + wid) * 1024);
     }
     ++i_kt;
   };
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s) issue(s);
+  const int n_pro = nk < STAGES - 1 ? nk : STAGES - 1;
+  for (int s = 0; s < n_pro; ++s) issue(s);
   stamp(p, 1);
 
   // ---- 3. per-lane patch addressing: pixel of every subtile, tap (0,0) ----
@@ -497,8 +564,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
   };
   const int rd_off = (4 * l15 + (lq ^ swz_g(l15))) * 16;
   auto read_frags = [&](Frags& f, int kt) {
-    const int tap_raw = kt / steps_per_tap, cs = kt - tap_raw * steps_per_tap;  // wave-uniform
-    const int tap = tap_raw < 9 ? tap_raw : 8;                                 // dummy steps past the end stay inside the patch
+    const int tap = fast_div(kt, p.spt_magic), cs = kt - tap * steps_per_tap;  // wave-uniform
     const int tap_off = (tap / 3) * HW_ + (tap - (tap / 3) * 3);
     const unsigned char* sb = conv_smem + (kt % STAGES) * STAGE_BYTES + rd_off;
     int hrow[WM_T], hsw[WM_T];  // byte offset of the pixel row, swizzle term
@@ -525,36 +591,60 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < WM_T; ++i) acc[n][i] = E::mma(f.a[j][n], f.b[j][i], acc[n][i]);
   };
+  EpiConsts<WN_T> ec;
+  load_epi_consts<WN_T>(sg, nb0 + wn * (WN_T * 16), lq, ec);
   Frags fa, fb;
-  wait_vmcnt<(STAGES - 2) * LPT>();  // patch + stage 0 landed
+  wait_stages<LPT>(n_pro - 1);  // patch + stage 0 landed
   __builtin_amdgcn_s_barrier();
   read_frags(fa, 0);
   stamp(p, 2);
-  // No conditionals inside: a branch around the reads makes hipcc fall back to s_waitcnt lgkmcnt(0) before the MFMAs.
-  // Steps past the end read / multiply all-zero dummy stages (they add exactly 0), so an odd step count is simply
-  // rounded up.
-  auto step = [&](int kt, Frags& cur, Frags& nxt) {
+  int kt = 0;
+  for (; kt + STAGES < nk; kt += 2) {
     wait_vmcnt<(STAGES - 3) * LPT>();
     __builtin_amdgcn_s_barrier();
     issue((kt + STAGES - 1) % STAGES);
-    read_frags(nxt, kt + 1);
-    mma_frags(cur);
-  };
-  for (int kt = 0; kt < nk; kt += 2) {
-    step(kt, fa, fb);
-    step(kt + 1, fb, fa);
+    read_frags(fb, kt + 1);
+    mma_frags(fa);
+    wait_vmcnt<(STAGES - 3) * LPT>();
+    __builtin_amdgcn_s_barrier();
+    issue((kt + STAGES) % STAGES);
+    read_frags(fa, kt + 2);
+    mma_frags(fb);
+  }
+  bool cur_a = true;
+  for (; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      const int issued = kt + STAGES - 1 < nk ? kt + STAGES - 1 : nk;
+      wait_stages<LPT>(issued - (kt + 2));
+      __builtin_amdgcn_s_barrier();
+      if (kt + STAGES - 1 < nk) issue((kt + STAGES - 1) % STAGES);
+      if (cur_a) {
+        read_frags(fb, kt + 1);
+        mma_frags(fa);
+      } else {
+        read_frags(fa, kt + 1);
+        mma_frags(fb);
+      }
+    } else if (cur_a) {
+      mma_frags(fa);
+    } else {
+      mma_frags(fb);
+    }
+    cur_a = !cur_a;
   }
   wait_vmcnt<0>();
   stamp(p, 3);
 
-  conv_epilogue<T, BM, BN, WM_T, WN_T>(p, sg, acc, wm, wn, nb0, l15, lq,
+  conv_epilogue<T, BM, BN, WM_T, WN_T>(p, sg, acc, ec, wm, wn, nb0, l15, lq,
                                        [&](int pl) {
                                          const int oy = ty0 + pl / TW, ox = tx0 + pl % TW;
                                          return (oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
                                        },
                                        conv_smem);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  stamp(p, 4);
+  if (p.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(p, 4);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- launch side
@@ -763,7 +853,11 @@ ConvLaunch conv_plan(const ConvParams& p) {
 hipError_t conv_launch(const ConvParams& pin, const ConvLaunch& l, hipStream_t stream) {
   ConvParams p = pin;
   const CfgInfo& c = kCfg[p.dtype][l.cfg];
+  auto magic = [](unsigned d) { return d > 1 ? (unsigned)(((1ull << 32) + d - 1) / d) : 0u; };
   p.grid_m = (int)l.grid.x;
+  p.gm_magic = magic(l.grid.x);
+  p.wo_magic = magic((unsigned)p.Wo);
+  p.spt_magic = magic((unsigned)(p.Cin / kstep_of(p, c)));
   int t = 0;
   for (int s = 0; s < p.nseg; ++s) {
     p.seg[s].tile0 = t;

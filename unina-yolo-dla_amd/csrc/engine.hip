@@ -696,7 +696,7 @@ int unina_debug_conv_stamps(unina_engine_t* e, int op_index, long long* out5, hi
   HIPCHK(e, hipMemsetAsync(p.stamps, 0, sizeof(long long) * 8, stream));
   HIPCHK(e, conv_launch(p, e->ops[op_index].cl, stream));
   HIPCHK(e, hipStreamSynchronize(stream));
-  HIPCHK(e, hipMemcpy(out5, p.stamps, sizeof(long long) * 7, hipMemcpyDeviceToHost));  // 5 shader-clock stamps + 2 at 100 MHz
+  HIPCHK(e, hipMemcpy(out5, p.stamps, sizeof(long long) * 8, hipMemcpyDeviceToHost));  // 5 shader-clock stamps + 2 at 100 MHz + entry
   return UNINA_OK;
 }
 

@@ -48,6 +48,7 @@ struct ConvParams {
   const void* zeros;   // >= 16 bytes of zeros in HBM: source of out-of-image taps / tile tails
   int force_cfg;       // >= 0: use this tile configuration (autotuner / tests); -1: heuristic
   int grid_m;          // number of M tiles (filled at launch): the 1-D grid is re-mapped XCD-aware in the kernel
+  unsigned gm_magic, wo_magic, spt_magic;  // ceil(2^32/d) for d = grid_m, Wo, K-steps per tap (0: d == 1), filled at launch
   int debug_mode;      // debug ablations (results invalid): 1 = no loads inside the K loop, 2 = no LDS reads/MFMA, 3 = MFMA without LDS reads
   long long* stamps;   // debug: s_memtime stamps of workgroup (0,0) (nullptr = off): start, prologue issued, first data, loop end, end
 };

@@ -297,7 +297,7 @@ class Engine:
 
     def conv_stamps(self, op_index: int, stream=None) -> List[int]:
         """In-kernel phase stamps (shader-clock ticks) of one launch of conv op `op_index` (debug)."""
-        buf = (C.c_longlong * 7)()
+        buf = (C.c_longlong * 8)()
         self._check(self.L.unina_debug_conv_stamps(self.h, op_index, buf, _stream_ptr(stream)))
         return [int(v) for v in buf]
 
