@@ -142,6 +142,19 @@ int unina_set_op_config(unina_engine_t *e, int op_index, int cfg);
  * Needs "images" bound. Results are bit-identical under every configuration. */
 int unina_autotune(unina_engine_t *e, int iters, hipStream_t stream);
 
+/* Block fusion (fp16 engines). At load the engine recognises every C3k2 block of the op table (the reference's
+ * model.py:76-110: cv1|cv2 -> n x Bottleneck -> cv3) and, while fusion is on (the default; UNINA_FUSE=0 in the
+ * environment starts with it off), runs each as ONE launch that keeps the block's intermediates in LDS
+ * (csrc/c3k2_fused.hip) -- the role of TensorRT's layer fusion in the reference's engine build. Results are
+ * bit-identical either way; with fusion on the blocks' internal buffers are not written (unina_debug_read_buffer of
+ * e.g. "neck.pan_c3k2_1.cat" then returns stale data), so per-layer checks and calibration switch it off.
+ * unina_fusion_groups: number of blocks currently running fused (0 when off / none recognised). */
+int unina_set_fusion(unina_engine_t *e, int enable);
+int unina_fusion_groups(const unina_engine_t *e);
+/* Load-time analysis alone, no device needed: number of C3k2 blocks of the engine file that would run fused
+ * (negative = -error code). */
+int unina_debug_fusable_groups(const char *path);
+
 /* Copies an internal activation buffer to the host as fp32 NCHW ([C,H,W]) -- parity tests only.
  * `name` is a buffer name from the engine file (e.g. "p3_fused"); returns UNINA_ERR_ARG if unknown. */
 int unina_debug_read_buffer(unina_engine_t *e, const char *name, float *host_out, size_t capacity_floats,

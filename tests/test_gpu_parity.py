@@ -63,7 +63,16 @@ def test_library_is_the_hip_engine(eng64):
     assert len(eng64.op_infos()) == 52
 
 
-def test_mini64_every_buffer_vs_oracle(pkg, eng64, oracle_mod, oracle_sd7, torch_cuda):
+@pytest.fixture
+def unfused64(eng64):
+    """Per-layer checks read the C3k2 blocks' internal buffers, which only the unfused op table writes."""
+    eng64.set_fusion(False)
+    yield eng64
+    assert eng64.set_fusion(True) == 7
+
+
+def test_mini64_every_buffer_vs_oracle(pkg, unfused64, oracle_mod, oracle_sd7, torch_cuda):
+    eng64 = unfused64
     x = pkg.rng.frame(1234, 64, 64)
     heads = eng64.forward(torch_cuda.from_numpy(x).cuda())
     ref = oracle_mod.forward(oracle_sd7, x, keep_all=True)
@@ -340,7 +349,11 @@ def test_tile_configs_and_autotune_are_bit_identical(pkg, sd7, torch_cuda):
     e = Engine.from_state_dict(sd7, g)
     try:
         x = _frame(pkg, torch_cuda, 1234, 128)
+        fused = {k: v.copy() for k, v in e.forward(x).items()}
+        e.set_fusion(False)                                   # tile configurations belong to the per-op kernels
         base = {k: v.copy() for k, v in e.forward(x).items()}
+        for k in base:
+            assert np.array_equal(fused[k], base[k]), ("fusion", k)
         infos = e.op_infos()
         ncfg = len(e.conv_configs())
         tried = 0
@@ -359,6 +372,36 @@ def test_tile_configs_and_autotune_are_bit_identical(pkg, sd7, torch_cuda):
         out = e.forward(x)
         for k in base:
             assert np.array_equal(out[k], base[k]), ("autotune", k)
+    finally:
+        e.close()
+
+
+BLOCK_OUTPUTS = ("neck.cat_fpn2", "neck.cat_fpn1", "neck.cat_pan2", "neck.cat_pan1", "p2_fused", "p3_out", "p4_out")
+
+
+@pytest.mark.parametrize("size", [64, 640, 96])
+def test_c3k2_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
+    """Each C3k2 block (model.py:76-110) as ONE launch with its intermediates in LDS (csrc/c3k2_fused.hip) vs the
+    2 + 2n per-conv launches: same MFMA, same K order, same fp16 rounding points -> every block output and every head
+    must agree bit for bit. 96x96 gives 24/12/6-pixel maps: partial tiles on every level."""
+    from unina_yolo_dla_amd.engine import Engine
+    e = Engine.from_state_dict(sd7, pkg.graph.Graph(in_h=size, in_w=size))
+    try:
+        assert e.L.unina_fusion_groups(e.h) == 7              # on by default
+        x = _frame(pkg, torch_cuda, 1234, size)
+        fused = {k: v.copy() for k, v in e.forward(x).items()}
+        fused_bufs = {b: e.read_buffer(b) for b in BLOCK_OUTPUTS}
+        assert sum("c3k2_fused" in o["kernel"] for o in e.op_infos()) == 7
+        assert e.set_fusion(False) == 0
+        plain = e.forward(x)
+        for b in BLOCK_OUTPUTS:
+            assert np.array_equal(fused_bufs[b], e.read_buffer(b)), b
+        for k in plain:
+            assert np.array_equal(fused[k], plain[k]), k
+        assert e.set_fusion(True) == 7
+        again = e.forward(x)
+        for k in plain:
+            assert np.array_equal(again[k], plain[k]), k
     finally:
         e.close()
 

@@ -30,7 +30,8 @@ tot = sum(o["ms"] for o in ops)
 print(f"{'#':>2} {'us':>7} {'TF/s':>6} {'GB/s':>6} {'grid':>5}  {'M':>6} {'N':>4} {'K':>5}  kernel / name")
 for i, o in enumerate(ops):
     us = o["ms"] * 1e3
-    print(f"{i:2d} {us:7.2f} {o['flops'] / o['ms'] / 1e9:6.1f} {o['bytes'] / o['ms'] / 1e6:6.0f} {o['grid']:5d}  "
+    ms_ = max(o["ms"], 1e-9)
+    print(f"{i:2d} {us:7.2f} {o['flops'] / ms_ / 1e9:6.1f} {o['bytes'] / ms_ / 1e6:6.0f} {o['grid']:5d}  "
           f"{o['m']:6d} {o['n']:4d} {o['k']:5d}  {o['kernel']:34s} {o['name'][:60]}")
 print(f"sum of ops: {tot * 1e3:.1f} us  ({g.macs() * 2 / tot / 1e9:.1f} TFLOP/s over the forward)")
 

@@ -20,6 +20,7 @@ ARCH = "gfx950"
 # translation unit -> extra flags
 UNITS = {
     "conv_igemm.hip": [],
+    "c3k2_fused.hip": [],
     "stem_pool.hip": [],
     "postprocess.hip": ["-ffp-contract=off"],   # box arithmetic must round like the reference's scalar code
     "preprocess.hip": ["-ffp-contract=off"],    # normalisation arithmetic rounds as written (oracle/preprocess_oracle.c)

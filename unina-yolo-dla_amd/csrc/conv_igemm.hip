@@ -23,48 +23,13 @@
 // zero page instead of branching.
 // Pipeline: STAGES LDS buffers, STAGES-1 K-steps in flight, one s_barrier per K-step, counted s_waitcnt vmcnt.
 #include "kernels.h"
+#include "mfma_common.h"
 
 namespace unina {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
+using namespace dev;
 
 namespace {
-
-__device__ __forceinline__ int swz_g(int r16) { return (0x78 >> (2 * (r16 >> 2))) & 3; }  // G = {0,2,3,1}
-
-__device__ __forceinline__ void glds16(const void* gptr, unsigned char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// "At most n stages of LPT DMA instructions each may still be in flight" for a run-time (wave-uniform) n: the
-// s_waitcnt immediate must be a constant, so the pipeline head / tail dispatch over the few possible values.
-template <int LPT>
-__device__ __forceinline__ void wait_stages(int n) {
-  constexpr int kMax = 63;  // vmcnt is a 6-bit field
-  switch (n) {
-    case 0: wait_vmcnt<0>(); break;
-    case 1: wait_vmcnt<(LPT < kMax ? LPT : kMax)>(); break;
-    case 2: wait_vmcnt<(2 * LPT < kMax ? 2 * LPT : kMax)>(); break;
-    case 3: wait_vmcnt<(3 * LPT < kMax ? 3 * LPT : kMax)>(); break;
-    case 4: wait_vmcnt<(4 * LPT < kMax ? 4 * LPT : kMax)>(); break;
-    case 5: wait_vmcnt<(5 * LPT < kMax ? 5 * LPT : kMax)>(); break;
-    default: wait_vmcnt<(6 * LPT < kMax ? 6 * LPT : kMax)>(); break;  // n >= 6: STAGES <= 8 keeps at most 6 behind the head
-  }
-}
-
-// x / d for 0 <= x, x * d < 2^32, with magic = ceil(2^32 / d) (0 encodes d == 1): one v_mul_hi_u32 instead of the
-// ~40-instruction software integer division.
-__device__ __forceinline__ int fast_div(int x, unsigned magic) {
-  return magic ? (int)__umulhi((unsigned)x, magic) : x;
-}
 
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 
@@ -853,11 +818,10 @@ ConvLaunch conv_plan(const ConvParams& p) {
 hipError_t conv_launch(const ConvParams& pin, const ConvLaunch& l, hipStream_t stream) {
   ConvParams p = pin;
   const CfgInfo& c = kCfg[p.dtype][l.cfg];
-  auto magic = [](unsigned d) { return d > 1 ? (unsigned)(((1ull << 32) + d - 1) / d) : 0u; };
   p.grid_m = (int)l.grid.x;
-  p.gm_magic = magic(l.grid.x);
-  p.wo_magic = magic((unsigned)p.Wo);
-  p.spt_magic = magic((unsigned)(p.Cin / kstep_of(p, c)));
+  p.gm_magic = div_magic(l.grid.x);
+  p.wo_magic = div_magic((unsigned)p.Wo);
+  p.spt_magic = div_magic((unsigned)(p.Cin / kstep_of(p, c)));
   int t = 0;
   for (int s = 0; s < p.nseg; ++s) {
     p.seg[s].tile0 = t;

@@ -39,6 +39,13 @@ struct PlannedOp {
   PoolParams pp;
   QuantParams qp;
   unina_op_info info;
+  // fused C3k2 block (c3k2_fused.hip): role 1 = first op of a fusable group (launches the whole block when fusion is
+  // on), 2 = absorbed by the group's first op (no launch of its own when fusion is on), 0 = ordinary op
+  int fuse_role = 0;
+  int group_last = -1;      // role 1: index of the group's last op (cv3)
+  int hid = 0, nb = 0;      // role 1: hidden width, bottleneck count
+  uint64_t stream_off = 0, fbias_off = 0;   // role 1: blob offsets of the packed stage stream / concatenated biases
+  C3k2Params fp;
 };
 
 struct DeviceResult {  // what the fused post-process writes; one D2H brings count + records
@@ -60,6 +67,8 @@ struct unina_engine {
   void* d_arena = nullptr;
   void* d_zeros = nullptr;          // zero page read by out-of-image taps
   std::vector<int> force_cfg;       // per-op tile configuration override (-1 = heuristic)
+  bool fuse = false;                // run fusable C3k2 groups as one launch each (fp16 engines; UNINA_FUSE=0 / unina_set_fusion)
+  int n_groups = 0;                 // fusable groups found at load
   int images_buf = -1;
   int out_buf[6] = {-1, -1, -1, -1, -1, -1};
   // post-process workspace
@@ -255,6 +264,52 @@ int plan(unina_engine* e) {
       return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: kind %u not executable", i, d.kind);
     }
   }
+  // fused C3k2 groups: parameters of the one-launch form; op infos describe what actually runs
+  for (size_t i = 0; i < e->ops.size(); ++i) {
+    PlannedOp& op = e->ops[i];
+    if (op.fuse_role != 1) continue;
+    const OpDesc& a = op.d;
+    const OpDesc& z = e->ops[op.group_last].d;
+    const Buffer& src = e->bufs[a.src_buf];
+    const Buffer& dst = e->bufs[z.seg[0].dst_buf];
+    C3k2Params& f = op.fp;
+    memset(&f, 0, sizeof f);
+    f.src = static_cast<const half_t*>(src.ptr) + a.seg[0].src_coff;
+    f.src_ld = (int)src.d.c;
+    f.Cin = (int)a.cin;
+    f.H = (int)a.in_h;
+    f.W = (int)a.in_w;
+    f.dst = static_cast<half_t*>(dst.ptr) + z.seg[0].dst_coff;
+    f.dst_ld = (int)dst.d.c;
+    f.wstream = reinterpret_cast<const unsigned char*>(blob + op.stream_off);
+    f.bias = reinterpret_cast<const float*>(blob + op.fbias_off);
+    f.zeros = e->d_zeros;
+    f.hid = op.hid;
+    f.nb = op.nb;
+    if (!c3k2_layout(&f)) return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: fused C3k2 block does not fit", i);
+    if (!e->fuse) continue;
+    unina_op_info& info = op.info;
+    double flops = 0, wbytes = 0;
+    for (int k = (int)i; k <= op.group_last; ++k) {
+      flops += e->ops[k].info.flops;
+      wbytes += 2.0 * e->ops[k].info.n * e->ops[k].info.k + 4.0 * e->ops[k].info.n;
+      if (k > (int)i) {
+        unina_op_info& ai = e->ops[k].info;
+        ai.flops = 0;
+        ai.bytes = 0;
+        ai.grid = 0;
+        snprintf(ai.kernel, sizeof ai.kernel, "(fused into op %zu)", i);
+      }
+    }
+    info.flops = flops;
+    info.bytes = 2.0 * f.H * f.W * f.Cin + wbytes + 2.0 * f.H * f.W * 2 * f.hid;   // input once, weights once, output once
+    info.n = 2 * f.hid;
+    info.k = 0;
+    info.grid = f.tiles_x * f.tiles_y;
+    info.block = 256;
+    snprintf(info.kernel, sizeof info.kernel, "%s", c3k2_kernel_name(f.hid, f.nb));
+    snprintf(info.name, sizeof info.name, "%.*s[c3k2 x%d]", (int)(strchr(a.name, '+') ? strchr(a.name, '+') - a.name - 4 : 60), a.name, f.nb);
+  }
   e->plan_dirty = false;
   drop_graph(e);
   return UNINA_OK;
@@ -262,6 +317,8 @@ int plan(unina_engine* e) {
 
 hipError_t launch_op(unina_engine* e, size_t i, hipStream_t s) {
   PlannedOp& op = e->ops[i];
+  if (e->fuse && op.fuse_role == 1) return c3k2_launch(op.fp, s);
+  if (e->fuse && op.fuse_role == 2) return hipSuccess;   // runs inside its group's launch
   switch (op.d.kind) {
     case kOpConv: return conv_launch(op.cp, op.cl, s);
     case kOpStem: return stem_launch(op.sp, s);
@@ -294,6 +351,13 @@ void op_regions(const unina_engine* e, size_t i, std::vector<Region>* reads, std
   const OpDesc& d = e->ops[i].d;
   reads->clear();
   writes->clear();
+  if (e->fuse && e->ops[i].fuse_role == 2) return;
+  if (e->fuse && e->ops[i].fuse_role == 1) {
+    const SegDesc& out = e->ops[e->ops[i].group_last].d.seg[0];
+    reads->push_back({(int)d.src_buf, (int)d.seg[0].src_coff, (int)(d.seg[0].src_coff + d.cin)});
+    writes->push_back({(int)out.dst_buf, (int)out.dst_coff, (int)(out.dst_coff + out.n_count)});
+    return;
+  }
   if (d.kind == kOpSppfPool) {
     const int c0 = (int)d.seg[0].src_coff, C = (int)d.cin;
     reads->push_back({(int)d.src_buf, c0, c0 + C});
@@ -395,6 +459,101 @@ int capture(unina_engine* e) {
   return UNINA_OK;
 }
 
+// ---- fusable C3k2 groups (model.py:76-110) -------------------------------------------------------------------------
+// The exporter lowers a C3k2 block to  [cv1|cv2 (1x1, two slices)] -> n x [b.cv1 (1x1), b.cv2 (3x3, +residual)] ->
+// [cv3 (1x1 over the concat buffer)]. This recognises that shape in the op table (structurally: buffers, slices and
+// residual wiring must match exactly, and no op outside the group may read the group's intermediates), packs the
+// group's weights into the stage stream of c3k2_fused.hip and appends it to the (host copy of the) blob.
+bool is_plain_conv(const OpDesc& d, uint32_t k, uint32_t nseg) {
+  if (d.kind != kOpConv || d.ksize != k || d.stride != 1 || !d.relu || d.nseg != nseg) return false;
+  for (uint32_t s = 0; s < nseg; ++s)
+    if (d.seg[s].flags || d.seg[s].m_off || d.seg[s].n_pad != d.seg[s].n_count) return false;
+  return true;
+}
+
+void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
+  const size_t n = e->ops.size();
+  for (size_t i = 0; i + 3 < n; ++i) {
+    const OpDesc& a = e->ops[i].d;
+    if (!is_plain_conv(a, 1, 2) || a.res_buf >= 0) continue;
+    const uint32_t h = a.seg[0].n_count;
+    if (a.seg[1].n_count != h || a.seg[0].src_coff != a.seg[1].src_coff) continue;
+    if (e->bufs[a.src_buf].d.dtype != kBufF16Nhwc) continue;
+    // bottlenecks
+    uint32_t cur_buf = a.seg[0].dst_buf, cur_coff = a.seg[0].dst_coff;
+    size_t j = i + 1;
+    int nb = 0;
+    std::vector<uint32_t> inter = {a.seg[0].dst_buf, a.seg[1].dst_buf};
+    while (j + 1 < n && nb < 2) {
+      const OpDesc& c1 = e->ops[j].d;
+      const OpDesc& c2 = e->ops[j + 1].d;
+      if (!is_plain_conv(c1, 1, 1) || !is_plain_conv(c2, 3, 1)) break;
+      if (c1.res_buf >= 0 || c1.cin != h || c1.seg[0].n_count != h || c1.src_buf != cur_buf || c1.seg[0].src_coff != cur_coff) break;
+      if (c2.cin != h || c2.seg[0].n_count != h || c2.src_buf != c1.seg[0].dst_buf || c2.seg[0].src_coff != c1.seg[0].dst_coff) break;
+      if (c2.res_buf != (int)cur_buf || c2.res_coff != (int)cur_coff) break;
+      inter.push_back(c1.seg[0].dst_buf);
+      inter.push_back(c2.seg[0].dst_buf);
+      cur_buf = c2.seg[0].dst_buf;
+      cur_coff = c2.seg[0].dst_coff;
+      j += 2;
+      ++nb;
+    }
+    if (nb < 1 || j >= n) continue;
+    const OpDesc& z = e->ops[j].d;  // cv3 over [last bottleneck | cv2]
+    if (!is_plain_conv(z, 1, 1) || z.res_buf >= 0 || z.cin != 2 * h || z.seg[0].n_count != 2 * h) continue;
+    if (z.src_buf != cur_buf || z.src_buf != a.seg[1].dst_buf || cur_coff != z.seg[0].src_coff || a.seg[1].dst_coff != cur_coff + h) continue;
+    if (e->bufs[z.seg[0].dst_buf].d.dtype != kBufF16Nhwc || z.seg[0].dst_coff % 8 || e->bufs[z.seg[0].dst_buf].d.c % 8) continue;
+    if (a.in_h != z.out_h || a.in_w != z.out_w) continue;
+    if (!c3k2_supported((int)h, nb, (int)a.cin)) continue;
+    // the group's intermediates must be private to it, and must not be its own input or output
+    bool priv = true;
+    for (uint32_t b : inter) {
+      if (b == a.src_buf || b == z.seg[0].dst_buf || (e->bufs[b].d.flags & (kBufInput | kBufOutput))) priv = false;
+      for (size_t k = 0; k < n && priv; ++k) {
+        if (k >= i && k <= j) continue;
+        const OpDesc& o = e->ops[k].d;
+        if (o.src_buf == b || o.res_buf == (int)b) priv = false;
+        for (uint32_t s = 0; s < o.nseg; ++s)
+          if (o.seg[s].dst_buf == b) priv = false;
+      }
+    }
+    if (!priv) continue;
+    // pack
+    std::vector<C3k2Conv> convs;
+    for (size_t k = i; k <= j; ++k) {
+      const OpDesc& o = e->ops[k].d;
+      C3k2Conv cv;
+      memset(&cv, 0, sizeof cv);
+      for (uint32_t s = 0; s < o.nseg; ++s) {
+        cv.w[s] = reinterpret_cast<const unsigned char*>(blob->data() + o.seg[s].w_off);
+        cv.bias[s] = reinterpret_cast<const float*>(blob->data() + o.seg[s].b_off);
+        cv.n[s] = (int)o.seg[s].n_count;
+      }
+      cv.K = (int)(o.ksize * o.ksize * o.cin);
+      convs.push_back(cv);
+    }
+    std::vector<unsigned char> stream;
+    std::vector<float> bias;
+    if (!c3k2_pack((int)h, nb, (int)a.cin, convs.data(), &stream, &bias)) continue;
+    blob->resize((blob->size() + 255) & ~(size_t)255);
+    const uint64_t so = blob->size();
+    blob->insert(blob->end(), stream.begin(), stream.end());
+    blob->resize((blob->size() + 255) & ~(size_t)255);
+    const uint64_t bo = blob->size();
+    blob->insert(blob->end(), reinterpret_cast<const char*>(bias.data()), reinterpret_cast<const char*>(bias.data() + bias.size()));
+    PlannedOp& head = e->ops[i];
+    head.fuse_role = 1;
+    head.group_last = (int)j;
+    head.hid = (int)h;
+    head.nb = nb;
+    head.stream_off = so;
+    head.fbias_off = bo;
+    for (size_t k = i + 1; k <= j; ++k) e->ops[k].fuse_role = 2;
+    ++e->n_groups;
+    i = j;
+  }
+}
+
 int find_buffer(const unina_engine* e, const char* name) {
   for (size_t i = 0; i < e->bufs.size(); ++i)
     if (!strncmp(e->bufs[i].d.name, name, sizeof e->bufs[i].d.name)) return (int)i;
@@ -482,6 +641,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   if (e->h.blob_bytes && fread(blob.data(), 1, blob.size(), f) != blob.size()) return bail(UNINA_ERR_FORMAT, "truncated weight blob");
   fclose(f);
   f = nullptr;
+  const size_t file_blob_bytes = blob.size();
 
   // table validation (indices, offsets) before anything touches the GPU
   for (auto& o : e->ops) {
@@ -517,6 +677,14 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   }
   if (e->images_buf < 0) return bail(UNINA_ERR_FORMAT, "engine file lacks the images input buffer");
 
+  // fusable C3k2 groups (fp16 engines): their packed weight streams are appended to the blob before upload
+  if (e->h.precision == kFp16) {
+    find_c3k2_groups(e, &blob);
+    const char* fz = getenv("UNINA_FUSE");
+    e->fuse = e->n_groups > 0 && !(fz && fz[0] == '0');
+  }
+  (void)file_blob_bytes;
+
   // ---- device side ----
   hipError_t err;
 #define LOADCHK(call)                                                            \
@@ -531,6 +699,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   for (auto& b : e->bufs)
     if (!(b.d.flags & kBufInput)) arena += (b.bytes + 255) & ~(size_t)255;
   LOADCHK(conv_init());
+  LOADCHK(c3k2_init());
   LOADCHK(hipMalloc(&e->d_zeros, 256));
   LOADCHK(hipMemset(e->d_zeros, 0, 256));
   LOADCHK(hipMalloc(&e->d_arena, arena ? arena : 256));
@@ -714,6 +883,46 @@ int unina_get_op_info(const unina_engine_t* ce, int index, unina_op_info* info) 
   return UNINA_OK;
 }
 
+// Load-time analysis only (no device is touched): how many C3k2 blocks of the engine file would run fused.
+int unina_debug_fusable_groups(const char* path) {
+  if (!path) return -UNINA_ERR_ARG;
+  FILE* f = fopen(path, "rb");
+  if (!f) return -UNINA_ERR_IO;
+  unina_engine e;
+  bool ok = fread(&e.h, sizeof e.h, 1, f) == 1 && !memcmp(e.h.magic, kMagic, 8) && e.h.version == kVersion &&
+            e.h.n_buffers && e.h.n_buffers <= 4096 && e.h.n_ops && e.h.n_ops <= 4096;
+  std::vector<char> blob;
+  if (ok) {
+    e.bufs.resize(e.h.n_buffers);
+    e.ops.resize(e.h.n_ops);
+    for (auto& b : e.bufs) ok = ok && fread(&b.d, sizeof b.d, 1, f) == 1;
+    for (auto& o : e.ops) ok = ok && fread(&o.d, sizeof o.d, 1, f) == 1;
+    blob.resize(e.h.blob_bytes);
+    ok = ok && (!e.h.blob_bytes || fread(blob.data(), 1, blob.size(), f) == blob.size());
+  }
+  fclose(f);
+  if (!ok) return -UNINA_ERR_FORMAT;
+  for (auto& o : e.ops) {
+    if (o.d.src_buf >= e.h.n_buffers || o.d.nseg < 1 || o.d.nseg > 2 || o.d.res_buf >= (int)e.h.n_buffers) return -UNINA_ERR_FORMAT;
+    for (uint32_t s = 0; s < o.d.nseg; ++s)
+      if (o.d.seg[s].dst_buf >= e.h.n_buffers || o.d.seg[s].w_off > blob.size() || o.d.seg[s].b_off > blob.size()) return -UNINA_ERR_FORMAT;
+  }
+  if (e.h.precision == kFp16) find_c3k2_groups(&e, &blob);
+  return e.n_groups;
+}
+
+int unina_set_fusion(unina_engine_t* e, int enable) {
+  if (!e) return UNINA_ERR_ARG;
+  const bool on = enable && e->n_groups > 0;
+  if (on != e->fuse) {
+    e->fuse = on;
+    e->plan_dirty = true;
+  }
+  return UNINA_OK;
+}
+
+int unina_fusion_groups(const unina_engine_t* e) { return e ? (e->fuse ? e->n_groups : 0) : -1; }
+
 int unina_conv_config_count(void) { return (int)kCfgCount; }
 
 const char* unina_conv_config_name(int cfg) { return conv_config_name(cfg, kF16); }
@@ -750,7 +959,7 @@ int unina_autotune(unina_engine_t* e, int iters, hipStream_t stream) {
   HIPCHK(e, hipEventCreate(&a));
   HIPCHK(e, hipEventCreate(&b));
   for (size_t i = 0; i < e->ops.size(); ++i) {
-    if (e->ops[i].d.kind != kOpConv) continue;
+    if (e->ops[i].d.kind != kOpConv || (e->fuse && e->ops[i].fuse_role)) continue;
     float best = 1e30f;
     int best_cfg = -1;
     for (int cfg = 0; cfg < (int)kCfgCount; ++cfg) {
@@ -790,6 +999,10 @@ int unina_profile_ops(unina_engine_t* e, int iters, float* ms_per_op, hipStream_
   HIPCHK(e, hipEventCreate(&a));
   HIPCHK(e, hipEventCreate(&b));
   for (size_t i = 0; i < e->ops.size(); ++i) {
+    if (e->fuse && e->ops[i].fuse_role == 2) {
+      ms_per_op[i] = 0.f;
+      continue;
+    }
     HIPCHK(e, launch_op(e, i, stream));
     HIPCHK(e, hipEventRecord(a, stream));
     for (int it = 0; it < iters; ++it) HIPCHK(e, launch_op(e, i, stream));

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <vector>
 
 #include "../../include/unina_mi355.h"
 
@@ -74,6 +75,39 @@ ConvLaunch conv_plan(const ConvParams& p);               // heuristic (or p.forc
 ConvLaunch conv_plan_with(const ConvParams& p, int cfg);
 const char* conv_config_name(int cfg, int dtype = kF16);
 hipError_t conv_launch(const ConvParams& p, const ConvLaunch& l, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// Fused C3k2 block (model.py:76-110): cv1|cv2 -> n x Bottleneck(1x1, 3x3 + shortcut) -> cv3 in ONE launch, all
+// intermediates in LDS (c3k2_fused.hip). fp16 engines only.
+// ------------------------------------------------------------------------------------------------
+struct C3k2Params {
+  const half_t* src;             // block input, channel offset applied
+  int src_ld, Cin;
+  int H, W;                      // spatial size (input == output)
+  half_t* dst;                   // block output (cv3), channel offset applied
+  int dst_ld;
+  const unsigned char* wstream;  // stage stream of every conv's weights in consumption order (c3k2_pack)
+  const float* bias;             // concatenated folded biases, same order
+  const void* zeros;             // >= 16 bytes of zeros in HBM
+  int hid, nb;                   // hidden width h = Cout/2, number of bottlenecks
+  // filled by c3k2_layout():
+  int n_bias, total_stages;
+  int tiles_x, tiles_y;
+  unsigned tiles_x_magic, nchx_magic;
+  int off_bias, off_ring, off_x, off_y, off_t, off_u1, off_u2, off_stage, smem_bytes;   // LDS layout (bytes)
+};
+struct C3k2Conv {                // one conv of the block as the exporter stored it (host pointers)
+  const unsigned char* w[2];     // packed 1-KiB fragment blocks [n/16][K/32] per output slice (slice 1 only for cv1|cv2)
+  const float* bias[2];
+  int n[2];                      // output channels per slice (multiples of 16)
+  int K;                         // ksize*ksize*cin
+};
+hipError_t c3k2_init();
+bool c3k2_layout(C3k2Params* p);
+bool c3k2_supported(int hid, int nb, int cin);
+bool c3k2_pack(int hid, int nb, int cin, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias);
+hipError_t c3k2_launch(const C3k2Params& p, hipStream_t stream);
+const char* c3k2_kernel_name(int hid, int nb);
 
 // ------------------------------------------------------------------------------------------------
 // Stem: fp32 NCHW image -> 3x3/s2 conv (Cin=3) + bias + ReLU -> NHWC fp16

@@ -49,6 +49,7 @@ ABI_SYMBOLS = [
     "unina_tensor_address", "unina_enqueue", "unina_infer", "unina_infer_async", "unina_postprocess_async",
     "unina_last_error", "unina_op_count", "unina_get_op_info", "unina_profile_ops", "unina_debug_read_buffer",
     "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune", "unina_debug_post_stamps", "unina_debug_conv_stamps",
+    "unina_set_fusion", "unina_fusion_groups", "unina_debug_fusable_groups",
     "create_norm_params_imagenet", "create_norm_params", "preprocess_bgra_resize", "preprocess_bgra", "preprocess_nv12",
     "allocate_preprocess_buffer", "free_preprocess_buffer", "create_preprocess_stream", "destroy_preprocess_stream",
     "init_postprocess_resources", "cleanup_postprocess_resources", "reset_detection_counter", "get_detection_count",
@@ -87,6 +88,9 @@ def load_library() -> C.CDLL:
     L.unina_conv_config_name.argtypes = [ci]
     L.unina_set_op_config.argtypes = [vp, ci, ci]
     L.unina_autotune.argtypes = [vp, ci, vp]
+    L.unina_set_fusion.argtypes = [vp, ci]
+    L.unina_fusion_groups.argtypes = [vp]
+    L.unina_debug_fusable_groups.argtypes = [C.c_char_p]
     L.unina_debug_post_stamps.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.unina_debug_conv_stamps.argtypes = [vp, ci, C.POINTER(C.c_longlong), vp]
     # cuda_preprocess.h drop-in symbols
@@ -312,6 +316,12 @@ class Engine:
         self._check(rc)
         return True
 
+    def set_fusion(self, enable: bool) -> int:
+        """C3k2 block fusion on/off (bit-identical results; off = every internal buffer is written, for per-layer
+        checks and calibration). Returns the number of blocks now running as one launch."""
+        self._check(self.L.unina_set_fusion(self.h, int(bool(enable))))
+        return self.L.unina_fusion_groups(self.h)
+
     def read_buffer(self, name: str) -> np.ndarray:
         """Internal activation buffer -> [C,H,W] fp32 (parity tests)."""
         c, h, w = C.c_int(-1), C.c_int(), C.c_int()
@@ -333,6 +343,7 @@ def calibrate_amax(sd: Dict[str, np.ndarray], graph: Optional[Graph], frames, de
     b = _export.EngineBuilder(sd, graph)
     names = [n for (n, _h, _w, _c, dtype, _f, _s) in b.buffers if dtype == _export.BUF_F16]
     eng = Engine.from_state_dict(sd, graph, device)
+    eng.set_fusion(False)          # every internal buffer must be written: the calibrator reads them all
     try:
         def per_frame():
             for x in frames:
