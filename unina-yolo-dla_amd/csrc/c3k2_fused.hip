@@ -1,20 +1,26 @@
 // c3k2_fused.hip -- one launch for a whole C3k2 block (reference: unina_yolo_dla/model.py:76-110, Bottleneck :53-73).
 //
-//     a | b = ReLU(BN(cv1(x))) | ReLU(BN(cv2(x)))                 1x1, Cin -> h | h          (step S1, one GEMM, N = 2h)
-//     for each bottleneck:  t = ReLU(BN(b.cv1(a)))                1x1, h -> h                (S2)
-//                           a = ReLU(BN(b.cv2(t))) + a            3x3, h -> h, pad 1         (S3)
-//     y = ReLU(BN(cv3(cat[a, b])))                                1x1, 2h -> 2h              (S4)
+//     a | b = ReLU(BN(cv1(x))) | ReLU(BN(cv2(x)))                 1x1, Cin -> h | h          (step 0, one GEMM, N = 2h)
+//     for each bottleneck:  t = ReLU(BN(b.cv1(a)))                1x1, h -> h                (odd steps)
+//                           a = ReLU(BN(b.cv2(t))) + a            3x3, h -> h, pad 1         (even steps)
+//     y = ReLU(BN(cv3(cat[a, b])))                                1x1, 2h -> 2h              (last step)
 //
 // The unfused op table runs this as 2 + 2n launches that each sit on the ~4 us launch / latency floor. Here a
 // workgroup owns a TH x TW tile of the block's output and keeps every intermediate tensor of its tile IN LDS:
-//   * the input patch (tile + n-pixel halo, all Cin channels) is DMA'd into LDS once;
-//   * every step is an MFMA GEMM whose B operand (activations, pixels as columns) is read from an LDS image and whose
-//     A operand (weights) streams from L2 through an LDS-DMA ring that never stops between steps: the weights of all
-//     steps are ONE flat stream of fixed-size stages (packed by the host in consumption order, c3k2_pack), so the
-//     next step's weights are already landing while the current step's epilogue runs;
+//   * the input patch (tile + n-pixel halo, all Cin channels) is DMA'd into LDS once (global_load_lds);
+//   * every step is an MFMA GEMM whose B operand (activations, pixels as columns) is read from an LDS image;
+//   * the A operand (weights) never touches LDS: a wave owns ONE 16-channel subtile of a step's output, so each
+//     1-KiB weight fragment block is needed by exactly that wave (x the few waves that split the pixels) and is
+//     loaded straight from L2 into its registers, 16 bytes per lane. All steps' blocks form one flat per-wave
+//     sequence (packed by c3k2_pack in consumption order) that is prefetched D blocks ahead through a circular
+//     register queue ACROSS step boundaries -- weights depend on nothing, so the L2 latency is paid once per launch
+//     and the bytes in flight per CU are D KiB x waves, not an LDS ring (the first version streamed weights through
+//     a 48 KiB LDS-DMA ring and was bound by DMA issue rate and ring depth: 33 us for the 917 KB of stage3's block);
 //   * epilogues (bias, ReLU, zero outside the image = the 3x3's zero padding, residual) write fp16 LDS images;
 //     only cv3's output goes to HBM (staged through LDS, full 16-byte row segments).
-// The 1x1 convs in front of a 3x3 are recomputed on the halo (1.27-1.9x of their small cost).
+// The 1x1 convs in front of a 3x3 are recomputed on the halo (1.27-1.9x of their small cost). Every loop is
+// unrolled at compile time (shapes, including Cin, are template parameters), so queue slots are plain registers and
+// the compiler's own counted s_waitcnt vmcnt tracks the prefetches.
 // Arithmetic is identical to the unfused kernels: same MFMA (v_mfma_f32_16x16x32_f16), same K order (tap-major, 32
 // channels per block), same fp32 epilogue and the same fp16 rounding points -> results are bit-identical (tested).
 //
@@ -42,85 +48,47 @@ __host__ __device__ constexpr Img make_img(int base, int nch) {
   return (nch % 16 == 0) ? Img{base, nch, 0, 15} : ((nch % 8 == 0) ? Img{base, nch, 1, 7} : Img{base, nch, 2, 3});
 }
 
-template <int SB, int RING>
-struct Pipe {
-  static constexpr int LPT = SB / 4, STAGE_BYTES = SB * 1024;
-  const unsigned char* gsrc;  // this lane's source address inside stage 0 (block wid, slot lane)
-  unsigned char* ring;        // LDS: RING stage buffers
-  int total, issued, cur, ibuf, cbuf, wid;
-
-  __device__ __forceinline__ void issue() {
-    const unsigned char* g = gsrc + (size_t)issued * STAGE_BYTES;
-    unsigned char* l = ring + ibuf * STAGE_BYTES + wid * 1024;
-#pragma unroll
-    for (int q = 0; q < LPT; ++q) glds16(g + q * 4096, l + q * 4096);
-    ++issued;
-    ibuf = ibuf + 1 == RING ? 0 : ibuf + 1;
+// ---- compile-time description of the block's GEMM steps -----------------------------------------------------------
+// step 0: cv1|cv2 (K = CIN, N = 2h); odd steps: bottleneck 1x1 (K = h, N = h); even steps: bottleneck 3x3 (K = 9h,
+// N = h); last step: cv3 (K = 2h, N = 2h). kb = K / 32 weight blocks per 16-channel subtile, ns = N / 16 subtiles.
+template <int H_, int NB, int CIN, int NW>
+struct Steps {
+  static constexpr int N = 2 + 2 * NB;
+  static constexpr int kb(int s) { return s == 0 ? CIN / 32 : (s == N - 1 ? 2 * H_ / 32 : ((s & 1) ? H_ / 32 : 9 * H_ / 32)); }
+  static constexpr int ns(int s) { return (s == 0 || s == N - 1) ? 2 * H_ / 16 : H_ / 16; }
+  // wave roles: every wave works in every step. waves_n waves split the channel subtiles (wnt each), the remaining
+  // factor waves_m splits the pixels (those waves load the same weight blocks: L1 serves the repeats).
+  static constexpr int waves_n(int s) { return ns(s) < NW ? ns(s) : NW; }
+  static constexpr int wnt(int s) { return ns(s) / waves_n(s); }
+  static constexpr int waves_m(int s) { return NW / waves_n(s); }
+  static constexpr int first(int s) {  // index of step s' first block in a wave's flat weight sequence
+    int t = 0;
+    for (int i = 0; i < s; ++i) t += kb(i) * wnt(i);
+    return t;
   }
-  // Stage `cur` is usable after this: its DMA has landed in every wave's view (counted vmcnt + barrier); the same
-  // barrier retires every wave's reads of stage cur-1 (its buffer is refilled here) and publishes the LDS writes of
-  // the previous step's epilogue (lgkmcnt(0) first).
-  __device__ __forceinline__ void acquire() {
-    wait_stages<LPT>(issued - cur - 1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (issued < total) issue();
+  static constexpr int total() { return first(N); }
+  static constexpr int blk(int s) {    // offset of step s in the packed stream, in 1-KiB blocks
+    int t = 0;
+    for (int i = 0; i < s; ++i) t += kb(i) * ns(i);
+    return t;
   }
-  __device__ __forceinline__ const unsigned char* stage() const { return ring + cbuf * STAGE_BYTES; }
-  __device__ __forceinline__ void release() {
-    ++cur;
-    cbuf = cbuf + 1 == RING ? 0 : cbuf + 1;
+  static constexpr int step_of(int g) {
+    int s = 0;
+    while (s < N - 1 && g >= first(s + 1)) ++s;
+    return s;
   }
 };
 
-constexpr int waves_m_for(int P) { return ((P + 15) / 16 >= 8) ? 4 : 2; }
-constexpr int stages_of(int kb, int n, int sb) { return (kb + sb / (n / 16) - 1) / (sb / (n / 16)); }
-
-// One GEMM step: D[N channels][P pixels] = sum over KB k-blocks of W-block x X-block.
-//   baddr(sub, kb) : LDS byte address of this lane's 16-byte B fragment of pixel subtile `sub`, k-block kb
-//   epi(sub, n, acc): consumes the 4 channels n..n+3 of pixel sub*16 + (lane & 15)
-template <int P, int N, int SB, int RING, typename BAddr, typename Epi>
-__device__ __forceinline__ void gemm_step(Pipe<SB, RING>& pipe, const unsigned char* smem, int KB, int lane, int wid,
-                                          BAddr baddr, Epi epi) {
-  constexpr int WAVES_M = waves_m_for(P), WAVES_N = 4 / WAVES_M;
-  constexpr int MS = (P + 15) / 16, NS = N / 16;
-  constexpr int WM_T = (MS + WAVES_M - 1) / WAVES_M, WN_T = NS / WAVES_N, KPS = SB / NS;
-  static_assert(NS % WAVES_N == 0 && SB % NS == 0 && KPS >= 1, "step tiling");
-  const int wm = wid % WAVES_M, wn = wid / WAVES_M;
-  const int l15 = lane & 15, lq = lane >> 4;
-  const int rd_off = (4 * l15 + (lq ^ swz_g(l15))) * 16;
-  floatx4 acc[WN_T][WM_T];
-#pragma unroll
-  for (int j = 0; j < WN_T; ++j)
-#pragma unroll
-    for (int i = 0; i < WM_T; ++i) acc[j][i] = floatx4{0.f, 0.f, 0.f, 0.f};
-  const int nst = (KB + KPS - 1) / KPS;
-  for (int s = 0; s < nst; ++s) {
-    pipe.acquire();
-    const unsigned char* sb = pipe.stage() + rd_off;
-#pragma unroll
-    for (int jk = 0; jk < KPS; ++jk) {
-      int kb = s * KPS + jk;
-      kb = kb < KB ? kb : KB - 1;  // zero-padded weight blocks past the end: multiply finite data by 0
-      half8 a[WN_T], b[WM_T];
-#pragma unroll
-      for (int i = 0; i < WM_T; ++i) b[i] = *reinterpret_cast<const half8*>(smem + baddr(wm * WM_T + i, kb));
-#pragma unroll
-      for (int j = 0; j < WN_T; ++j) a[j] = *reinterpret_cast<const half8*>(sb + ((jk * NS + wn * WN_T + j) << 10));
-#pragma unroll
-      for (int j = 0; j < WN_T; ++j)
-#pragma unroll
-        for (int i = 0; i < WM_T; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[i], acc[j][i], 0, 0, 0);
-    }
-    pipe.release();
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
   }
-#pragma unroll
-  for (int j = 0; j < WN_T; ++j)
-#pragma unroll
-    for (int i = 0; i < WM_T; ++i)
-      if (wm * WM_T + i < MS) epi(wm * WM_T + i, (wn * WN_T + j) * 16 + lq * 4, acc[j][i]);
 }
+
+constexpr int imin(int a, int b) { return a < b ? a : b; }
+constexpr int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 
 __device__ __forceinline__ floatx4 bias_relu(const floatx4& acc, const float* bias_lds, int n) {
   floatx4 v = acc + *reinterpret_cast<const floatx4*>(bias_lds + n);
@@ -138,20 +106,29 @@ __device__ __forceinline__ floatx4 load_h4(const unsigned char* smem, const Img&
   const half4 hv = *reinterpret_cast<const half4*>(smem + im.addr(row, n >> 3) + (n & 4) * 2);
   return floatx4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
 }
+__device__ __forceinline__ void lds_barrier() {  // publishes this wave's LDS writes; does NOT drain the weight prefetches
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 
 }  // namespace
 
 extern __shared__ __align__(16) unsigned char c3_smem[];
 
-template <int H_, int TH, int TW, int NB>
-__global__ __launch_bounds__(256) void c3k2_fused_kernel(const C3k2Params p) {
+// NW waves per workgroup (roles per step: Steps::waves_n / wnt / waves_m); D = weight prefetch depth in 1-KiB blocks
+// per wave. There is no wave-uniform branch around any global load: the kernel is straight-line code, so the
+// compiler's counted s_waitcnt vmcnt keeps D loads in flight across every step boundary.
+template <int H_, int TH, int TW, int NB, int CIN, int NW, int D>
+__global__ __launch_bounds__(NW * 64) void c3k2_fused_kernel(const C3k2Params p) {
   static_assert(NB == 1 || NB == 2, "bottleneck count");
-  constexpr int SB = H_ >= 128 ? 16 : 8, RING = H_ >= 128 ? 3 : 4;
+  typedef Steps<H_, NB, CIN, NW> ST;
+  static_assert((NW & (NW - 1)) == 0 && NW >= 2 && NW <= 16, "waves per workgroup");
   constexpr int R0W = TW + 2 * NB, P0 = (TH + 2 * NB) * R0W;   // input / first-level region (tile + NB-pixel halo)
   constexpr int R1W = TW + 2, P1 = (TH + 2) * R1W;              // NB == 2: region of the first bottleneck's output
   constexpr int PT = TH * TW;
   constexpr int HB = H_ / 32;                                   // k-blocks per tap of the hidden width
-  typedef Pipe<SB, RING> PipeT;
+  constexpr int NT = NW * 64;
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -161,19 +138,31 @@ __global__ __launch_bounds__(256) void c3k2_fused_kernel(const C3k2Params p) {
   const int ty0 = tyi * TH, tx0 = txi * TW;
   const half_t* zeros = reinterpret_cast<const half_t*>(p.zeros);
 
-  // biases of every step -> LDS (read by the epilogues without touching the vmcnt bookkeeping of the ring)
+  // ---- weight prefetch queue: element g of this wave's flat sequence lives in slot g % D ----
+  const unsigned char* wbase = p.wstream + (4 * l15 + (lq ^ swz_g(l15))) * 16;   // this lane's 16 bytes of any block
+  half8 q[D];
+  auto fetch = [&](auto gc) {
+    constexpr int g = decltype(gc)::value;
+    if constexpr (g < ST::total()) {
+      constexpr int s = ST::step_of(g), e = g - ST::first(s), wnt = ST::wnt(s), kb = e / wnt, j = e - kb * wnt, ns = ST::ns(s);
+      const int nsub = (wid % ST::waves_n(s)) * wnt + j;
+      q[g % D] = *reinterpret_cast<const half8*>(wbase + (size_t)(ST::blk(s) + kb * ns + nsub) * 1024);
+    }
+  };
+
+  // biases of every step -> LDS
   float* bias_lds = reinterpret_cast<float*>(smem + p.off_bias);
-  for (int i = threadIdx.x; i < p.n_bias; i += 256) bias_lds[i] = p.bias[i];
+  for (int i = threadIdx.x; i < p.n_bias; i += NT) bias_lds[i] = p.bias[i];
 
   // input patch: 16-byte slot s = (region pixel r, chunk cs); out-of-image pixels read the zero page
-  const Img X = make_img(p.off_x, p.Cin >> 3);
+  constexpr Img X = make_img(0, CIN / 8);
   {
-    const int nchx = p.Cin >> 3, nslots = P0 * nchx;
-    for (int s0 = wid * 64; s0 < nslots; s0 += 256) {
+    constexpr int nchx = CIN / 8, nslots = P0 * nchx;
+    for (int s0 = wid * 64; s0 < nslots; s0 += NT) {
       const int s = s0 + lane;
       const half_t* g = zeros;
       if (s < nslots) {
-        const int r = fast_div(s, p.nchx_magic), cs = s - r * nchx;
+        const int r = s / nchx, cs = s - r * nchx;
         const int ry = r / R0W, rx = r - ry * R0W;
         const int iy = ty0 - NB + ry, ix = tx0 - NB + rx;
         if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
@@ -182,27 +171,71 @@ __global__ __launch_bounds__(256) void c3k2_fused_kernel(const C3k2Params p) {
       glds16(g, smem + p.off_x + s0 * 16);
     }
   }
+  static_for<0, D>(fetch);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed (LDS-DMA is not tracked by the compiler)
+  lds_barrier();
 
-  PipeT pipe;
-  pipe.gsrc = p.wstream + wid * 1024 + lane * 16;
-  pipe.ring = smem + p.off_ring;
-  pipe.total = p.total_stages;
-  pipe.issued = pipe.cur = pipe.ibuf = pipe.cbuf = 0;
-  pipe.wid = wid;
-  for (int s = 0; s < RING - 1 && s < pipe.total; ++s) pipe.issue();
-
+  const Img Xi = Img{p.off_x, X.nch, X.sh, X.mask};
   const Img Y = make_img(p.off_y, 2 * H_ / 8);   // a | b on R0
   const Img T = make_img(p.off_t, H_ / 8);       // t of the current bottleneck (R0, then R1)
   const Img U1 = make_img(p.off_u1, H_ / 8);     // NB == 2: first bottleneck's output on R1
   const Img U2 = make_img(p.off_u2, H_ / 8);     // last bottleneck's output on the tile
   auto in_image = [&](int iy, int ix) { return (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W; };
 
-  // ---- S1: a | b = ReLU(W12 x + b12) on R0 ------------------------------------------------------------------------
-  gemm_step<P0, 2 * H_, SB, RING>(
-      pipe, smem, p.Cin >> 5, lane, wid,
-      [&](int sub, int kb) {
+  // One GEMM step S over P pixels:  baddr(sub, kb) = LDS byte address of this lane's B fragment of pixel subtile
+  // `sub` / k-block kb (kb is a compile-time constant);  epi(sub, n, acc) consumes channels n..n+3 of pixel
+  // sub*16 + l15. Ends with the barrier that publishes the epilogue's LDS writes.
+  auto run_step = [&](auto sc, auto pc, auto baddr, auto epi) {
+    constexpr int S = decltype(sc)::value, P = decltype(pc)::value;
+    constexpr int KB = ST::kb(S), G0 = ST::first(S), WN_T = ST::wnt(S), WVN = ST::waves_n(S), WVM = ST::waves_m(S);
+    constexpr int MS = (P + 15) / 16, WM_T = (MS + WVM - 1) / WVM;
+    constexpr bool DB = WM_T <= 6;   // B fragments double-buffered in registers when they fit comfortably
+    const int wm = wid / WVN, wn = wid % WVN;
+    floatx4 acc[WN_T][WM_T];
+    half8 b[2][WM_T];
+#pragma unroll
+    for (int i = 0; i < WM_T; ++i) {
+#pragma unroll
+      for (int j = 0; j < WN_T; ++j) acc[j][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (DB) b[0][i] = *reinterpret_cast<const half8*>(smem + baddr(wm * WM_T + i, std::integral_constant<int, 0>{}));
+    }
+    static_for<0, KB>([&](auto kc) {
+      constexpr int kb = decltype(kc)::value;
+      half8 a[WN_T];
+#pragma unroll
+      for (int j = 0; j < WN_T; ++j) a[j] = q[(G0 + kb * WN_T + j) % D];
+      static_for<0, WN_T>([&](auto jc) { fetch(std::integral_constant<int, G0 + kb * WN_T + decltype(jc)::value + D>{}); });
+      if constexpr (DB) {
+        if constexpr (kb + 1 < KB) {
+#pragma unroll
+          for (int i = 0; i < WM_T; ++i)
+            b[(kb + 1) & 1][i] = *reinterpret_cast<const half8*>(smem + baddr(wm * WM_T + i, std::integral_constant<int, kb + 1>{}));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < WM_T; ++i) b[kb & 1][i] = *reinterpret_cast<const half8*>(smem + baddr(wm * WM_T + i, kc));
+      }
+#pragma unroll
+      for (int j = 0; j < WN_T; ++j)
+#pragma unroll
+        for (int i = 0; i < WM_T; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[kb & 1][i], acc[j][i], 0, 0, 0);
+    });
+#pragma unroll
+    for (int j = 0; j < WN_T; ++j)
+#pragma unroll
+      for (int i = 0; i < WM_T; ++i)
+        if (wm * WM_T + i < MS) epi(wm * WM_T + i, (wn * WN_T + j) * 16 + lq * 4, acc[j][i]);
+    lds_barrier();
+  };
+  auto I = [](auto v) { return v; };
+  (void)I;
+#define STEP(S, P) std::integral_constant<int, (S)>{}, std::integral_constant<int, (P)>{}
+
+  // ---- step 0: a | b = ReLU(W12 x + b12) on R0 --------------------------------------------------------------------
+  run_step(STEP(0, P0),
+      [&](int sub, auto kc) {
         const int r = sub * 16 + l15;
-        return X.addr(r < P0 ? r : P0 - 1, kb * 4 + lq);
+        return Xi.addr(r < P0 ? r : P0 - 1, decltype(kc)::value * 4 + lq);
       },
       [&](int sub, int n, const floatx4& acc) {
         const int r = sub * 16 + l15;
@@ -211,12 +244,11 @@ __global__ __launch_bounds__(256) void c3k2_fused_kernel(const C3k2Params p) {
   const float* bias_b = bias_lds + 2 * H_;
 
   // ---- bottleneck 0 -----------------------------------------------------------------------------------------------
-  // S2: t = ReLU(Wb1 a + b) on R0, forced to 0 outside the image (zero padding of the 3x3 that follows)
-  gemm_step<P0, H_, SB, RING>(
-      pipe, smem, HB, lane, wid,
-      [&](int sub, int kb) {
+  // t = ReLU(Wb1 a + b) on R0, forced to 0 outside the image (zero padding of the 3x3 that follows)
+  run_step(STEP(1, P0),
+      [&](int sub, auto kc) {
         const int r = sub * 16 + l15;
-        return Y.addr(r < P0 ? r : P0 - 1, kb * 4 + lq);
+        return Y.addr(r < P0 ? r : P0 - 1, decltype(kc)::value * 4 + lq);
       },
       [&](int sub, int n, const floatx4& acc) {
         const int r = sub * 16 + l15;
@@ -227,14 +259,13 @@ __global__ __launch_bounds__(256) void c3k2_fused_kernel(const C3k2Params p) {
         store_h4(smem, T, r, n, v);
       });
   if constexpr (NB == 1) {
-    // S3: u = ReLU(3x3(t) + b) + a on the tile
-    gemm_step<PT, H_, SB, RING>(
-        pipe, smem, 9 * HB, lane, wid,
-        [&](int sub, int kb) {
+    // u = ReLU(3x3(t) + b) + a on the tile
+    run_step(STEP(2, PT),
+        [&](int sub, auto kc) {
+          constexpr int kb = decltype(kc)::value, tap = kb / HB, cb = kb - tap * HB, th3 = tap / 3;
           int pp = sub * 16 + l15;
           pp = pp < PT ? pp : PT - 1;
           const int py = pp / TW, px = pp - py * TW;
-          const int tap = kb / HB, cb = kb - tap * HB, th3 = tap / 3;
           return T.addr((py + th3) * R0W + px + (tap - th3 * 3), cb * 4 + lq);
         },
         [&](int sub, int n, const floatx4& acc) {
@@ -245,14 +276,13 @@ __global__ __launch_bounds__(256) void c3k2_fused_kernel(const C3k2Params p) {
           store_h4(smem, U2, pp, n, v);
         });
   } else {
-    // S3a: u1 = ReLU(3x3(t1) + b) + a on R1
-    gemm_step<P1, H_, SB, RING>(
-        pipe, smem, 9 * HB, lane, wid,
-        [&](int sub, int kb) {
+    // u1 = ReLU(3x3(t1) + b) + a on R1
+    run_step(STEP(2, P1),
+        [&](int sub, auto kc) {
+          constexpr int kb = decltype(kc)::value, tap = kb / HB, cb = kb - tap * HB, th3 = tap / 3;
           int pp = sub * 16 + l15;
           pp = pp < P1 ? pp : P1 - 1;
           const int py = pp / R1W, px = pp - py * R1W;
-          const int tap = kb / HB, cb = kb - tap * HB, th3 = tap / 3;
           return T.addr((py + th3) * R0W + px + (tap - th3 * 3), cb * 4 + lq);
         },
         [&](int sub, int n, const floatx4& acc) {
@@ -264,12 +294,11 @@ __global__ __launch_bounds__(256) void c3k2_fused_kernel(const C3k2Params p) {
         });
     // ---- bottleneck 1 ---------------------------------------------------------------------------------------------
     const float* bias_c = bias_b + 2 * H_;
-    // S2b: t2 = ReLU(Wb1' u1 + b) on R1, 0 outside the image
-    gemm_step<P1, H_, SB, RING>(
-        pipe, smem, HB, lane, wid,
-        [&](int sub, int kb) {
+    // t2 = ReLU(Wb1' u1 + b) on R1, 0 outside the image
+    run_step(STEP(3, P1),
+        [&](int sub, auto kc) {
           const int r = sub * 16 + l15;
-          return U1.addr(r < P1 ? r : P1 - 1, kb * 4 + lq);
+          return U1.addr(r < P1 ? r : P1 - 1, decltype(kc)::value * 4 + lq);
         },
         [&](int sub, int n, const floatx4& acc) {
           const int r = sub * 16 + l15;
@@ -279,14 +308,13 @@ __global__ __launch_bounds__(256) void c3k2_fused_kernel(const C3k2Params p) {
           if (!in_image(ty0 - 1 + ry, tx0 - 1 + rx)) v = floatx4{0.f, 0.f, 0.f, 0.f};
           store_h4(smem, T, r, n, v);
         });
-    // S3b: u2 = ReLU(3x3(t2) + b) + u1 on the tile
-    gemm_step<PT, H_, SB, RING>(
-        pipe, smem, 9 * HB, lane, wid,
-        [&](int sub, int kb) {
+    // u2 = ReLU(3x3(t2) + b) + u1 on the tile
+    run_step(STEP(4, PT),
+        [&](int sub, auto kc) {
+          constexpr int kb = decltype(kc)::value, tap = kb / HB, cb = kb - tap * HB, th3 = tap / 3;
           int pp = sub * 16 + l15;
           pp = pp < PT ? pp : PT - 1;
           const int py = pp / TW, px = pp - py * TW;
-          const int tap = kb / HB, cb = kb - tap * HB, th3 = tap / 3;
           return T.addr((py + th3) * R1W + px + (tap - th3 * 3), cb * 4 + lq);
         },
         [&](int sub, int n, const floatx4& acc) {
@@ -298,19 +326,21 @@ __global__ __launch_bounds__(256) void c3k2_fused_kernel(const C3k2Params p) {
         });
   }
 
-  // ---- S4: y = ReLU(W3 [u | b] + b3) on the tile -> staging image (linear rows) -> HBM ----------------------------
+  // ---- last step: y = ReLU(W3 [u | b] + b3) on the tile -> staging image (linear rows) -> HBM ----------------------
   constexpr int ROWB = 2 * H_ * 2 + 16;  // staged output row: 2h halfs + 16 bytes of padding (bank spread)
   unsigned char* stage = smem + p.off_stage;
   const float* bias_3 = bias_lds + 2 * H_ * (1 + NB);
-  gemm_step<PT, 2 * H_, SB, RING>(
-      pipe, smem, 2 * HB, lane, wid,
-      [&](int sub, int kb) {
+  run_step(STEP(ST::N - 1, PT),
+      [&](int sub, auto kc) {
+        constexpr int kb = decltype(kc)::value;
         int pp = sub * 16 + l15;
         pp = pp < PT ? pp : PT - 1;
-        const int py = pp / TW, px = pp - py * TW;
-        const int a0 = U2.addr(pp, kb * 4 + lq);                                            // k-blocks [0, h/32): u
-        const int a1 = Y.addr((py + NB) * R0W + px + NB, H_ / 8 + (kb - HB) * 4 + lq);      // k-blocks [h/32, 2h/32): b
-        return kb < HB ? a0 : a1;
+        if constexpr (kb < HB) {                                  // k-blocks [0, h/32): u
+          return U2.addr(pp, kb * 4 + lq);
+        } else {                                                  // k-blocks [h/32, 2h/32): b = channels [h, 2h) of Y
+          const int py = pp / TW, px = pp - py * TW;
+          return Y.addr((py + NB) * R0W + px + NB, H_ / 8 + (kb - HB) * 4 + lq);
+        }
       },
       [&](int sub, int n, const floatx4& acc) {
         const int pp = sub * 16 + l15;
@@ -321,12 +351,10 @@ __global__ __launch_bounds__(256) void c3k2_fused_kernel(const C3k2Params p) {
         for (int r = 0; r < 4; ++r) hv[r] = (half_t)v[r];
         *reinterpret_cast<half4*>(stage + pp * ROWB + n * 2) = hv;
       });
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+#undef STEP
   typedef float vec16 __attribute__((ext_vector_type(4)));  // 16 opaque bytes
   constexpr int CPR = 2 * H_ * 2 / 16;                      // 16-byte chunks per output pixel
-  for (int c = threadIdx.x; c < PT * CPR; c += 256) {
+  for (int c = threadIdx.x; c < PT * CPR; c += NT) {
     const int pp = c / CPR, ch = c - pp * CPR;
     const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
     if (oy < p.H && ox < p.W)
@@ -339,19 +367,25 @@ __global__ __launch_bounds__(256) void c3k2_fused_kernel(const C3k2Params p) {
 namespace {
 
 struct Class {
-  int hid, nb, th, tw, sb, ring;
+  int hid, nb, cin, th, tw, nw;
+  const char* name;
   void (*fn)(const C3k2Params);
 };
+#define C3K2(H_, TH, TW, NB, CIN, NW, D) \
+  {H_, NB, CIN, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D>}
 const Class kClasses[] = {
-    {32, 1, 8, 16, 8, 4, c3k2_fused_kernel<32, 8, 16, 1>},
-    {64, 1, 8, 8, 8, 4, c3k2_fused_kernel<64, 8, 8, 1>},
-    {64, 2, 8, 8, 8, 4, c3k2_fused_kernel<64, 8, 8, 2>},
-    {128, 1, 4, 8, 16, 3, c3k2_fused_kernel<128, 4, 8, 1>},
-    {128, 2, 4, 8, 16, 3, c3k2_fused_kernel<128, 4, 8, 2>},
+    C3K2(32, 8, 16, 1, 64, 8, 4),      // backbone.stage1_block        160^2 at 640
+    C3K2(32, 8, 16, 1, 128, 8, 4),     // neck.fpn_c3k2_2
+    C3K2(64, 8, 8, 2, 128, 8, 8),      // backbone.stage2_c3k2          80^2
+    C3K2(64, 8, 8, 1, 256, 8, 8),      // neck.fpn_c3k2_1
+    C3K2(64, 8, 8, 1, 192, 8, 8),      // neck.pan_c3k2_1
+    C3K2(128, 4, 8, 2, 256, 8, 16),    // backbone.stage3_c3k2          40^2
+    C3K2(128, 4, 8, 1, 384, 8, 16),    // neck.pan_c3k2_2
 };
-const Class* find_class(int hid, int nb) {
+#undef C3K2
+const Class* find_class(int hid, int nb, int cin) {
   for (const Class& c : kClasses)
-    if (c.hid == hid && c.nb == nb) return &c;
+    if (c.hid == hid && c.nb == nb && c.cin == cin) return &c;
   return nullptr;
 }
 constexpr int kMaxLds = 160 * 1024;
@@ -371,32 +405,28 @@ bool c3k2_supported(int hid, int nb, int cin) {
   C3k2Params p;
   memset(&p, 0, sizeof p);
   p.hid = hid; p.nb = nb; p.Cin = cin; p.H = p.W = 64;
-  return cin % 64 == 0 && c3k2_layout(&p);
+  return c3k2_layout(&p);
 }
 
-// Fills tile geometry, stage counts and the LDS layout of `p` (needs hid, nb, Cin, H, W). False = no such class / no fit.
+// Fills tile geometry and the LDS layout of `p` (needs hid, nb, Cin, H, W). False = no such class / no fit.
 bool c3k2_layout(C3k2Params* p) {
-  const Class* c = find_class(p->hid, p->nb);
-  if (!c || p->Cin % 32) return false;
+  const Class* c = find_class(p->hid, p->nb, p->Cin);
+  if (!c) return false;
   const int h = p->hid, nb = p->nb;
   const int p0 = (c->th + 2 * nb) * (c->tw + 2 * nb), p1 = (c->th + 2) * (c->tw + 2), pt = c->th * c->tw;
   p->tiles_x = (p->W + c->tw - 1) / c->tw;
   p->tiles_y = (p->H + c->th - 1) / c->th;
   p->tiles_x_magic = div_magic((unsigned)p->tiles_x);
-  p->nchx_magic = div_magic((unsigned)(p->Cin / 8));
   p->n_bias = 2 * h * (2 + nb);
-  p->total_stages = stages_of(p->Cin / 32, 2 * h, c->sb) + nb * (stages_of(h / 32, h, c->sb) + stages_of(9 * h / 32, h, c->sb)) +
-                    stages_of(2 * h / 32, 2 * h, c->sb);
   const int x_bytes = align_up(p0 * p->Cin * 2, 1024) + 1024;  // the last patch DMA instruction may overrun by < 1 KiB
   const int t_bytes = p0 * h * 2, u1_bytes = nb == 2 ? p1 * h * 2 : 0, u2_bytes = pt * h * 2;
   const int stage_bytes = pt * (2 * h * 2 + 16);
-  // region A: the input patch; once S1 has consumed it, t (and later the output staging tile), u1 and u2 live there
+  // region A: the input patch; once step 0 has consumed it, t (and later the output staging tile), u1 and u2 live there
   const int head = t_bytes > stage_bytes ? t_bytes : stage_bytes;
   const int a_need = align_up(head, 16) + align_up(u1_bytes, 16) + align_up(u2_bytes, 16);
   const int a_bytes = x_bytes > a_need ? x_bytes : a_need;
   int off = 0;
   p->off_bias = off; off += align_up(p->n_bias * 4, 1024);
-  p->off_ring = off; off += c->ring * c->sb * 1024;
   p->off_x = off;
   p->off_t = off;
   p->off_stage = off;
@@ -409,12 +439,11 @@ bool c3k2_layout(C3k2Params* p) {
 }
 
 // Packs the weights of the block's convs (execution order: cv1|cv2, {b.cv1, b.cv2} x nb, cv3; each given as the
-// exporter's [n/16][K/32] 1-KiB fragment blocks) into the stage stream the kernel's ring consumes, and concatenates
-// the biases. Stage of a step with N output channels: SB blocks = (SB / (N/16)) k-blocks x (N/16) channel subtiles,
-// k-block-major; the tail of a step's last stage is zero blocks.
+// exporter's [n/16][K/32] 1-KiB fragment blocks) into the stream the kernel reads: per step, k-block-major
+// [K/32][N/16] blocks (the wave that owns subtile j of step s reads blocks blk(s) + kb*ns + j, kb = 0..), and
+// concatenates the biases.
 bool c3k2_pack(int hid, int nb, int cin, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias) {
-  const Class* c = find_class(hid, nb);
-  if (!c) return false;
+  if (!find_class(hid, nb, cin)) return false;
   stream->clear();
   bias->clear();
   const int nconv = 2 + 2 * nb;
@@ -424,17 +453,14 @@ bool c3k2_pack(int hid, int nb, int cin, const C3k2Conv* convs, std::vector<unsi
     const int want_n = (ci == 0 || ci == nconv - 1) ? 2 * hid : hid;
     const int want_k = ci == 0 ? cin : (ci == nconv - 1 ? 2 * hid : ((ci & 1) ? hid : 9 * hid));
     if (n != want_n || cv.K != want_k || cv.n[0] % 16 || cv.n[1] % 16) return false;
-    const int ns = n / 16, kbn = cv.K / 32, kps = c->sb / ns;
-    const int nst = (kbn + kps - 1) / kps;
+    const int ns = n / 16, kbn = cv.K / 32;
     const size_t base = stream->size();
-    stream->resize(base + (size_t)nst * c->sb * 1024, 0);
+    stream->resize(base + (size_t)kbn * ns * 1024, 0);
     for (int kb = 0; kb < kbn; ++kb)
       for (int s = 0; s < ns; ++s) {
         const int seg = s * 16 < cv.n[0] ? 0 : 1;
         const int ls = seg ? s - cv.n[0] / 16 : s;
-        const unsigned char* src = cv.w[seg] + ((size_t)ls * kbn + kb) * 1024;
-        unsigned char* dst = stream->data() + base + ((size_t)(kb / kps) * c->sb + (size_t)(kb % kps) * ns + s) * 1024;
-        memcpy(dst, src, 1024);
+        memcpy(stream->data() + base + ((size_t)kb * ns + s) * 1024, cv.w[seg] + ((size_t)ls * kbn + kb) * 1024, 1024);
       }
     for (int seg = 0; seg < 2; ++seg)
       for (int i = 0; i < cv.n[seg]; ++i) bias->push_back(cv.bias[seg][i]);
@@ -443,17 +469,20 @@ bool c3k2_pack(int hid, int nb, int cin, const C3k2Conv* convs, std::vector<unsi
 }
 
 hipError_t c3k2_launch(const C3k2Params& p, hipStream_t stream) {
-  const Class* c = find_class(p.hid, p.nb);
+  const Class* c = find_class(p.hid, p.nb, p.Cin);
   if (!c) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(c->fn, dim3(p.tiles_x * p.tiles_y, 1, 1), dim3(256, 1, 1), p.smem_bytes, stream, p);
+  hipLaunchKernelGGL(c->fn, dim3(p.tiles_x * p.tiles_y, 1, 1), dim3(c->nw * 64, 1, 1), p.smem_bytes, stream, p);
   return hipGetLastError();
 }
 
-const char* c3k2_kernel_name(int hid, int nb) {
-  static const char* names[] = {"c3k2_fused<32,8x16,1>", "c3k2_fused<64,8x8,1>", "c3k2_fused<64,8x8,2>",
-                                "c3k2_fused<128,4x8,1>", "c3k2_fused<128,4x8,2>"};
-  const Class* c = find_class(hid, nb);
-  return c ? names[c - kClasses] : "c3k2_fused<?>";
+const char* c3k2_kernel_name(int hid, int nb, int cin) {
+  const Class* c = find_class(hid, nb, cin);
+  return c ? c->name : "c3k2_fused<?>";
+}
+
+int c3k2_block_threads(int hid, int nb, int cin) {
+  const Class* c = find_class(hid, nb, cin);
+  return c ? c->nw * 64 : 0;
 }
 
 }  // namespace unina

@@ -306,8 +306,8 @@ int plan(unina_engine* e) {
     info.n = 2 * f.hid;
     info.k = 0;
     info.grid = f.tiles_x * f.tiles_y;
-    info.block = 256;
-    snprintf(info.kernel, sizeof info.kernel, "%s", c3k2_kernel_name(f.hid, f.nb));
+    info.block = c3k2_block_threads(f.hid, f.nb, f.Cin);
+    snprintf(info.kernel, sizeof info.kernel, "%s", c3k2_kernel_name(f.hid, f.nb, f.Cin));
     snprintf(info.name, sizeof info.name, "%.*s[c3k2 x%d]", (int)(strchr(a.name, '+') ? strchr(a.name, '+') - a.name - 4 : 60), a.name, f.nb);
   }
   e->plan_dirty = false;

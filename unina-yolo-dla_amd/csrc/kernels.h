@@ -86,15 +86,15 @@ struct C3k2Params {
   int H, W;                      // spatial size (input == output)
   half_t* dst;                   // block output (cv3), channel offset applied
   int dst_ld;
-  const unsigned char* wstream;  // stage stream of every conv's weights in consumption order (c3k2_pack)
+  const unsigned char* wstream;  // every conv's weight blocks in consumption order (c3k2_pack)
   const float* bias;             // concatenated folded biases, same order
   const void* zeros;             // >= 16 bytes of zeros in HBM
   int hid, nb;                   // hidden width h = Cout/2, number of bottlenecks
   // filled by c3k2_layout():
-  int n_bias, total_stages;
+  int n_bias;
   int tiles_x, tiles_y;
-  unsigned tiles_x_magic, nchx_magic;
-  int off_bias, off_ring, off_x, off_y, off_t, off_u1, off_u2, off_stage, smem_bytes;   // LDS layout (bytes)
+  unsigned tiles_x_magic;
+  int off_bias, off_x, off_y, off_t, off_u1, off_u2, off_stage, smem_bytes;   // LDS layout (bytes)
 };
 struct C3k2Conv {                // one conv of the block as the exporter stored it (host pointers)
   const unsigned char* w[2];     // packed 1-KiB fragment blocks [n/16][K/32] per output slice (slice 1 only for cv1|cv2)
@@ -107,7 +107,8 @@ bool c3k2_layout(C3k2Params* p);
 bool c3k2_supported(int hid, int nb, int cin);
 bool c3k2_pack(int hid, int nb, int cin, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias);
 hipError_t c3k2_launch(const C3k2Params& p, hipStream_t stream);
-const char* c3k2_kernel_name(int hid, int nb);
+const char* c3k2_kernel_name(int hid, int nb, int cin);
+int c3k2_block_threads(int hid, int nb, int cin);
 
 // ------------------------------------------------------------------------------------------------
 // Stem: fp32 NCHW image -> 3x3/s2 conv (Cin=3) + bias + ReLU -> NHWC fp16
