@@ -111,16 +111,17 @@ def test_export_rejects_unsupported_width(pkg):
 
 
 def test_c3k2_groups_are_recognised_at_load(lib, pkg, sd7, tmp_path):
-    """Load-time block fusion (csrc/c3k2_fused.hip): the structural matcher finds the seven C3k2 blocks of graph (A)
-    (model.py:76-110) in the exporter's op table, six in the lite_p2 variant, none in an fp32 engine file."""
+    """Load-time block fusion (csrc/c3k2_fused.hip, head_fused.hip): the structural matcher finds the seven C3k2 blocks
+    of graph (A) (model.py:76-110) and the P2 DetectionHead (model.py:274-303; the only head whose weights a workgroup
+    can stream) in the exporter's op table, one block fewer in the lite_p2 variant, none in an fp32 engine file."""
     from unina_yolo_dla_amd import export
     g = pkg.graph.Graph(in_h=64, in_w=64)
     path = str(tmp_path / "a.une")
     export.export_engine(sd7, path, g)
-    assert lib.unina_debug_fusable_groups(path.encode()) == 7
+    assert lib.unina_debug_fusable_groups(path.encode()) == 8
     export.export_engine(sd7, path, g, precision=export.FP32)
     assert lib.unina_debug_fusable_groups(path.encode()) == 0
     gl = pkg.graph.Graph(in_h=64, in_w=64, lite_p2=True)
     export.export_engine(pkg.synth.make_state_dict(7, gl), path, gl)
-    assert lib.unina_debug_fusable_groups(path.encode()) == 6
+    assert lib.unina_debug_fusable_groups(path.encode()) == 7
     assert lib.unina_debug_fusable_groups(b"/nonexistent.une") == -1

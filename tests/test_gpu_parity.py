@@ -68,7 +68,7 @@ def unfused64(eng64):
     """Per-layer checks read the C3k2 blocks' internal buffers, which only the unfused op table writes."""
     eng64.set_fusion(False)
     yield eng64
-    assert eng64.set_fusion(True) == 7
+    assert eng64.set_fusion(True) == 8
 
 
 def test_mini64_every_buffer_vs_oracle(pkg, unfused64, oracle_mod, oracle_sd7, torch_cuda):
@@ -380,25 +380,26 @@ BLOCK_OUTPUTS = ("neck.cat_fpn2", "neck.cat_fpn1", "neck.cat_pan2", "neck.cat_pa
 
 
 @pytest.mark.parametrize("size", [64, 640, 96])
-def test_c3k2_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
-    """Each C3k2 block (model.py:76-110) as ONE launch with its intermediates in LDS (csrc/c3k2_fused.hip) vs the
-    2 + 2n per-conv launches: same MFMA, same K order, same fp16 rounding points -> every block output and every head
+def test_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
+    """Each C3k2 block (model.py:76-110) and the P2 DetectionHead (model.py:274-303) as ONE launch with its
+    intermediates in LDS (csrc/c3k2_fused.hip, head_fused.hip) vs the per-conv launches: same MFMA, same K order, same fp16 rounding points -> every block output and every head
     must agree bit for bit. 96x96 gives 24/12/6-pixel maps: partial tiles on every level."""
     from unina_yolo_dla_amd.engine import Engine
     e = Engine.from_state_dict(sd7, pkg.graph.Graph(in_h=size, in_w=size))
     try:
-        assert e.L.unina_fusion_groups(e.h) == 7              # on by default
+        assert e.L.unina_fusion_groups(e.h) == 8              # 7 C3k2 blocks + the P2 head, on by default
         x = _frame(pkg, torch_cuda, 1234, size)
         fused = {k: v.copy() for k, v in e.forward(x).items()}
         fused_bufs = {b: e.read_buffer(b) for b in BLOCK_OUTPUTS}
         assert sum("c3k2_fused" in o["kernel"] for o in e.op_infos()) == 7
+        assert sum("head_fused" in o["kernel"] for o in e.op_infos()) == 1
         assert e.set_fusion(False) == 0
         plain = e.forward(x)
         for b in BLOCK_OUTPUTS:
             assert np.array_equal(fused_bufs[b], e.read_buffer(b)), b
         for k in plain:
             assert np.array_equal(fused[k], plain[k]), k
-        assert e.set_fusion(True) == 7
+        assert e.set_fusion(True) == 8
         again = e.forward(x)
         for k in plain:
             assert np.array_equal(again[k], plain[k]), k

@@ -1,0 +1,176 @@
+// block_pipeline.h -- shared device machinery of the block-fused kernels (c3k2_fused.hip, head_fused.hip). gfx950 only.
+//
+// A block kernel runs a short compile-time list of GEMM "steps" per workgroup. Activations (the MFMA B operand, pixels
+// as columns) live in LDS images; weights (the A operand) stream from L2 straight into registers: a wave owns wnt
+// 16-channel subtiles of a step's output, so its weight blocks form ONE flat sequence over all steps (packed by the
+// host in consumption order) which is prefetched D blocks ahead through a circular register queue that keeps running
+// across step boundaries. Every loop is unrolled at compile time and there is no wave-uniform branch around a global
+// load, so queue slots are plain registers and the compiler's own counted s_waitcnt vmcnt tracks the prefetches.
+#pragma once
+#include <type_traits>
+
+#include "mfma_common.h"
+
+namespace unina {
+namespace dev {
+
+// LDS image: pixel row r owns nch 16-byte chunks (8 fp16 channels each); chunk c lives at slot c ^ ((r >> sh) & mask)
+// of its row, (sh, mask) chosen from the row pitch so that the 16 pixels of a fragment read hit 16 different bank slots.
+struct Img {
+  int base, nch, sh, mask;
+  __device__ __forceinline__ int key(int row) const { return (row >> sh) & mask; }
+  __device__ __forceinline__ int addr(int row, int chunk) const { return base + ((row * nch + (chunk ^ key(row))) << 4); }
+};
+__host__ __device__ constexpr Img make_img(int base, int nch) {
+  // pitch = nch 16-byte slots; a ds_read_b128 group covers 16 slots' worth of banks
+  return (nch % 16 == 0) ? Img{base, nch, 0, 15} : ((nch % 8 == 0) ? Img{base, nch, 1, 7} : Img{base, nch, 2, 3});
+}
+
+// Step table. PLAN provides: N (steps), kb(s) = K/32 weight blocks per channel subtile, ns(s) = output channels / 16,
+// wnt(s) = subtiles per wave. Wave roles: waves_n = ns / wnt waves split the channels, waves_m = NW / waves_n split
+// the pixels (those load the same weight blocks: L1 serves the repeats). Every wave works in every step.
+template <typename PLAN, int NW>
+struct StepTable {
+  static constexpr int N = PLAN::N;
+  static constexpr int kb(int s) { return PLAN::kb(s); }
+  static constexpr int ns(int s) { return PLAN::ns(s); }
+  static constexpr int wnt(int s) { return PLAN::wnt(s); }
+  static constexpr int waves_n(int s) { return ns(s) / wnt(s); }
+  static constexpr int waves_m(int s) { return NW / waves_n(s); }
+  static constexpr bool valid() {
+    for (int s = 0; s < N; ++s)
+      if (ns(s) % wnt(s) || waves_n(s) > NW || NW % waves_n(s)) return false;
+    return true;
+  }
+  static constexpr int first(int s) {  // index of step s' first block in a wave's flat weight sequence
+    int t = 0;
+    for (int i = 0; i < s; ++i) t += kb(i) * wnt(i);
+    return t;
+  }
+  static constexpr int total() { return first(N); }
+  static constexpr int blk(int s) {    // offset of step s in the packed stream, in 1-KiB blocks
+    int t = 0;
+    for (int i = 0; i < s; ++i) t += kb(i) * ns(i);
+    return t;
+  }
+  static constexpr int step_of(int g) {
+    int s = 0;
+    while (s < N - 1 && g >= first(s + 1)) ++s;
+    return s;
+  }
+};
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// Element G of this wave's flat weight sequence -> queue slot G % D. wbase = stream + this lane's 16 bytes of a block.
+template <typename ST, int D, int G>
+__device__ __forceinline__ void wq_fetch(half8 (&q)[D], const unsigned char* wbase, int wid) {
+  if constexpr (G < ST::total()) {
+    constexpr int s = ST::step_of(G), e = G - ST::first(s), wnt = ST::wnt(s), kb = e / wnt, j = e - kb * wnt, ns = ST::ns(s);
+    const int nsub = (wid % ST::waves_n(s)) * wnt + j;
+    q[G % D] = *reinterpret_cast<const half8*>(wbase + (size_t)(ST::blk(s) + kb * ns + nsub) * 1024);
+  }
+}
+
+__device__ __forceinline__ void lds_barrier() {  // publishes this wave's LDS writes; does NOT drain the weight prefetches
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// One GEMM step S over P pixels.
+//   baddr(sub, kc) : LDS byte address of this lane's 16-byte B fragment of pixel subtile `sub`, k-block kc (an
+//                    std::integral_constant) -- the same for all of the wave's channel subtiles
+//   epi(sub, n, acc): consumes channels n..n+3 of pixel sub*16 + (lane & 15)
+// Ends with the barrier that publishes the epilogue's LDS writes.
+template <typename ST, int D, int S, int P, typename BAddr, typename Epi>
+__device__ __forceinline__ void run_step(half8 (&q)[D], const unsigned char* wbase, const unsigned char* smem, int wid,
+                                         int lane, BAddr baddr, Epi epi) {
+  constexpr int KB = ST::kb(S), G0 = ST::first(S), WN_T = ST::wnt(S), WVN = ST::waves_n(S), WVM = ST::waves_m(S);
+  constexpr int MS = (P + 15) / 16, WM_T = (MS + WVM - 1) / WVM;
+  constexpr bool DB = WM_T <= 6;   // B fragments double-buffered in registers when they fit comfortably
+  const int wm = wid / WVN, wn = wid % WVN, lq = lane >> 4;
+  floatx4 acc[WN_T][WM_T];
+  half8 b[2][WM_T];
+#pragma unroll
+  for (int i = 0; i < WM_T; ++i) {
+#pragma unroll
+    for (int j = 0; j < WN_T; ++j) acc[j][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (DB) b[0][i] = *reinterpret_cast<const half8*>(smem + baddr(wm * WM_T + i, std::integral_constant<int, 0>{}));
+  }
+  static_for<0, KB>([&](auto kc) {
+    constexpr int kb = decltype(kc)::value;
+    half8 a[WN_T];
+#pragma unroll
+    for (int j = 0; j < WN_T; ++j) a[j] = q[(G0 + kb * WN_T + j) % D];
+    static_for<0, WN_T>([&](auto jc) { wq_fetch<ST, D, G0 + kb * WN_T + decltype(jc)::value + D>(q, wbase, wid); });
+    if constexpr (DB) {
+      if constexpr (kb + 1 < KB) {
+#pragma unroll
+        for (int i = 0; i < WM_T; ++i)
+          b[(kb + 1) & 1][i] = *reinterpret_cast<const half8*>(smem + baddr(wm * WM_T + i, std::integral_constant<int, kb + 1>{}));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WM_T; ++i) b[kb & 1][i] = *reinterpret_cast<const half8*>(smem + baddr(wm * WM_T + i, kc));
+    }
+#pragma unroll
+    for (int j = 0; j < WN_T; ++j)
+#pragma unroll
+      for (int i = 0; i < WM_T; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[kb & 1][i], acc[j][i], 0, 0, 0);
+  });
+#pragma unroll
+  for (int j = 0; j < WN_T; ++j)
+#pragma unroll
+    for (int i = 0; i < WM_T; ++i)
+      if (wm * WM_T + i < MS) epi(wm * WM_T + i, (wn * WN_T + j) * 16 + lq * 4, acc[j][i]);
+  lds_barrier();
+}
+
+__device__ __forceinline__ floatx4 bias_relu(const floatx4& acc, const float* bias_lds, int n) {
+  floatx4 v = acc + *reinterpret_cast<const floatx4*>(bias_lds + n);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+  return v;
+}
+__device__ __forceinline__ void store_h4(unsigned char* smem, const Img& im, int row, int n, const floatx4& v) {
+  half4 hv;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) hv[r] = (_Float16)v[r];
+  *reinterpret_cast<half4*>(smem + im.addr(row, n >> 3) + (n & 4) * 2) = hv;
+}
+__device__ __forceinline__ floatx4 load_h4(const unsigned char* smem, const Img& im, int row, int n) {
+  const half4 hv = *reinterpret_cast<const half4*>(smem + im.addr(row, n >> 3) + (n & 4) * 2);
+  return floatx4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+}
+
+// Input patch -> LDS image by LDS-DMA: 16-byte slot s = (region pixel r of an RH x RW region whose origin is image
+// pixel (y0, x0), chunk cs); out-of-image pixels read the zero page. NT threads; every wave must afterwards wait
+// vmcnt(0) (its own DMAs) and pass a barrier before anyone reads the image.
+template <int RH, int RW, int CIN, int NT>
+__device__ __forceinline__ void load_patch(unsigned char* lds_img, const _Float16* src, int src_ld, int H, int W, int y0,
+                                           int x0, const void* zeros, int wid, int lane) {
+  constexpr Img X = make_img(0, CIN / 8);
+  constexpr int nchx = CIN / 8, nslots = RH * RW * nchx;
+  for (int s0 = wid * 64; s0 < nslots; s0 += NT) {
+    const int s = s0 + lane;
+    const _Float16* g = reinterpret_cast<const _Float16*>(zeros);
+    if (s < nslots) {
+      const int r = s / nchx, cs = s - r * nchx;
+      const int ry = r / RW, rx = r - ry * RW;
+      const int iy = y0 + ry, ix = x0 + rx;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        g = src + (size_t)(iy * W + ix) * src_ld + ((cs ^ X.key(r)) << 3);
+    }
+    glds16(g, lds_img + s0 * 16);
+  }
+}
+
+}  // namespace dev
+}  // namespace unina

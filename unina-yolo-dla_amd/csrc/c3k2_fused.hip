@@ -24,10 +24,8 @@
 // Arithmetic is identical to the unfused kernels: same MFMA (v_mfma_f32_16x16x32_f16), same K order (tap-major, 32
 // channels per block), same fp32 epilogue and the same fp16 rounding points -> results are bit-identical (tested).
 //
-// LDS image: pixel row r owns nch 16-byte chunks (8 channels each); chunk c lives at slot c ^ ((r >> sh) & mask) of
-// its row, (sh, mask) chosen from the row pitch so that the 16 pixels of a fragment read hit 16 different bank slots.
 #include "kernels.h"
-#include "mfma_common.h"
+#include "block_pipeline.h"
 
 #include <cstring>
 #include <vector>
@@ -38,79 +36,15 @@ using namespace dev;
 
 namespace {
 
-struct Img {
-  int base, nch, sh, mask;
-  __device__ __forceinline__ int key(int row) const { return (row >> sh) & mask; }
-  __device__ __forceinline__ int addr(int row, int chunk) const { return base + ((row * nch + (chunk ^ key(row))) << 4); }
-};
-__host__ __device__ constexpr Img make_img(int base, int nch) {
-  // pitch = nch 16-byte slots; a ds_read_b128 group covers 16 slots' worth of banks
-  return (nch % 16 == 0) ? Img{base, nch, 0, 15} : ((nch % 8 == 0) ? Img{base, nch, 1, 7} : Img{base, nch, 2, 3});
-}
-
-// ---- compile-time description of the block's GEMM steps -----------------------------------------------------------
 // step 0: cv1|cv2 (K = CIN, N = 2h); odd steps: bottleneck 1x1 (K = h, N = h); even steps: bottleneck 3x3 (K = 9h,
-// N = h); last step: cv3 (K = 2h, N = 2h). kb = K / 32 weight blocks per 16-channel subtile, ns = N / 16 subtiles.
+// N = h); last step: cv3 (K = 2h, N = 2h). A wave owns one channel subtile, or ns / NW of them when ns > NW.
 template <int H_, int NB, int CIN, int NW>
-struct Steps {
+struct C3k2Plan {
   static constexpr int N = 2 + 2 * NB;
   static constexpr int kb(int s) { return s == 0 ? CIN / 32 : (s == N - 1 ? 2 * H_ / 32 : ((s & 1) ? H_ / 32 : 9 * H_ / 32)); }
   static constexpr int ns(int s) { return (s == 0 || s == N - 1) ? 2 * H_ / 16 : H_ / 16; }
-  // wave roles: every wave works in every step. waves_n waves split the channel subtiles (wnt each), the remaining
-  // factor waves_m splits the pixels (those waves load the same weight blocks: L1 serves the repeats).
-  static constexpr int waves_n(int s) { return ns(s) < NW ? ns(s) : NW; }
-  static constexpr int wnt(int s) { return ns(s) / waves_n(s); }
-  static constexpr int waves_m(int s) { return NW / waves_n(s); }
-  static constexpr int first(int s) {  // index of step s' first block in a wave's flat weight sequence
-    int t = 0;
-    for (int i = 0; i < s; ++i) t += kb(i) * wnt(i);
-    return t;
-  }
-  static constexpr int total() { return first(N); }
-  static constexpr int blk(int s) {    // offset of step s in the packed stream, in 1-KiB blocks
-    int t = 0;
-    for (int i = 0; i < s; ++i) t += kb(i) * ns(i);
-    return t;
-  }
-  static constexpr int step_of(int g) {
-    int s = 0;
-    while (s < N - 1 && g >= first(s + 1)) ++s;
-    return s;
-  }
+  static constexpr int wnt(int s) { return ns(s) <= NW ? 1 : ns(s) / NW; }
 };
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
-constexpr int imin(int a, int b) { return a < b ? a : b; }
-constexpr int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
-
-__device__ __forceinline__ floatx4 bias_relu(const floatx4& acc, const float* bias_lds, int n) {
-  floatx4 v = acc + *reinterpret_cast<const floatx4*>(bias_lds + n);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-  return v;
-}
-__device__ __forceinline__ void store_h4(unsigned char* smem, const Img& im, int row, int n, const floatx4& v) {
-  half4 hv;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) hv[r] = (half_t)v[r];
-  *reinterpret_cast<half4*>(smem + im.addr(row, n >> 3) + (n & 4) * 2) = hv;
-}
-__device__ __forceinline__ floatx4 load_h4(const unsigned char* smem, const Img& im, int row, int n) {
-  const half4 hv = *reinterpret_cast<const half4*>(smem + im.addr(row, n >> 3) + (n & 4) * 2);
-  return floatx4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
-}
-__device__ __forceinline__ void lds_barrier() {  // publishes this wave's LDS writes; does NOT drain the weight prefetches
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
 
 }  // namespace
 
@@ -122,7 +56,8 @@ extern __shared__ __align__(16) unsigned char c3_smem[];
 template <int H_, int TH, int TW, int NB, int CIN, int NW, int D>
 __global__ __launch_bounds__(NW * 64) void c3k2_fused_kernel(const C3k2Params p) {
   static_assert(NB == 1 || NB == 2, "bottleneck count");
-  typedef Steps<H_, NB, CIN, NW> ST;
+  typedef StepTable<C3k2Plan<H_, NB, CIN, NW>, NW> ST;
+  static_assert(ST::valid(), "wave roles");
   static_assert((NW & (NW - 1)) == 0 && NW >= 2 && NW <= 16, "waves per workgroup");
   constexpr int R0W = TW + 2 * NB, P0 = (TH + 2 * NB) * R0W;   // input / first-level region (tile + NB-pixel halo)
   constexpr int R1W = TW + 2, P1 = (TH + 2) * R1W;              // NB == 2: region of the first bottleneck's output
@@ -136,42 +71,18 @@ __global__ __launch_bounds__(NW * 64) void c3k2_fused_kernel(const C3k2Params p)
   unsigned char* smem = c3_smem;
   const int tyi = fast_div((int)blockIdx.x, p.tiles_x_magic), txi = (int)blockIdx.x - tyi * p.tiles_x;
   const int ty0 = tyi * TH, tx0 = txi * TW;
-  const half_t* zeros = reinterpret_cast<const half_t*>(p.zeros);
 
   // ---- weight prefetch queue: element g of this wave's flat sequence lives in slot g % D ----
   const unsigned char* wbase = p.wstream + (4 * l15 + (lq ^ swz_g(l15))) * 16;   // this lane's 16 bytes of any block
   half8 q[D];
-  auto fetch = [&](auto gc) {
-    constexpr int g = decltype(gc)::value;
-    if constexpr (g < ST::total()) {
-      constexpr int s = ST::step_of(g), e = g - ST::first(s), wnt = ST::wnt(s), kb = e / wnt, j = e - kb * wnt, ns = ST::ns(s);
-      const int nsub = (wid % ST::waves_n(s)) * wnt + j;
-      q[g % D] = *reinterpret_cast<const half8*>(wbase + (size_t)(ST::blk(s) + kb * ns + nsub) * 1024);
-    }
-  };
-
   // biases of every step -> LDS
   float* bias_lds = reinterpret_cast<float*>(smem + p.off_bias);
   for (int i = threadIdx.x; i < p.n_bias; i += NT) bias_lds[i] = p.bias[i];
 
-  // input patch: 16-byte slot s = (region pixel r, chunk cs); out-of-image pixels read the zero page
+  // input patch (tile + NB-pixel halo, all CIN channels) -> LDS image
   constexpr Img X = make_img(0, CIN / 8);
-  {
-    constexpr int nchx = CIN / 8, nslots = P0 * nchx;
-    for (int s0 = wid * 64; s0 < nslots; s0 += NT) {
-      const int s = s0 + lane;
-      const half_t* g = zeros;
-      if (s < nslots) {
-        const int r = s / nchx, cs = s - r * nchx;
-        const int ry = r / R0W, rx = r - ry * R0W;
-        const int iy = ty0 - NB + ry, ix = tx0 - NB + rx;
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-          g = p.src + (size_t)(iy * p.W + ix) * p.src_ld + ((cs ^ X.key(r)) << 3);
-      }
-      glds16(g, smem + p.off_x + s0 * 16);
-    }
-  }
-  static_for<0, D>(fetch);
+  load_patch<TH + 2 * NB, R0W, CIN, NT>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0 - NB, tx0 - NB, p.zeros, wid, lane);
+  static_for<0, D>([&](auto gc) { wq_fetch<ST, D, decltype(gc)::value>(q, wbase, wid); });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed (LDS-DMA is not tracked by the compiler)
   lds_barrier();
 
@@ -182,53 +93,9 @@ __global__ __launch_bounds__(NW * 64) void c3k2_fused_kernel(const C3k2Params p)
   const Img U2 = make_img(p.off_u2, H_ / 8);     // last bottleneck's output on the tile
   auto in_image = [&](int iy, int ix) { return (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W; };
 
-  // One GEMM step S over P pixels:  baddr(sub, kb) = LDS byte address of this lane's B fragment of pixel subtile
-  // `sub` / k-block kb (kb is a compile-time constant);  epi(sub, n, acc) consumes channels n..n+3 of pixel
-  // sub*16 + l15. Ends with the barrier that publishes the epilogue's LDS writes.
   auto run_step = [&](auto sc, auto pc, auto baddr, auto epi) {
-    constexpr int S = decltype(sc)::value, P = decltype(pc)::value;
-    constexpr int KB = ST::kb(S), G0 = ST::first(S), WN_T = ST::wnt(S), WVN = ST::waves_n(S), WVM = ST::waves_m(S);
-    constexpr int MS = (P + 15) / 16, WM_T = (MS + WVM - 1) / WVM;
-    constexpr bool DB = WM_T <= 6;   // B fragments double-buffered in registers when they fit comfortably
-    const int wm = wid / WVN, wn = wid % WVN;
-    floatx4 acc[WN_T][WM_T];
-    half8 b[2][WM_T];
-#pragma unroll
-    for (int i = 0; i < WM_T; ++i) {
-#pragma unroll
-      for (int j = 0; j < WN_T; ++j) acc[j][i] = floatx4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (DB) b[0][i] = *reinterpret_cast<const half8*>(smem + baddr(wm * WM_T + i, std::integral_constant<int, 0>{}));
-    }
-    static_for<0, KB>([&](auto kc) {
-      constexpr int kb = decltype(kc)::value;
-      half8 a[WN_T];
-#pragma unroll
-      for (int j = 0; j < WN_T; ++j) a[j] = q[(G0 + kb * WN_T + j) % D];
-      static_for<0, WN_T>([&](auto jc) { fetch(std::integral_constant<int, G0 + kb * WN_T + decltype(jc)::value + D>{}); });
-      if constexpr (DB) {
-        if constexpr (kb + 1 < KB) {
-#pragma unroll
-          for (int i = 0; i < WM_T; ++i)
-            b[(kb + 1) & 1][i] = *reinterpret_cast<const half8*>(smem + baddr(wm * WM_T + i, std::integral_constant<int, kb + 1>{}));
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < WM_T; ++i) b[kb & 1][i] = *reinterpret_cast<const half8*>(smem + baddr(wm * WM_T + i, kc));
-      }
-#pragma unroll
-      for (int j = 0; j < WN_T; ++j)
-#pragma unroll
-        for (int i = 0; i < WM_T; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[kb & 1][i], acc[j][i], 0, 0, 0);
-    });
-#pragma unroll
-    for (int j = 0; j < WN_T; ++j)
-#pragma unroll
-      for (int i = 0; i < WM_T; ++i)
-        if (wm * WM_T + i < MS) epi(wm * WM_T + i, (wn * WN_T + j) * 16 + lq * 4, acc[j][i]);
-    lds_barrier();
+    dev::run_step<ST, D, decltype(sc)::value, decltype(pc)::value>(q, wbase, smem, wid, lane, baddr, epi);
   };
-  auto I = [](auto v) { return v; };
-  (void)I;
 #define STEP(S, P) std::integral_constant<int, (S)>{}, std::integral_constant<int, (P)>{}
 
   // ---- step 0: a | b = ReLU(W12 x + b12) on R0 --------------------------------------------------------------------
@@ -438,22 +305,15 @@ bool c3k2_layout(C3k2Params* p) {
   return off <= kMaxLds;
 }
 
-// Packs the weights of the block's convs (execution order: cv1|cv2, {b.cv1, b.cv2} x nb, cv3; each given as the
-// exporter's [n/16][K/32] 1-KiB fragment blocks) into the stream the kernel reads: per step, k-block-major
-// [K/32][N/16] blocks (the wave that owns subtile j of step s reads blocks blk(s) + kb*ns + j, kb = 0..), and
-// concatenates the biases.
-bool c3k2_pack(int hid, int nb, int cin, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias) {
-  if (!find_class(hid, nb, cin)) return false;
+// Packs the weights of a block's convs (each given as the exporter's [n/16][K/32] 1-KiB fragment blocks, up to two
+// output slices) into the stream the block kernels read: per conv, k-block-major [K/32][N/16] blocks (the wave that
+// owns subtile j of step s reads blocks blk(s) + kb*ns + j, kb = 0..), and concatenates the biases.
+void block_pack(const C3k2Conv* convs, int nconv, std::vector<unsigned char>* stream, std::vector<float>* bias) {
   stream->clear();
   bias->clear();
-  const int nconv = 2 + 2 * nb;
   for (int ci = 0; ci < nconv; ++ci) {
     const C3k2Conv& cv = convs[ci];
-    const int n = cv.n[0] + cv.n[1];
-    const int want_n = (ci == 0 || ci == nconv - 1) ? 2 * hid : hid;
-    const int want_k = ci == 0 ? cin : (ci == nconv - 1 ? 2 * hid : ((ci & 1) ? hid : 9 * hid));
-    if (n != want_n || cv.K != want_k || cv.n[0] % 16 || cv.n[1] % 16) return false;
-    const int ns = n / 16, kbn = cv.K / 32;
+    const int ns = (cv.n[0] + cv.n[1]) / 16, kbn = cv.K / 32;
     const size_t base = stream->size();
     stream->resize(base + (size_t)kbn * ns * 1024, 0);
     for (int kb = 0; kb < kbn; ++kb)
@@ -465,6 +325,19 @@ bool c3k2_pack(int hid, int nb, int cin, const C3k2Conv* convs, std::vector<unsi
     for (int seg = 0; seg < 2; ++seg)
       for (int i = 0; i < cv.n[seg]; ++i) bias->push_back(cv.bias[seg][i]);
   }
+}
+
+// C3k2 convs in execution order: cv1|cv2, {b.cv1, b.cv2} x nb, cv3.
+bool c3k2_pack(int hid, int nb, int cin, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias) {
+  if (!find_class(hid, nb, cin)) return false;
+  const int nconv = 2 + 2 * nb;
+  for (int ci = 0; ci < nconv; ++ci) {
+    const C3k2Conv& cv = convs[ci];
+    const int want_n = (ci == 0 || ci == nconv - 1) ? 2 * hid : hid;
+    const int want_k = ci == 0 ? cin : (ci == nconv - 1 ? 2 * hid : ((ci & 1) ? hid : 9 * hid));
+    if (cv.n[0] + cv.n[1] != want_n || cv.K != want_k || cv.n[0] % 16 || cv.n[1] % 16) return false;
+  }
+  block_pack(convs, nconv, stream, bias);
   return true;
 }
 

@@ -42,7 +42,9 @@ struct PlannedOp {
   // fused C3k2 block (c3k2_fused.hip): role 1 = first op of a fusable group (launches the whole block when fusion is
   // on), 2 = absorbed by the group's first op (no launch of its own when fusion is on), 0 = ordinary op
   int fuse_role = 0;
-  int group_last = -1;      // role 1: index of the group's last op (cv3)
+  int fuse_kind = 0;        // role 1: 1 = C3k2 block (c3k2_fused.hip), 2 = DetectionHead (head_fused.hip)
+  HeadParams hp;
+  int group_last = -1;      // role 1: index of the group's last op (cv3 / the head's output convs)
   int hid = 0, nb = 0;      // role 1: hidden width, bottleneck count
   uint64_t stream_off = 0, fbias_off = 0;   // role 1: blob offsets of the packed stage stream / concatenated biases
   C3k2Params fp;
@@ -264,10 +266,53 @@ int plan(unina_engine* e) {
       return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: kind %u not executable", i, d.kind);
     }
   }
-  // fused C3k2 groups: parameters of the one-launch form; op infos describe what actually runs
+  // fused groups: parameters of the one-launch form; op infos describe what actually runs
   for (size_t i = 0; i < e->ops.size(); ++i) {
     PlannedOp& op = e->ops[i];
     if (op.fuse_role != 1) continue;
+    if (op.fuse_kind == 2) {
+      const OpDesc& a = op.d;
+      const OpDesc& z = e->ops[op.group_last].d;
+      const Buffer& src = e->bufs[a.src_buf];
+      HeadParams& f = op.hp;
+      memset(&f, 0, sizeof f);
+      f.src = static_cast<const half_t*>(src.ptr) + a.seg[0].src_coff;
+      f.src_ld = (int)src.d.c;
+      f.C = (int)a.cin;
+      f.H = (int)a.in_h;
+      f.W = (int)a.in_w;
+      f.out_cls = static_cast<float*>(e->bufs[z.seg[0].dst_buf].ptr);
+      f.out_reg = static_cast<float*>(e->bufs[z.seg[1].dst_buf].ptr);
+      f.n_cls = (int)z.seg[0].n_count;
+      f.n_reg = (int)z.seg[1].n_count;
+      f.wstream = reinterpret_cast<const unsigned char*>(blob + op.stream_off);
+      f.bias = reinterpret_cast<const float*>(blob + op.fbias_off);
+      f.zeros = e->d_zeros;
+      if (!head_layout(&f)) return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: fused head does not fit", i);
+      if (!e->fuse) continue;
+      unina_op_info& info = op.info;
+      double flops = 0, wbytes = 0;
+      for (int k = (int)i; k <= op.group_last; ++k) {
+        flops += e->ops[k].info.flops;
+        wbytes += 2.0 * e->ops[k].info.n * e->ops[k].info.k + 4.0 * e->ops[k].info.n;
+        if (k > (int)i) {
+          unina_op_info& ai = e->ops[k].info;
+          ai.flops = 0;
+          ai.bytes = 0;
+          ai.grid = 0;
+          snprintf(ai.kernel, sizeof ai.kernel, "(fused into op %zu)", i);
+        }
+      }
+      info.flops = flops;
+      info.bytes = 2.0 * f.H * f.W * f.C + wbytes + 4.0 * f.H * f.W * (f.n_cls + f.n_reg);
+      info.n = f.n_cls + f.n_reg;
+      info.k = 0;
+      info.grid = f.tiles_x * f.tiles_y;
+      info.block = head_block_threads(f.C);
+      snprintf(info.kernel, sizeof info.kernel, "%s", head_kernel_name(f.C));
+      snprintf(info.name, sizeof info.name, "%.*s[head]", (int)(strchr(a.name, '.') ? strchr(a.name, '.') - a.name : 60), a.name);
+      continue;
+    }
     const OpDesc& a = op.d;
     const OpDesc& z = e->ops[op.group_last].d;
     const Buffer& src = e->bufs[a.src_buf];
@@ -317,7 +362,7 @@ int plan(unina_engine* e) {
 
 hipError_t launch_op(unina_engine* e, size_t i, hipStream_t s) {
   PlannedOp& op = e->ops[i];
-  if (e->fuse && op.fuse_role == 1) return c3k2_launch(op.fp, s);
+  if (e->fuse && op.fuse_role == 1) return op.fuse_kind == 2 ? head_launch(op.hp, s) : c3k2_launch(op.fp, s);
   if (e->fuse && op.fuse_role == 2) return hipSuccess;   // runs inside its group's launch
   switch (op.d.kind) {
     case kOpConv: return conv_launch(op.cp, op.cl, s);
@@ -353,9 +398,10 @@ void op_regions(const unina_engine* e, size_t i, std::vector<Region>* reads, std
   writes->clear();
   if (e->fuse && e->ops[i].fuse_role == 2) return;
   if (e->fuse && e->ops[i].fuse_role == 1) {
-    const SegDesc& out = e->ops[e->ops[i].group_last].d.seg[0];
+    const OpDesc& last = e->ops[e->ops[i].group_last].d;
     reads->push_back({(int)d.src_buf, (int)d.seg[0].src_coff, (int)(d.seg[0].src_coff + d.cin)});
-    writes->push_back({(int)out.dst_buf, (int)out.dst_coff, (int)(out.dst_coff + out.n_count)});
+    for (uint32_t s = 0; s < last.nseg; ++s)
+      writes->push_back({(int)last.seg[s].dst_buf, (int)last.seg[s].dst_coff, (int)(last.seg[s].dst_coff + last.seg[s].n_count)});
     return;
   }
   if (d.kind == kOpSppfPool) {
@@ -543,6 +589,7 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     blob->insert(blob->end(), reinterpret_cast<const char*>(bias.data()), reinterpret_cast<const char*>(bias.data() + bias.size()));
     PlannedOp& head = e->ops[i];
     head.fuse_role = 1;
+    head.fuse_kind = 1;
     head.group_last = (int)j;
     head.hid = (int)h;
     head.nb = nb;
@@ -551,6 +598,78 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     for (size_t k = i + 1; k <= j; ++k) e->ops[k].fuse_role = 2;
     ++e->n_groups;
     i = j;
+  }
+}
+
+// A DetectionHead (model.py:274-303) in the exporter's table: [cls.0|reg.0 3x3, same input, two slices of h0] ->
+// [cls.1|reg.1 3x3, slice i reads h0's slice i, writes h1's slice i] -> [cls.2|reg.2 1x1 without ReLU into the two
+// fp32 planar outputs]. Fused when the channel width has a head_fused.hip class and h0 / h1 are private.
+void find_head_groups(unina_engine* e, std::vector<char>* blob) {
+  const size_t n = e->ops.size();
+  for (size_t i = 0; i + 2 < n; ++i) {
+    const OpDesc& a = e->ops[i].d;
+    const OpDesc& b = e->ops[i + 1].d;
+    const OpDesc& c = e->ops[i + 2].d;
+    if (e->ops[i].fuse_role || e->ops[i + 1].fuse_role || e->ops[i + 2].fuse_role) continue;
+    if (!is_plain_conv(a, 3, 2) || !is_plain_conv(b, 3, 2) || a.res_buf >= 0 || b.res_buf >= 0) continue;
+    const uint32_t C = a.cin;
+    if (a.seg[0].n_count != C || a.seg[1].n_count != C || a.seg[0].src_coff != a.seg[1].src_coff) continue;
+    const uint32_t h0 = a.seg[0].dst_buf;
+    if (a.seg[1].dst_buf != h0 || a.seg[0].dst_coff != 0 || a.seg[1].dst_coff != C || e->bufs[h0].d.c != 2 * C) continue;
+    if (b.cin != C || b.src_buf != h0 || b.seg[0].src_coff != 0 || b.seg[1].src_coff != C || b.seg[0].n_count != C || b.seg[1].n_count != C) continue;
+    const uint32_t h1 = b.seg[0].dst_buf;
+    if (b.seg[1].dst_buf != h1 || b.seg[0].dst_coff != 0 || b.seg[1].dst_coff != C || e->bufs[h1].d.c != 2 * C || h1 == h0) continue;
+    if (c.kind != kOpConv || c.ksize != 1 || c.stride != 1 || c.relu || c.nseg != 2 || c.res_buf >= 0 || c.cin != C || c.src_buf != h1) continue;
+    if (c.seg[0].src_coff != 0 || c.seg[1].src_coff != C) continue;
+    bool ok = true;
+    for (int s = 0; s < 2; ++s)
+      ok = ok && (c.seg[s].flags == kSegPlanarF32) && !c.seg[s].m_off && c.seg[s].n_pad == 16 && c.seg[s].n_count <= 16 &&
+           c.seg[s].dst_coff == 0 && e->bufs[c.seg[s].dst_buf].d.dtype == kBufF32Planar;
+    if (!ok || e->bufs[a.src_buf].d.dtype != kBufF16Nhwc || !head_supported((int)C)) continue;
+    if (a.in_h != c.out_h || a.in_w != c.out_w) continue;
+    for (uint32_t hb : {h0, h1}) {
+      if (hb == a.src_buf || (e->bufs[hb].d.flags & (kBufInput | kBufOutput))) ok = false;
+      for (size_t k = 0; k < n && ok; ++k) {
+        if (k >= i && k <= i + 2) continue;
+        const OpDesc& o = e->ops[k].d;
+        if (o.src_buf == hb || o.res_buf == (int)hb) ok = false;
+        for (uint32_t s = 0; s < o.nseg; ++s)
+          if (o.seg[s].dst_buf == hb) ok = false;
+      }
+    }
+    if (!ok) continue;
+    std::vector<C3k2Conv> convs;
+    for (size_t k = i; k <= i + 2; ++k) {
+      const OpDesc& o = e->ops[k].d;
+      C3k2Conv cv;
+      memset(&cv, 0, sizeof cv);
+      for (uint32_t s = 0; s < 2; ++s) {
+        cv.w[s] = reinterpret_cast<const unsigned char*>(blob->data() + o.seg[s].w_off);
+        cv.bias[s] = reinterpret_cast<const float*>(blob->data() + o.seg[s].b_off);
+        cv.n[s] = (int)o.seg[s].n_pad;
+      }
+      cv.K = (int)(o.ksize * o.ksize * o.cin);
+      convs.push_back(cv);
+    }
+    std::vector<unsigned char> stream;
+    std::vector<float> bias;
+    block_pack(convs.data(), 3, &stream, &bias);
+    blob->resize((blob->size() + 255) & ~(size_t)255);
+    const uint64_t so = blob->size();
+    blob->insert(blob->end(), stream.begin(), stream.end());
+    blob->resize((blob->size() + 255) & ~(size_t)255);
+    const uint64_t bo = blob->size();
+    blob->insert(blob->end(), reinterpret_cast<const char*>(bias.data()), reinterpret_cast<const char*>(bias.data() + bias.size()));
+    PlannedOp& head = e->ops[i];
+    head.fuse_role = 1;
+    head.fuse_kind = 2;
+    head.group_last = (int)i + 2;
+    head.hid = (int)C;
+    head.stream_off = so;
+    head.fbias_off = bo;
+    e->ops[i + 1].fuse_role = e->ops[i + 2].fuse_role = 2;
+    ++e->n_groups;
+    i += 2;
   }
 }
 
@@ -680,6 +799,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   // fusable C3k2 groups (fp16 engines): their packed weight streams are appended to the blob before upload
   if (e->h.precision == kFp16) {
     find_c3k2_groups(e, &blob);
+    find_head_groups(e, &blob);
     const char* fz = getenv("UNINA_FUSE");
     e->fuse = e->n_groups > 0 && !(fz && fz[0] == '0');
   }
@@ -700,6 +820,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
     if (!(b.d.flags & kBufInput)) arena += (b.bytes + 255) & ~(size_t)255;
   LOADCHK(conv_init());
   LOADCHK(c3k2_init());
+  LOADCHK(head_init());
   LOADCHK(hipMalloc(&e->d_zeros, 256));
   LOADCHK(hipMemset(e->d_zeros, 0, 256));
   LOADCHK(hipMalloc(&e->d_arena, arena ? arena : 256));
@@ -907,7 +1028,10 @@ int unina_debug_fusable_groups(const char* path) {
     for (uint32_t s = 0; s < o.d.nseg; ++s)
       if (o.d.seg[s].dst_buf >= e.h.n_buffers || o.d.seg[s].w_off > blob.size() || o.d.seg[s].b_off > blob.size()) return -UNINA_ERR_FORMAT;
   }
-  if (e.h.precision == kFp16) find_c3k2_groups(&e, &blob);
+  if (e.h.precision == kFp16) {
+    find_c3k2_groups(&e, &blob);
+    find_head_groups(&e, &blob);
+  }
   return e.n_groups;
 }
 

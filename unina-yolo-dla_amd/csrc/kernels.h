@@ -110,6 +110,37 @@ hipError_t c3k2_launch(const C3k2Params& p, hipStream_t stream);
 const char* c3k2_kernel_name(int hid, int nb, int cin);
 int c3k2_block_threads(int hid, int nb, int cin);
 
+// Generic packer of the block kernels' weight stream: per conv, k-block-major [K/32][N/16] 1-KiB blocks (slice 0's
+// channel subtiles first), then the concatenated biases (n entries per slice).
+void block_pack(const C3k2Conv* convs, int nconv, std::vector<unsigned char>* stream, std::vector<float>* bias);
+
+// ------------------------------------------------------------------------------------------------
+// Fused DetectionHead (model.py:274-303): cls.0|reg.0 (3x3) -> cls.1|reg.1 (grouped 3x3) -> cls.2|reg.2 (grouped 1x1,
+// raw fp32 planar outputs) in ONE launch (head_fused.hip). fp16 engines, heads whose weights a workgroup can stream.
+// ------------------------------------------------------------------------------------------------
+struct HeadParams {
+  const half_t* src;             // feature map, channel offset applied
+  int src_ld, C;
+  int H, W;
+  float* out_cls;                // fp32 planar [n_cls][H*W]
+  float* out_reg;                // fp32 planar [n_reg][H*W]
+  int n_cls, n_reg;              // valid output channels (<= 16 each; the weight blocks are zero-padded to 16 rows)
+  const unsigned char* wstream;  // block_pack of the three launches' convs
+  const float* bias;
+  const void* zeros;
+  // filled by head_layout():
+  int n_bias;
+  int tiles_x, tiles_y;
+  unsigned tiles_x_magic;
+  int off_bias, off_x, off_h0, off_h1, smem_bytes;
+};
+hipError_t head_init();
+bool head_supported(int c);
+bool head_layout(HeadParams* p);
+hipError_t head_launch(const HeadParams& p, hipStream_t stream);
+const char* head_kernel_name(int c);
+int head_block_threads(int c);
+
 // ------------------------------------------------------------------------------------------------
 // Stem: fp32 NCHW image -> 3x3/s2 conv (Cin=3) + bias + ReLU -> NHWC fp16
 // ------------------------------------------------------------------------------------------------
