@@ -23,7 +23,7 @@
 // zero page instead of branching.
 // Pipeline: STAGES LDS buffers, STAGES-1 K-steps in flight, one s_barrier per K-step, counted s_waitcnt vmcnt.
 #include "kernels.h"
-#include "mfma_common.h"
+#include "block_pipeline.h"
 
 namespace unina {
 
@@ -129,7 +129,7 @@ template <typename T, int BM, int BN, int WM_T, int WN_T, typename PixToM>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg& sg,
                                               typename Elem<T>::acc_t (&acc)[WN_T][WM_T], const EpiConsts<WN_T>& ec,
                                               int wm, int wn, int nb0, int l15, int lq, PixToM pix_to_m,
-                                              unsigned char* stage) {
+                                              unsigned char* stage, int nthreads = 256) {
   typedef Elem<T> E;
   const int od = sg.out_dtype;
   const int esz = od == kF32 ? 4 : (od == kF16 ? 2 : 1);
@@ -201,7 +201,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg
   typedef float vec16 __attribute__((ext_vector_type(4)));  // 16 opaque bytes
   unsigned char* dst = static_cast<unsigned char*>(sg.dst);
   const int cpr = BN * esz / 16, epc = 16 / esz;  // 16-byte chunks per pixel row, elements per chunk
-  for (int c = threadIdx.x; c < BM * cpr; c += 256) {
+  for (int c = threadIdx.x; c < BM * cpr; c += nthreads) {
     const int pl = c / cpr, ch = c - pl * cpr;
     const int n = nb0 + ch * epc;
     const int m = pix_to_m(pl);
@@ -612,6 +612,92 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
   }
 }
 
+// ============================================================================================ 3x3 register-queue kernel
+// 3x3 / stride 1 / pad 1 with the input patch resident in LDS (as conv3x3_halo) and the WEIGHTS STREAMED L2 -> REGISTERS:
+// a wave owns one 16-channel subtile of the workgroup's BN channels, so its weight blocks are one contiguous run of the
+// exporter's [n/16][K/32] fragment-block array, prefetched D blocks ahead through a circular register queue
+// (block_pipeline.h). Compared with the LDS-DMA ring this puts D KiB x waves of weights in flight per CU instead of
+// (STAGES-1) K-steps (24 KB), needs no barrier inside the K loop, and leaves LDS bandwidth to the activation fragments:
+// the weight-heavy head layers at 80^2 / 40^2 (590 KB / 2.4 MB of weights per launch) are bound by exactly that.
+// fp16 only; Cin is a template parameter (the K loop is unrolled at compile time so queue slots are registers).
+// Same MFMA, same K order (tap-major, 32 channels per block), same epilogue as the other kernels: bit-identical.
+template <int TH, int TW, int BN, int CIN, int NW, int D>
+__global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
+  typedef Elem<half_t> E;
+  constexpr int BM = TH * TW, R0W = TW + 2, R0H = TH + 2, NT = NW * 64, CB = CIN / 32, KB = 9 * CB;
+  constexpr int NS = BN / 16, WVM = NW / NS, MS = (BM + 15) / 16, WM_T = (MS + WVM - 1) / WVM;
+  static_assert(NW % NS == 0 && WM_T >= 1 && KB >= D, "tile");
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wid / NS, wn = wid % NS;
+  const int l15 = lane & 15, lq = lane >> 4;
+  int bx, by;
+  tile_of_block(p, &bx, &by);
+  const int sidx = (p.nseg > 1 && by >= p.seg[1].tile0) ? 1 : 0;
+  const ConvSeg& sg = p.seg[sidx];
+  const int n_pad = (sg.n_count + 15) & ~15;
+  const int nb0 = (by - sg.tile0) * BN;
+  const int tiles_x = (p.Wo + TW - 1) / TW;
+  const int tyi = fast_div(bx, p.tx_magic), txi = bx - tyi * tiles_x;
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+
+  int nsub = (nb0 >> 4) + wn;                       // this wave's channel subtile (tail tiles: clamp, never stored)
+  nsub = nsub * 16 < n_pad ? nsub : (n_pad >> 4) - 1;
+  const unsigned char* wptr = static_cast<const unsigned char*>(sg.w) + (size_t)nsub * KB * 1024 + (4 * l15 + (lq ^ swz_g(l15))) * 16;
+  half8 q[D];
+  auto fetch = [&](auto gc) {
+    constexpr int g = decltype(gc)::value;
+    if constexpr (g < KB) q[g % D] = *reinterpret_cast<const half8*>(wptr + g * 1024);
+  };
+
+  constexpr Img X = make_img(0, CIN / 8);
+  load_patch<R0H, R0W, CIN, NT>(conv_smem, static_cast<const half_t*>(p.src) + sg.src_coff, p.src_ld, p.H, p.W, ty0 - 1,
+                                tx0 - 1, p.zeros, wid, lane);
+  static_for<0, D>(fetch);
+  EpiConsts<1> ec;
+  load_epi_consts<1>(sg, nb0 + wn * 16, lq, ec);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
+  lds_barrier();
+
+  int row0[WM_T];
+#pragma unroll
+  for (int i = 0; i < WM_T; ++i) {
+    int pp = (wm * WM_T + i) * 16 + l15;
+    pp = pp < BM ? pp : BM - 1;                     // subtiles past the tile: any valid pixel (never stored)
+    row0[i] = (pp / TW) * R0W + pp % TW;
+  }
+  auto baddr = [&](int i, auto kc) {
+    constexpr int kb = decltype(kc)::value, tap = kb / CB, cb = kb - tap * CB, th3 = tap / 3;
+    return X.addr(row0[i] + th3 * R0W + (tap - th3 * 3), cb * 4 + lq);
+  };
+  typename E::acc_t acc[1][WM_T];
+  half8 b[2][WM_T];
+#pragma unroll
+  for (int i = 0; i < WM_T; ++i) {
+    acc[0][i] = typename E::acc_t{0, 0, 0, 0};
+    b[0][i] = *reinterpret_cast<const half8*>(conv_smem + baddr(i, std::integral_constant<int, 0>{}));
+  }
+  static_for<0, KB>([&](auto kc) {
+    constexpr int kb = decltype(kc)::value;
+    const half8 a = q[kb % D];
+    fetch(std::integral_constant<int, kb + D>{});
+    if constexpr (kb + 1 < KB) {
+#pragma unroll
+      for (int i = 0; i < WM_T; ++i) b[(kb + 1) & 1][i] = *reinterpret_cast<const half8*>(conv_smem + baddr(i, std::integral_constant<int, kb + 1>{}));
+    }
+#pragma unroll
+    for (int i = 0; i < WM_T; ++i) acc[0][i] = E::mma(a, b[kb & 1][i], acc[0][i]);
+  });
+
+  conv_epilogue<half_t, BM, BN, WM_T, 1>(p, sg, acc, ec, wm, wn, nb0, l15, lq,
+                                         [&](int pl) {
+                                           const int oy = ty0 + pl / TW, ox = tx0 + pl % TW;
+                                           return (pl < BM && oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
+                                         },
+                                         conv_smem, NT);
+}
+
 // ---------------------------------------------------------------------------------------------- launch side
 namespace {
 
@@ -620,7 +706,9 @@ struct CfgInfo {
   const char* name;
   void (*fn)(const ConvParams);
   size_t smem;         // im2col kernel: total dynamic LDS; halo kernel: weight ring only (the patch is added per op)
-  int th, tw;          // halo kernel: spatial tile (0 = im2col kernel)
+  int th, tw;          // halo / register-queue kernels: spatial tile (0 = im2col kernel)
+  int cin = 0;         // register-queue kernel: the input channel count it is instantiated for (0 = any)
+  int nthreads = 256;
 };
 
 constexpr size_t stage_bytes(int bm, int bn) { return (size_t)bm * (bn * 4 + 16); }  // epilogue staging tile (fp32 worst case)
@@ -637,6 +725,11 @@ constexpr size_t smem_of() {
 #define HALO(T, TN, TH, TW, BN, BK, WM, WN, ST)                                                     \
   {(TH) * (TW), BN, BK, ST, "conv3x3_halo<" TN "," #TH "x" #TW "," #BN "," #BK "," #WM "," #WN "," #ST ">", \
    conv3x3_halo<T, TH, TW, BN, BK, WM, WN, ST>, (size_t)ST * ((((BN) / 16) * ((BK) / 32) + 3) / 4) * 4 * 1024, TH, TW}
+
+#define REGQ(TH, TW, BN, CIN, NW, D)                                                                 \
+  {(TH) * (TW), BN, 32, 3, "conv3x3_regq<f16," #TH "x" #TW "," #BN "," #CIN "," #NW "w>",                \
+   conv3x3_regq<TH, TW, BN, CIN, NW, D>, 0, TH, TW, CIN, (NW) * 64}
+#define NOCFG {0, 0, 0, 0, "n/a", nullptr, 0, 0, 0, -1, 0}
 
 // [dtype][config]; BK is in fp16-equivalent k (KSUB = BK/32 fragment blocks): a K-step covers BK channels in fp16
 // and BK/2 channels in fp32.
@@ -670,6 +763,17 @@ const CfgInfo kCfg[3][kCfgCount] = {
         HALO(half_t, "f16", 8, 16, 64, 128, 2, 2, 4), // kCfgHalo8x16n64k128
         CFG(half_t, "f16", 32, 64, 128, 1, 4, 4),     // kCfg32x64k128
         CFG(half_t, "f16", 64, 64, 128, 2, 2, 4),     // kCfg64x64k128
+        REGQ(8, 16, 64, 128, 8, 16),                  // kCfgRegq8x16n64c128   (P3 head layers at 640^2)
+        REGQ(8, 8, 64, 128, 8, 16),                   // kCfgRegq8x8n64c128
+        REGQ(8, 8, 64, 256, 8, 16),                   // kCfgRegq8x8n64c256    (P4 head layers)
+        REGQ(8, 8, 32, 256, 8, 16),                   // kCfgRegq8x8n32c256
+        REGQ(8, 16, 64, 64, 8, 16),                   // kCfgRegq8x16n64c64    (P2 head layers when not fused)
+        REGQ(8, 16, 32, 128, 8, 16),                  // kCfgRegq8x16n32c128
+        // row bands x ONE channel subtile: at 640^2 exactly 256 workgroups, a weight block is read by 8 / 16 CUs only
+        REGQ(5, 40, 16, 256, 4, 16),                  // kCfgRegq5x40n16c256   (P4 head layers: 40x40 maps)
+        REGQ(5, 80, 16, 128, 4, 16),                  // kCfgRegq5x80n16c128   (P3 head layers: 80x80 maps)
+        REGQ(5, 40, 32, 256, 8, 16),                  // kCfgRegq5x40n32c256
+        REGQ(10, 40, 16, 128, 4, 16),                 // kCfgRegq10x40n16c128
     },
     {
         CFG(float, "f32", 64, 64, 64, 2, 2, 4),
@@ -700,6 +804,7 @@ const CfgInfo kCfg[3][kCfgCount] = {
         HALO(float, "f32", 8, 16, 64, 128, 2, 2, 4),
         CFG(float, "f32", 32, 64, 128, 1, 4, 4),
         CFG(float, "f32", 64, 64, 128, 2, 2, 4),
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,     // register-queue kernels are fp16 only
     },
     {
         CFG(signed char, "i8", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
@@ -730,16 +835,23 @@ const CfgInfo kCfg[3][kCfgCount] = {
         HALO(signed char, "i8", 8, 16, 64, 128, 2, 2, 4), // kCfgHalo8x16n64k128
         CFG(signed char, "i8", 32, 64, 128, 1, 4, 4),     // kCfg32x64k128
         CFG(signed char, "i8", 64, 64, 128, 2, 2, 4),     // kCfg64x64k128
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
     },
 };
 #undef CFG
 #undef HALO
+#undef REGQ
+#undef NOCFG
 
 inline int block_k(int dtype) { return dtype == kF32 ? 16 : (dtype == kI8 ? 64 : 32); }
 inline int kstep_of(const ConvParams& p, const CfgInfo& c) { return (c.bk / 32) * block_k(p.dtype); }
 inline size_t esize(const ConvParams& p) { return p.dtype == kF32 ? 4 : (p.dtype == kI8 ? 1 : 2); }
 inline size_t smem_for(const ConvParams& p, const CfgInfo& c) {
   if (!c.th) return c.smem;
+  if (c.cin) {  // register-queue kernel: patch (+ < 1 KiB overrun of its last DMA instruction) or the epilogue staging tile
+    const size_t patch = (((size_t)(c.th + 2) * (c.tw + 2) * c.cin * 2 + 1023) & ~(size_t)1023) + 1024;
+    return max_sz(patch, stage_bytes((c.bm + 15) & ~15, c.bn));
+  }
   const size_t patch = (size_t)(c.th + 2) * (c.tw + 2) * p.Cin * esize(p);
   return max_sz(c.smem + ((patch + 1023) & ~(size_t)1023), stage_bytes(c.bm, c.bn));
 }
@@ -756,6 +868,7 @@ int n_tiles(const ConvParams& p, int bn) {
 hipError_t conv_init() {
   for (int d = 0; d < 3; ++d)
     for (int c = 0; c < kCfgCount; ++c) {
+      if (!kCfg[d][c].fn) continue;
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kCfg[d][c].fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(kCfg[d][c].th ? kMaxLds : kCfg[d][c].smem));
       if (e != hipSuccess) return e;
@@ -766,6 +879,13 @@ hipError_t conv_init() {
 bool conv_config_valid(const ConvParams& p, int cfg) {
   if (cfg < 0 || cfg >= kCfgCount) return false;
   const CfgInfo& c = kCfg[p.dtype][cfg];
+  if (!c.fn) return false;
+  if (c.cin) {  // register-queue kernel: 3x3 / stride 1 on exactly its Cin, fp16 in; every slice at least one tile wide
+    if (p.dtype != kF16 || p.Cin != c.cin || p.ksize != 3 || p.stride != 1 || p.pad != 1 || smem_for(p, c) > kMaxLds) return false;
+    for (int s = 0; s < p.nseg; ++s)
+      if (((p.seg[s].n_count + 15) & ~15) < c.bn) return false;
+    return true;
+  }
   if (p.Cin % kstep_of(p, c)) return false;
   if (c.th) {  // halo kernel: 3x3, stride 1, pad 1, power-of-two chunk count, patch + ring must fit the CU's LDS
     const int nch = (int)(p.Cin * esize(p) / 16);
@@ -785,7 +905,7 @@ ConvLaunch conv_plan_with(const ConvParams& p, int cfg) {
   l.cfg = (ConvConfig)cfg;
   if (c.th) l.grid = dim3(((p.Ho + c.th - 1) / c.th) * ((p.Wo + c.tw - 1) / c.tw), n_tiles(p, c.bn), 1);
   else l.grid = dim3((p.M + c.bm - 1) / c.bm, n_tiles(p, c.bn), 1);
-  l.block = dim3(256, 1, 1);
+  l.block = dim3(c.nthreads, 1, 1);
   l.kernel_name = c.name;
   return l;
 }
@@ -822,6 +942,7 @@ hipError_t conv_launch(const ConvParams& pin, const ConvLaunch& l, hipStream_t s
   p.gm_magic = div_magic(l.grid.x);
   p.wo_magic = div_magic((unsigned)p.Wo);
   p.spt_magic = div_magic((unsigned)(p.Cin / kstep_of(p, c)));
+  if (c.th) p.tx_magic = div_magic((unsigned)((p.Wo + c.tw - 1) / c.tw));
   int t = 0;
   for (int s = 0; s < p.nseg; ++s) {
     p.seg[s].tile0 = t;

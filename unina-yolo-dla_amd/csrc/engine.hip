@@ -77,6 +77,7 @@ struct unina_engine {
   GpuDetection* d_cand = nullptr;
   int* d_block_count = nullptr;
   unsigned int* d_ticket = nullptr;
+  void* d_post_ws = nullptr;         // two-launch post-process workspace (sorted candidates, mask tiles, second ticket)
   DeviceResult* d_result = nullptr;
   DeviceResult* h_result = nullptr;  // pinned
   int post_blocks = 0;
@@ -90,6 +91,18 @@ struct unina_engine {
   int n_streams = 1;                       // parallel graph paths (UNINA_STREAMS); measured no gain on ROCm 7.2, so 1
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  // full-frame graph (unina_infer / unina_infer_async): stem + forward + post-process as ONE hipGraphLaunch. The two
+  // nodes whose parameters change from frame to frame (input pointer; thresholds / output buffers) are re-pointed with
+  // hipGraphExecKernelNodeSetParams instead of being launched separately (which cost a ~9 us bubble in front of the
+  // post-process and a separate submission for the stem).
+  bool full_graph = true;
+  hipGraph_t fgraph = nullptr;
+  hipGraphExec_t fexec = nullptr;
+  hipGraphNode_t stem_node = nullptr, post_node = nullptr, post_node2 = nullptr;
+  bool post_split = true;            // post-process as two launches (UNINA_POST_SPLIT=0: everything in one workgroup)
+  int stem_op = -1;
+  StemParams f_stem;
+  PostParams f_post;
   std::string err;
 };
 
@@ -127,8 +140,13 @@ int engine_dtype(const unina_engine* e);
 void drop_graph(unina_engine* e) {
   if (e->exec) (void)hipGraphExecDestroy(e->exec);
   if (e->graph) (void)hipGraphDestroy(e->graph);
+  if (e->fexec) (void)hipGraphExecDestroy(e->fexec);
+  if (e->fgraph) (void)hipGraphDestroy(e->fgraph);
   e->exec = nullptr;
   e->graph = nullptr;
+  e->fexec = nullptr;
+  e->fgraph = nullptr;
+  e->stem_node = e->post_node = e->post_node2 = nullptr;
 }
 
 int engine_dtype(const unina_engine* e) { return e->h.precision == kFp32 ? kF32 : kF16; }
@@ -673,6 +691,127 @@ void find_head_groups(unina_engine* e, std::vector<char>* blob) {
   }
 }
 
+// ---- full-frame graph ------------------------------------------------------------------------------------------------
+hipError_t last_captured_node(hipStream_t st, hipGraphNode_t* node) {
+  hipStreamCaptureStatus status;
+  unsigned long long id = 0;
+  hipGraph_t g = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t ndeps = 0;
+  hipError_t err = hipStreamGetCaptureInfo_v2(st, &status, &id, &g, &deps, &ndeps);
+  if (err != hipSuccess) return err;
+  if (status != hipStreamCaptureStatusActive || ndeps != 1) return hipErrorInvalidValue;
+  *node = deps[0];
+  return hipSuccess;
+}
+
+int capture_full(unina_engine* e, const PostParams& pp) {
+  if (e->fexec) (void)hipGraphExecDestroy(e->fexec);
+  if (e->fgraph) (void)hipGraphDestroy(e->fgraph);
+  e->fexec = nullptr;
+  e->fgraph = nullptr;
+  e->stem_node = e->post_node = e->post_node2 = nullptr;
+  e->stem_op = -1;
+  hipStream_t st = e->capture_stream;
+  HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  hipError_t err = hipSuccess;
+  int rc = UNINA_OK;
+  for (size_t j = 0; j < e->ops.size() && err == hipSuccess; ++j) {
+    err = launch_op(e, j, st);
+    if (err != hipSuccess) {
+      rc = fail(e, UNINA_ERR_HIP, "op %zu (%s): %s", j, e->ops[j].d.name, hipGetErrorString(err));
+      break;
+    }
+    if (is_eager(e, j) && e->ops[j].d.kind == kOpStem && e->stem_op < 0) {
+      err = last_captured_node(st, &e->stem_node);
+      e->stem_op = (int)j;
+    }
+  }
+  LaunchDesc pd[2];
+  const int npost = postprocess_desc(pp, pd);
+  if (npost < 1) err = hipErrorInvalidValue;
+  for (int k = 0; k < npost && err == hipSuccess; ++k) {
+    PostParams copy = pp;
+    void* args[] = {&copy};
+    err = hipLaunchKernel(pd[k].func, pd[k].grid, pd[k].block, args, pd[k].shmem, st);
+    if (err == hipSuccess) err = last_captured_node(st, k == 0 ? &e->post_node : &e->post_node2);
+  }
+  hipError_t end = hipStreamEndCapture(st, &e->fgraph);
+  if (rc != UNINA_OK) return rc;
+  if (err != hipSuccess) return fail(e, UNINA_ERR_HIP, "full-frame graph capture: %s", hipGetErrorString(err));
+  if (end != hipSuccess) return fail(e, UNINA_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(end));
+  if (e->stem_op < 0 || !e->stem_node || !e->post_node) return fail(e, UNINA_ERR_STATE, "full-frame graph: stem / post-process node not found");
+  HIPCHK(e, hipGraphInstantiate(&e->fexec, e->fgraph, nullptr, nullptr, 0));
+  e->f_stem = e->ops[e->stem_op].sp;
+  e->f_post = pp;
+  return UNINA_OK;
+}
+
+template <typename P>
+hipError_t set_node(hipGraphExec_t exec, hipGraphNode_t node, const LaunchDesc& d, const P& params) {
+  P copy = params;
+  void* args[] = {&copy};
+  hipKernelNodeParams np;
+  memset(&np, 0, sizeof np);
+  np.func = const_cast<void*>(d.func);
+  np.gridDim = d.grid;
+  np.blockDim = d.block;
+  np.sharedMemBytes = d.shmem;
+  np.kernelParams = args;
+  return hipGraphExecKernelNodeSetParams(exec, node, &np);
+}
+
+// One graph launch for the whole frame; re-points the stem / post-process nodes when their parameters changed.
+int launch_full(unina_engine* e, const PostParams& pp, hipStream_t stream) {
+  if (!e->fexec) {
+    int rc = capture_full(e, pp);
+    if (rc != UNINA_OK) return rc;
+  } else {
+    const StemParams& sp = e->ops[e->stem_op].sp;
+    if (memcmp(&sp, &e->f_stem, sizeof sp)) {
+      LaunchDesc d;
+      HIPCHK(e, stem_desc(sp, &d));
+      HIPCHK(e, set_node(e->fexec, e->stem_node, d, sp));
+      e->f_stem = sp;
+    }
+    if (memcmp(&pp, &e->f_post, sizeof pp)) {
+      LaunchDesc d[2];
+      const int npost = postprocess_desc(pp, d);
+      if (npost < 1 || (npost == 2) != (e->post_node2 != nullptr)) return fail(e, UNINA_ERR_STATE, "post-process launch shape changed");
+      HIPCHK(e, set_node(e->fexec, e->post_node, d[0], pp));
+      if (npost == 2) HIPCHK(e, set_node(e->fexec, e->post_node2, d[1], pp));
+      e->f_post = pp;
+    }
+  }
+  HIPCHK(e, hipGraphLaunch(e->fexec, stream));
+  return UNINA_OK;
+}
+
+// Mean duration of op `i` measured INSIDE the frame sequence: every repetition replays ops 0..i-1 first, so the op
+// finds the caches as it does in a real frame (weights cold in L2, inputs just written). Timing back-to-back repeats
+// of one launch instead keeps its weights L2-resident and ranks weight-heavy configurations wrongly (measured: a
+// configuration that re-reads 2.4 MB of weights from 25 workgroup columns won the warm timing at 13.4 us and ran
+// 20.8 us in the frame). `launch` issues op i (so that the autotuner can substitute a candidate configuration).
+template <typename F>
+int time_in_sequence(unina_engine* e, size_t i, int iters, hipStream_t stream, hipEvent_t a, hipEvent_t b, F launch, float* ms_out) {
+  float total = 0.f;
+  for (int it = 0; it < iters; ++it) {
+    for (size_t k = 0; k < i; ++k) {
+      hipError_t err = launch_op(e, k, stream);
+      if (err != hipSuccess) return fail(e, UNINA_ERR_HIP, "op %zu (%s): %s", k, e->ops[k].d.name, hipGetErrorString(err));
+    }
+    HIPCHK(e, hipEventRecord(a, stream));
+    HIPCHK(e, launch());
+    HIPCHK(e, hipEventRecord(b, stream));
+    HIPCHK(e, hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(e, hipEventElapsedTime(&ms, a, b));
+    total += ms;
+  }
+  *ms_out = total / (float)iters;
+  return UNINA_OK;
+}
+
 int find_buffer(const unina_engine* e, const char* name) {
   for (size_t i = 0; i < e->bufs.size(); ++i)
     if (!strncmp(e->bufs[i].d.name, name, sizeof e->bufs[i].d.name)) return (int)i;
@@ -716,6 +855,7 @@ int fill_post_params(unina_engine* e, PostParams* pp, float conf, float iou, flo
   pp->cand = e->d_cand;
   pp->block_count = e->d_block_count;
   pp->ticket = e->d_ticket;
+  if (e->post_split) post_bind_workspace(pp, e->d_post_ws);
   pp->out = d_out;
   pp->out_count = d_count;
   pp->out_candidates = d_cand_count;
@@ -843,6 +983,8 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   LOADCHK(hipMalloc(&e->d_block_count, sizeof(int) * (size_t)e->post_blocks));
   LOADCHK(hipMalloc(&e->d_ticket, sizeof(unsigned int)));
   LOADCHK(hipMemset(e->d_ticket, 0, sizeof(unsigned int)));
+  LOADCHK(hipMalloc(&e->d_post_ws, post_workspace_bytes()));
+  LOADCHK(hipMemset(e->d_post_ws, 0, post_workspace_bytes()));
   LOADCHK(hipMalloc(&e->d_result, sizeof(DeviceResult)));
   LOADCHK(hipMemset(e->d_result, 0, sizeof(DeviceResult)));
   LOADCHK(hipHostMalloc(&e->h_result, sizeof(DeviceResult), hipHostMallocDefault));
@@ -852,6 +994,8 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   const char* ng = getenv("UNINA_NO_GRAPH");
   e->use_graph = !(ng && ng[0] == '1');
   if (const char* ns = getenv("UNINA_STREAMS")) e->n_streams = atoi(ns) > 0 ? atoi(ns) : 1;
+  if (const char* fg = getenv("UNINA_FULL_GRAPH")) e->full_graph = fg[0] != '0';
+  if (const char* ps = getenv("UNINA_POST_SPLIT")) e->post_split = ps[0] != '0';
   e->plan_dirty = true;
   *out = e;
   return UNINA_OK;
@@ -865,7 +1009,7 @@ void unina_unload_engine(unina_engine_t* e) {
   for (hipStream_t st : e->side_streams) (void)hipStreamDestroy(st);
   for (hipEvent_t ev : e->op_events) (void)hipEventDestroy(ev);
   if (e->fork_event) (void)hipEventDestroy(e->fork_event);
-  void* dev[] = {e->d_blob, e->d_arena, e->d_zeros, e->d_cand, e->d_block_count, e->d_ticket, e->d_result};
+  void* dev[] = {e->d_blob, e->d_arena, e->d_zeros, e->d_cand, e->d_block_count, e->d_ticket, e->d_post_ws, e->d_result};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (e->h_result) (void)hipHostFree(e->h_result);
@@ -942,6 +1086,18 @@ int unina_infer_async(unina_engine_t* e, const float* d_images, float conf, floa
   if (d_images) {
     int rc = unina_set_tensor_address(e, "images", const_cast<float*>(d_images));
     if (rc != UNINA_OK) return rc;
+  }
+  if (e->full_graph && e->use_graph && e->n_streams <= 1) {
+    if (!d_out || !d_out_count) return UNINA_ERR_ARG;
+    HIPCHK(e, hipSetDevice(e->device));
+    if (!e->bufs[e->images_buf].ptr) return fail(e, UNINA_ERR_STATE, "tensor 'images' is not bound");
+    if (e->plan_dirty) {
+      int rc = plan(e);
+      if (rc != UNINA_OK) return rc;
+    }
+    PostParams pp;
+    fill_post_params(e, &pp, conf, iou, q, d_out, d_out_count, &e->d_result->candidates);
+    return launch_full(e, pp, stream);
   }
   int rc = unina_enqueue(e, stream);
   if (rc != UNINA_OK) return rc;
@@ -1089,13 +1245,9 @@ int unina_autotune(unina_engine_t* e, int iters, hipStream_t stream) {
     for (int cfg = 0; cfg < (int)kCfgCount; ++cfg) {
       if (!conv_config_valid(e->ops[i].cp, cfg)) continue;
       const ConvLaunch l = conv_plan_with(e->ops[i].cp, cfg);
-      HIPCHK(e, conv_launch(e->ops[i].cp, l, stream));
-      HIPCHK(e, hipEventRecord(a, stream));
-      for (int it = 0; it < iters; ++it) HIPCHK(e, conv_launch(e->ops[i].cp, l, stream));
-      HIPCHK(e, hipEventRecord(b, stream));
-      HIPCHK(e, hipEventSynchronize(b));
       float ms = 0.f;
-      HIPCHK(e, hipEventElapsedTime(&ms, a, b));
+      rc = time_in_sequence(e, i, iters, stream, a, b, [&]() { return conv_launch(e->ops[i].cp, l, stream); }, &ms);
+      if (rc != UNINA_OK) return rc;
       if (ms < best) {
         best = ms;
         best_cfg = cfg;
@@ -1127,14 +1279,8 @@ int unina_profile_ops(unina_engine_t* e, int iters, float* ms_per_op, hipStream_
       ms_per_op[i] = 0.f;
       continue;
     }
-    HIPCHK(e, launch_op(e, i, stream));
-    HIPCHK(e, hipEventRecord(a, stream));
-    for (int it = 0; it < iters; ++it) HIPCHK(e, launch_op(e, i, stream));
-    HIPCHK(e, hipEventRecord(b, stream));
-    HIPCHK(e, hipEventSynchronize(b));
-    float ms = 0.f;
-    HIPCHK(e, hipEventElapsedTime(&ms, a, b));
-    ms_per_op[i] = ms / (float)iters;
+    rc = time_in_sequence(e, i, iters, stream, a, b, [&]() { return launch_op(e, i, stream); }, &ms_per_op[i]);
+    if (rc != UNINA_OK) return rc;
   }
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);

@@ -49,7 +49,7 @@ struct ConvParams {
   const void* zeros;   // >= 16 bytes of zeros in HBM: source of out-of-image taps / tile tails
   int force_cfg;       // >= 0: use this tile configuration (autotuner / tests); -1: heuristic
   int grid_m;          // number of M tiles (filled at launch): the 1-D grid is re-mapped XCD-aware in the kernel
-  unsigned gm_magic, wo_magic, spt_magic;  // ceil(2^32/d) for d = grid_m, Wo, K-steps per tap (0: d == 1), filled at launch
+  unsigned gm_magic, wo_magic, spt_magic, tx_magic;  // ceil(2^32/d) for d = grid_m, Wo, K-steps per tap, spatial tiles per row (0: d == 1), filled at launch
   int debug_mode;      // debug ablations (results invalid): 1 = no loads inside the K loop, 2 = no LDS reads/MFMA, 3 = MFMA without LDS reads
   long long* stamps;   // debug: s_memtime stamps of workgroup (0,0) (nullptr = off): start, prologue issued, first data, loop end, end
 };
@@ -62,6 +62,8 @@ enum ConvConfig : int {
   kCfgHalo16x16n64, kCfgHalo16x16n32, kCfgHalo8x16n64w41, kCfgHalo8x8n64w41,
   kCfgHalo8x8n32k128, kCfgHalo8x8n32k256, kCfgHalo8x8n64k128, kCfgHalo8x16n32k128, kCfgHalo8x16n64k128,
   kCfg32x64k128, kCfg64x64k128,
+  kCfgRegq8x16n64c128, kCfgRegq8x8n64c128, kCfgRegq8x8n64c256, kCfgRegq8x8n32c256, kCfgRegq8x16n64c64, kCfgRegq8x16n32c128,
+  kCfgRegq5x40n16c256, kCfgRegq5x80n16c128, kCfgRegq5x40n32c256, kCfgRegq10x40n16c128,
   kCfgCount
 };
 struct ConvLaunch {
@@ -153,6 +155,14 @@ struct StemParams {
   int H, W, Ho, Wo, Co, dst_ld;
 };
 hipError_t stem_launch(const StemParams& p, hipStream_t stream, dim3* grid_out = nullptr, dim3* block_out = nullptr);
+// Launch descriptor of a kernel whose only argument is its parameter struct: what hipGraphExecKernelNodeSetParams needs
+// to re-point a captured node at new parameters (a different input frame, other thresholds / output buffers).
+struct LaunchDesc {
+  const void* func;
+  dim3 grid, block;
+  unsigned shmem;
+};
+hipError_t stem_desc(const StemParams& p, LaunchDesc* out);
 
 // ------------------------------------------------------------------------------------------------
 // SPPF pool pyramid: y1 = pool5(x), y2 = pool5(y1), y3 = pool5(y2) (== 5x5, 9x9, 13x13 clipped windows of x)
@@ -201,9 +211,20 @@ struct PostParams {
   int* out_count;            // kept
   int* out_candidates;       // optional (may be nullptr): number of cells that passed the threshold
   long long* stamps;         // optional debug: 8 wall_clock64 stamps of the last block's phases (nullptr = off)
+  // two-launch form (engine): launch 1 ends with the sorted candidates in this workspace, launch 2 builds the
+  // suppression-mask tiles on many CUs and its last block scans + compacts. All nullptr = everything in launch 1.
+  float4* ws_box;            // [MAX_DETECTIONS] sorted boxes
+  float2* ws_cc;             // [MAX_DETECTIONS] sorted (confidence, class bits)
+  int* ws_n;                 // number of sorted candidates
+  unsigned long long* ws_mask;    // upper-triangular 64x64-bit suppression tiles
+  unsigned long long* ws_tilenz;  // per tile: rows with a non-empty mask
+  unsigned int* ticket2;     // arrival counter of launch 2 (zero at rest)
 };
+size_t post_workspace_bytes();
+void post_bind_workspace(PostParams* p, void* ws);   // ws: post_workspace_bytes() of device memory, zeroed once
 constexpr int kPostBlock = 1024;
 int post_num_blocks(const int gw[3], const int gh[3]);
 hipError_t postprocess_launch(const PostParams& p, hipStream_t stream);
+int postprocess_desc(const PostParams& p, LaunchDesc out[2]);   // number of launches (1 or 2), or -1 on error
 
 }  // namespace unina

@@ -118,17 +118,17 @@ __device__ __forceinline__ bool decode_cell(const float* __restrict__ cls, const
 
 // Publishes this block's global stores and draws an arrival ticket; returns true in exactly one block (the last
 // to arrive), with every other block's stores visible to it (agent-scope release / acquire).
-__device__ __forceinline__ bool arrive_and_check_last(unsigned int* ticket, Smem& s) {
+__device__ __forceinline__ bool arrive_and_check_last(unsigned int* ticket, int* is_last /*LDS*/) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s.is_last = (t == gridDim.x - 1) ? 1 : 0;
+    *is_last = (t == gridDim.x - 1) ? 1 : 0;
   }
   __syncthreads();
-  if (!s.is_last) return false;
+  if (!*is_last) return false;
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -189,17 +189,31 @@ __device__ __forceinline__ GpuDetection get(const Smem& s, int pos, int valid) {
 
 __device__ __forceinline__ int tri_off(int c, int nw) { return 64 * (c * nw - (c * (c - 1)) / 2); }
 
-// Records 0..n) sit in s.box / s.cc in enumeration order. On return they are in SORTED order (confidence
-// descending, ties by enumeration order) and s.removed holds the greedy-NMS suppression bits by sorted index.
-//   sort : rank sort -- thread i counts the keys larger than its own with broadcast LDS reads (no barriers)
-//   masks: the upper-triangular 64x64 tiles are dealt round-robin to the 16 waves; lane = row, the 64 columns of
-//          a tile are visited in lock-step so every LDS read is a broadcast; the division only runs for pairs
-//          that really overlap
-//   scan : wave 0 walks the chunks in order and visits only rows that suppress something
-__device__ void sort_and_nms(Smem& s, int n, float iou_thr, long long* stamps = nullptr) {
-#define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
+// Sequential greedy pass over the suppression bitmap by ONE wave: walks the 64-row chunks in order and visits only
+// rows that suppress something; a row that was itself suppressed suppresses nothing. lane w (< kWords) owns word w.
+__device__ __forceinline__ void greedy_scan(const unsigned long long* mask, const unsigned long long* rownz,
+                                            unsigned long long* removed, int nw, int lane) {
+  unsigned long long removed_reg = 0ull;
+  for (int c = 0; c < nw; ++c) {
+    unsigned long long todo = rownz[c];
+    unsigned long long cur = __shfl(removed_reg, c);
+    const int base = tri_off(c, nw), stride = nw - c;
+    while (todo) {
+      const int r = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      if ((cur >> r) & 1ull) continue;  // row r was itself suppressed: it suppresses nothing
+      if (lane >= c && lane < nw) removed_reg |= mask[base + r * stride + (lane - c)];
+      cur = __shfl(removed_reg, c);
+    }
+  }
+  if (lane < kWords) removed[lane] = removed_reg;
+}
+
+// Records 0..n) sit in s.box / s.cc in enumeration order; on return they are in SORTED order (confidence descending,
+// ties by enumeration order), padded to a multiple of 64 with never-suppressed dummies. Rank sort: thread i counts
+// the keys larger than its own with broadcast LDS reads (no barriers).
+__device__ void rank_sort_records(Smem& s, int n) {
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = tid >> 6;
   // keys; entries n..n8) are zero so that the fixed-trip, unrolled scans below never count them
   const int n8 = (n + 7) & ~7;
   if (tid < n8)
@@ -233,7 +247,30 @@ __device__ void sort_and_nms(Smem& s, int n, float iou_thr, long long* stamps = 
   }
   if (tid < kWords) s.rownz[tid] = 0ull;
   __syncthreads();
+}
 
+// One pair test of the greedy NMS, shared by the one-block and the tiled form (identical arithmetic and order).
+__device__ __forceinline__ bool suppresses(const float4& a, const float2& ac, float area_a, const float4& bb, const float2& bc,
+                                           bool ordered, float iou_thr) {
+  const float ix1 = fmaxf(a.x, bb.x), iy1 = fmaxf(a.y, bb.y);
+  const float ix2 = fminf(a.z, bb.z), iy2 = fminf(a.w, bb.w);
+  const bool cand = ordered && __float_as_int(bc.y) == __float_as_int(ac.y) && ac.x > bc.x && !(ix1 >= ix2 || iy1 >= iy2);
+  if (!cand) return false;
+  const float inter = (ix2 - ix1) * (iy2 - iy1);
+  const float area_b = (bb.z - bb.x) * (bb.w - bb.y);
+  return inter / (area_a + area_b - inter + 1e-6f) > iou_thr;
+}
+
+// One-block form: sort, then s.removed = greedy-NMS suppression bits by sorted index.
+//   masks: the upper-triangular 64x64 tiles are dealt round-robin to the 16 waves; lane = row, the 64 columns of
+//          a tile are visited in lock-step so every LDS read is a broadcast; the division only runs for pairs
+//          that really overlap
+//   scan : wave 0 walks the chunks in order and visits only rows that suppress something
+__device__ void sort_and_nms(Smem& s, int n, float iou_thr, long long* stamps = nullptr) {
+#define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
+  rank_sort_records(s, n);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
   STAMP(3);
   const int nw = (n + 63) >> 6;
   const int ntiles = nw * (nw + 1) / 2;
@@ -250,7 +287,6 @@ __device__ void sort_and_nms(Smem& s, int n, float iou_thr, long long* stamps = 
     const float2 ac = s.cc[row_ok ? i : 0];
     const float area_a = (a.z - a.x) * (a.w - a.y);
     unsigned long long bits = 0ull;
-    const int acls = __float_as_int(ac.y);
     for (int b0 = 0; b0 < 64; b0 += 8) {  // fixed trip count: 16 broadcast LDS reads in flight
       float4 bb[8];
       float2 bc[8];
@@ -262,15 +298,7 @@ __device__ void sort_and_nms(Smem& s, int n, float iou_thr, long long* stamps = 
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int j = w * 64 + b0 + u;
-        const float ix1 = fmaxf(a.x, bb[u].x), iy1 = fmaxf(a.y, bb[u].y);
-        const float ix2 = fminf(a.z, bb[u].z), iy2 = fminf(a.w, bb[u].w);
-        const bool cand = row_ok && j > i && __float_as_int(bc[u].y) == acls && ac.x > bc[u].x &&
-                          !(ix1 >= ix2 || iy1 >= iy2);
-        if (cand) {
-          const float inter = (ix2 - ix1) * (iy2 - iy1);
-          const float area_b = (bb[u].z - bb[u].x) * (bb[u].w - bb[u].y);
-          if (inter / (area_a + area_b - inter + 1e-6f) > iou_thr) bits |= 1ull << (b0 + u);
-        }
+        if (suppresses(a, ac, area_a, bb[u], bc[u], row_ok && j > i, iou_thr)) bits |= 1ull << (b0 + u);
       }
     }
     s.mask[tri_off(c, nw) + lane * (nw - c) + (w - c)] = bits;
@@ -280,22 +308,7 @@ __device__ void sort_and_nms(Smem& s, int n, float iou_thr, long long* stamps = 
   __syncthreads();
   STAMP(4);
 
-  if (tid < 64) {
-    unsigned long long removed_reg = 0ull;  // lane w (< kWords) owns word w of the suppression bitmap
-    for (int c = 0; c < nw; ++c) {
-      unsigned long long todo = s.rownz[c];
-      unsigned long long cur = __shfl(removed_reg, c);
-      const int base = tri_off(c, nw), stride = nw - c;
-      while (todo) {
-        const int r = __ffsll((long long)todo) - 1;
-        todo &= todo - 1ull;
-        if ((cur >> r) & 1ull) continue;  // row r was itself suppressed: it suppresses nothing
-        if (lane >= c && lane < nw) removed_reg |= s.mask[base + r * stride + (lane - c)];
-        cur = __shfl(removed_reg, c);
-      }
-    }
-    if (lane < kWords) s.removed[lane] = removed_reg;
-  }
+  if (tid < 64) greedy_scan(s.mask, s.rownz, s.removed, nw, lane);
   __syncthreads();
   STAMP(5);
 #undef STAMP
@@ -329,7 +342,7 @@ __global__ __launch_bounds__(kPostBlock) void postprocess_kernel(const PostParam
     if (tid == 0) p.block_count[blockIdx.x] = total;
   }
   if (p.stamps && tid == 0 && blockIdx.x == 0) p.stamps[0] = wall_clock64();
-  if (!arrive_and_check_last(p.ticket, s)) return;
+  if (!arrive_and_check_last(p.ticket, &s.is_last)) return;
   if (p.stamps && tid == 0) p.stamps[1] = wall_clock64();
 
   // ---- phase 2 (one block): gather in enumeration order ----
@@ -387,6 +400,22 @@ __global__ __launch_bounds__(kPostBlock) void postprocess_kernel(const PostParam
   __syncthreads();
 
   if (p.stamps && tid == 0) p.stamps[2] = wall_clock64();
+  if (p.ws_box) {
+    // two-launch form: publish the sorted candidates; nms_tiles_kernel (next launch) does the rest on many CUs
+    rank_sort_records(s, n);
+    const int n64 = (n + 63) & ~63;
+    if (tid < n64) {
+      p.ws_box[tid] = s.box[tid];
+      p.ws_cc[tid] = s.cc[tid];
+    }
+    if (tid == 0) {
+      *p.ws_n = n;
+      if (p.out_candidates) *p.out_candidates = total;
+      __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+      if (p.stamps) p.stamps[3] = wall_clock64();
+    }
+    return;
+  }
   sort_and_nms(s, n, p.iou_thr, p.stamps);
 
   // ---- compaction + output ----
@@ -402,6 +431,115 @@ __global__ __launch_bounds__(kPostBlock) void postprocess_kernel(const PostParam
   }
 }
 
+// ---- launch 2 of the two-launch form: suppression-mask tiles on many CUs, then scan + compaction by the last block ----
+// The one-block form spends ~27 of its ~42 us (n ~ 500) building the n^2/2 pair bitmap on ONE CU (VALU-bound). Here
+// every upper-triangular 64x64 tile is its own 256-thread workgroup (wave v: columns 16v..16v+15, lane = row); the
+// workgroup that draws the last arrival ticket (same release/acquire hand-off as launch 1) loads the tiles, runs the
+// sequential greedy scan on one wave and writes the compacted output. Pair arithmetic and order are unchanged.
+constexpr int kTileThreads = 256;
+constexpr int kMaxTiles = kWords * (kWords + 1) / 2;
+struct Smem2 {
+  float4 rbox[64], cbox[64];
+  float2 rcc[64], ccc[64];
+  unsigned short piece[64][4];
+  unsigned long long mask[kTriWords];
+  unsigned long long rownz[kWords];
+  unsigned long long removed[kWords];
+  int wave_cnt[4];
+  int is_last;
+};
+
+__global__ __launch_bounds__(kTileThreads) void nms_tiles_kernel(const PostParams p) {
+  Smem2& s = *reinterpret_cast<Smem2*>(post_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = *p.ws_n;
+  const int nw = (n + 63) >> 6;
+  const int ntiles = nw * (nw + 1) / 2;
+  const int t = blockIdx.x;
+  if (t < ntiles) {
+    int c = 0, rem = t;  // tile t -> (chunk row c, word w >= c)
+    while (rem >= nw - c) {
+      rem -= nw - c;
+      ++c;
+    }
+    const int w = c + rem;
+    if (tid < 64) {           // launch 1 padded the sorted arrays to a multiple of 64
+      s.rbox[tid] = p.ws_box[c * 64 + tid];
+      s.rcc[tid] = p.ws_cc[c * 64 + tid];
+    } else if (tid < 128) {
+      s.cbox[tid - 64] = p.ws_box[w * 64 + tid - 64];
+      s.ccc[tid - 64] = p.ws_cc[w * 64 + tid - 64];
+    }
+    __syncthreads();
+    const int i = c * 64 + lane;
+    const bool row_ok = i < n;
+    const float4 a = s.rbox[lane];
+    const float2 ac = s.rcc[lane];
+    const float area_a = (a.z - a.x) * (a.w - a.y);
+    unsigned int bits = 0u;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int col = wv * 16 + u;
+      const int j = w * 64 + col;
+      if (suppresses(a, ac, area_a, s.cbox[col], s.ccc[col], row_ok && j > i, p.iou_thr)) bits |= 1u << u;
+    }
+    s.piece[lane][wv] = (unsigned short)bits;
+    __syncthreads();
+    if (tid < 64) {
+      const unsigned long long word = (unsigned long long)s.piece[tid][0] | ((unsigned long long)s.piece[tid][1] << 16) |
+                                      ((unsigned long long)s.piece[tid][2] << 32) | ((unsigned long long)s.piece[tid][3] << 48);
+      p.ws_mask[tri_off(c, nw) + tid * (nw - c) + (w - c)] = word;
+      const unsigned long long nz = __ballot(word != 0ull);
+      if (tid == 0) p.ws_tilenz[t] = nz;
+    }
+  }
+  if (!arrive_and_check_last(p.ticket2, &s.is_last)) return;
+
+  // ---- last block: scan + compaction + output ----
+  for (int k = tid; k < 64 * ntiles; k += kTileThreads) s.mask[k] = p.ws_mask[k];
+  if (tid < kWords) {
+    unsigned long long nz = 0ull;
+    if (tid < nw)
+      for (int w = tid; w < nw; ++w) nz |= p.ws_tilenz[(tid * nw - (tid * (tid - 1)) / 2) + (w - tid)];
+    s.rownz[tid] = nz;
+  }
+  __syncthreads();
+  if (tid < 64) greedy_scan(s.mask, s.rownz, s.removed, nw, lane);
+  __syncthreads();
+  int base = 0;
+  for (int i0 = 0; i0 < n; i0 += kTileThreads) {
+    const int i = i0 + tid;
+    const bool kept = i < n && !((s.removed[i >> 6] >> (i & 63)) & 1ull);
+    const unsigned long long b = __ballot(kept);
+    __syncthreads();  // protect wave_cnt from the previous round
+    if (lane == 0) s.wave_cnt[wv] = __popcll(b);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (v < wv) off += s.wave_cnt[v];
+      tot += s.wave_cnt[v];
+    }
+    if (kept) {
+      const float4 bx = p.ws_box[i];
+      const float2 cc = p.ws_cc[i];
+      GpuDetection d;
+      d.x1 = bx.x; d.y1 = bx.y; d.x2 = bx.z; d.y2 = bx.w;
+      d.confidence = cc.x;
+      d.class_id = __float_as_int(cc.y);
+      d.valid = 1;
+      d._pad = 0;
+      p.out[base + off + __popcll(b & ((1ull << lane) - 1ull))] = d;
+    }
+    base += tot;
+  }
+  if (tid == 0) {
+    *p.out_count = base;
+    __hip_atomic_store(p.ticket2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    if (p.stamps) p.stamps[6] = wall_clock64();
+  }
+}
+
 namespace { hipError_t post_init(); }
 
 int post_num_blocks(const int gw[3], const int gh[3]) {
@@ -409,17 +547,51 @@ int post_num_blocks(const int gw[3], const int gh[3]) {
   return (cells + kPostBlock - 1) / kPostBlock;
 }
 
-hipError_t postprocess_launch(const PostParams& p, hipStream_t stream) {
+size_t post_workspace_bytes() {
+  return sizeof(float4) * kMaxDet + sizeof(float2) * kMaxDet + sizeof(unsigned long long) * (kTriWords + kMaxTiles) + 256;
+}
+
+void post_bind_workspace(PostParams* p, void* ws) {
+  char* c = static_cast<char*>(ws);
+  p->ws_box = reinterpret_cast<float4*>(c); c += sizeof(float4) * kMaxDet;
+  p->ws_cc = reinterpret_cast<float2*>(c); c += sizeof(float2) * kMaxDet;
+  p->ws_mask = reinterpret_cast<unsigned long long*>(c); c += sizeof(unsigned long long) * kTriWords;
+  p->ws_tilenz = reinterpret_cast<unsigned long long*>(c); c += sizeof(unsigned long long) * kMaxTiles;
+  p->ws_n = reinterpret_cast<int*>(c);
+  p->ticket2 = reinterpret_cast<unsigned int*>(c + 64);
+}
+
+int postprocess_desc(const PostParams& p, LaunchDesc out[2]) {
   const int nb = post_num_blocks(p.gw, p.gh);
-  if (nb < 1 || nb > kPostBlock) return hipErrorInvalidValue;
+  if (nb < 1 || nb > kPostBlock) return -1;
   static bool attr_set = false;  // raise the dynamic-LDS limit once per process
   if (!attr_set) {
-    hipError_t e = post_init();
-    if (e != hipSuccess) return e;
+    if (post_init() != hipSuccess) return -1;
     attr_set = true;
   }
-  postprocess_kernel<<<nb, kPostBlock, kPostSmemBytes, stream>>>(p);
-  return hipGetLastError();
+  out[0].func = reinterpret_cast<const void*>(&postprocess_kernel);
+  out[0].grid = dim3(nb);
+  out[0].block = dim3(kPostBlock);
+  out[0].shmem = (unsigned)kPostSmemBytes;
+  if (!p.ws_box) return 1;
+  out[1].func = reinterpret_cast<const void*>(&nms_tiles_kernel);
+  out[1].grid = dim3(kMaxTiles);   // n is only known on the device: tiles past the triangle just draw their ticket
+  out[1].block = dim3(kTileThreads);
+  out[1].shmem = (unsigned)sizeof(Smem2);
+  return 2;
+}
+
+hipError_t postprocess_launch(const PostParams& p, hipStream_t stream) {
+  LaunchDesc d[2];
+  const int n = postprocess_desc(p, d);
+  if (n < 1) return hipErrorInvalidValue;
+  PostParams copy = p;
+  void* args[] = {&copy};
+  for (int k = 0; k < n; ++k) {
+    hipError_t e = hipLaunchKernel(d[k].func, d[k].grid, d[k].block, args, d[k].shmem, stream);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 // ================================================================================================ step-wise API
@@ -457,7 +629,7 @@ __global__ __launch_bounds__(kPostBlock) void decode_head_append_kernel(const fl
   const int pos = block_rank(pass, s, &total);
   if (pass) cand[(size_t)blockIdx.x * kT + pos] = d;
   if (tid == 0) block_count[blockIdx.x] = total;
-  if (!arrive_and_check_last(ticket, s)) return;
+  if (!arrive_and_check_last(ticket, &s.is_last)) return;
   const int nblocks = gridDim.x;
   const int tot = scan_block_counts(block_count, nblocks, s);
   const int base = *d_count;
@@ -497,7 +669,7 @@ hipError_t post_init() {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPostSmemBytes);
     if (e != hipSuccess) return e;
   }
-  return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(nms_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem2));
 }
 
 }  // namespace

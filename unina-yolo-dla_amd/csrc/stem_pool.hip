@@ -64,16 +64,27 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
   }
 }
 
-hipError_t stem_launch(const StemParams& p, hipStream_t stream, dim3* grid_out, dim3* block_out) {
-  dim3 grid((p.Ho * p.Wo + 255) / 256), block(256);
-  if (grid_out) *grid_out = grid;
-  if (block_out) *block_out = block;
-  if (p.Co == 32 && p.dtype == kF16) stem_conv_kernel<half_t, 32><<<grid, block, 0, stream>>>(p);
-  else if (p.Co == 64 && p.dtype == kF16) stem_conv_kernel<half_t, 64><<<grid, block, 0, stream>>>(p);
-  else if (p.Co == 32 && p.dtype == kF32) stem_conv_kernel<float, 32><<<grid, block, 0, stream>>>(p);
-  else if (p.Co == 64 && p.dtype == kF32) stem_conv_kernel<float, 64><<<grid, block, 0, stream>>>(p);
+hipError_t stem_desc(const StemParams& p, LaunchDesc* out) {
+  out->grid = dim3((p.Ho * p.Wo + 255) / 256);
+  out->block = dim3(256);
+  out->shmem = 0;
+  if (p.Co == 32 && p.dtype == kF16) out->func = reinterpret_cast<const void*>(&stem_conv_kernel<half_t, 32>);
+  else if (p.Co == 64 && p.dtype == kF16) out->func = reinterpret_cast<const void*>(&stem_conv_kernel<half_t, 64>);
+  else if (p.Co == 32 && p.dtype == kF32) out->func = reinterpret_cast<const void*>(&stem_conv_kernel<float, 32>);
+  else if (p.Co == 64 && p.dtype == kF32) out->func = reinterpret_cast<const void*>(&stem_conv_kernel<float, 64>);
   else return hipErrorInvalidValue;
-  return hipGetLastError();
+  return hipSuccess;
+}
+
+hipError_t stem_launch(const StemParams& p, hipStream_t stream, dim3* grid_out, dim3* block_out) {
+  LaunchDesc d;
+  hipError_t e = stem_desc(p, &d);
+  if (e != hipSuccess) return e;
+  if (grid_out) *grid_out = d.grid;
+  if (block_out) *block_out = d.block;
+  StemParams copy = p;
+  void* args[] = {&copy};
+  return hipLaunchKernel(d.func, d.grid, d.block, args, d.shmem, stream);
 }
 
 // ---------------------------------------------------------------------------------------------- SPPF pool
