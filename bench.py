@@ -5,9 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE frame through the whole hot path on one GPU: stem (reads the fp32 NCHW frame already resident
-in HBM) -> 50 fused implicit-GEMM conv launches + SPPF pool (one hipGraph replay) -> fused decode/sort/NMS
-kernel -> detections left in HBM. Weak scaling: every rank processes K frames of its own (frames shard
+A "step" is ONE frame through the whole hot path on one GPU, as ONE hipGraph launch of 29 kernels: stem (reads the
+fp32 NCHW frame already resident in HBM) -> 7 fused C3k2 block kernels, the fused P2 head, 17 implicit-GEMM conv
+launches, the SPPF pool -> decode / sort / NMS (two launches) -> detections left in HBM. Weak scaling: every rank processes K frames of its own (frames shard
 embarrassingly); the only collective is the RCCL all-gather of the fixed-size detection
 slots, issued every GATHER_EVERY frames on the rank's stream. value = N*K / max-over-ranks(time).
 
@@ -152,6 +152,7 @@ def main():
             k = by_kernel.setdefault(o["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
             k["ms"] += o["ms"]; k["flops"] += o["flops"]; k["bytes"] += o["bytes"]; k["launches"] += 1
         dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
+        top = sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])[:6]
         achieved_tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         total_ms = sum(o["ms"] for o in ops)
         roofline = {
@@ -164,6 +165,11 @@ def main():
             "algorithmic_gbs": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
             "sum_of_ops_ms": round(total_ms, 4),
             "whole_frame_tflops": round(fps / world * FLOPS_PER_FRAME.get(S, 0) / 1e12, 2),
+            # the six kernel instantiations with the largest share of the frame (same live timing)
+            "top_kernels": [{"kernel": k, "launches": v["launches"], "us_per_frame": round(1e3 * v["ms"], 2),
+                             "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else 0.0,
+                             "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS[dname], 4) if v["ms"] > 0 else 0.0}
+                            for k, v in top],
         }
 
         cpu = None
@@ -194,26 +200,36 @@ def main():
         print(json.dumps(line))
 
 
-def mangled(kernel: str) -> str:
-    """display name 'conv_glds<f16,32,64,64,1,4,4>' -> the Itanium-mangled symbol rocprofv3 reports."""
+def _kernel_key(name: str):
+    """(function name, integer template arguments) of a kernel, from the engine's display name
+    ('conv_glds<f16,32,64,64,1,4,4>', 'c3k2_fused<128,4x8,2,256,8w>'), the Itanium-mangled symbol or the demangled
+    signature rocprofv3 reports ('void unina::c3k2_fused_kernel<128, 4, 8, 2, 256, 8, 16>(unina::C3k2Params)')."""
     import re
-    m = re.match(r"(\w+)<(\w+),(.*)>", kernel)
-    if not m:
-        return kernel
-    fn, ty, rest = m.groups()
-    code = {"f16": "DF16_", "f32": "f", "i8": "a"}[ty]
-    nums = [n for part in rest.split(",") for n in part.split("x")]
-    return f"_ZN5unina{len(fn)}{fn}I{code}" + "".join(f"Li{n}E" for n in nums) + "EEvNS_10ConvParamsE"
+    m = re.match(r"_ZN5unina(\d+)", name)
+    if m:
+        n = int(m.group(1))
+        fn = name[m.end():m.end() + n]
+        return fn, tuple(int(x) for x in re.findall(r"Li(\d+)E", name))
+    name = name.replace("void ", "").replace("unina::", "")
+    fn = name.split("<")[0].split("(")[0].strip()
+    args = name.split("<", 1)[1].rsplit(">", 1)[0] if "<" in name else ""
+    return fn, tuple(int(x) for x in re.findall(r"\d+", re.sub(r"\bf16\b|\bf32\b|\bi8\b", "", args)))
 
 
 def pmc_traffic(kernel: str):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary (FETCH_SIZE x2 + WRITE_SIZE,
-    MI355X_MICROARCH.md HBM section), or None."""
+    MI355X_MICROARCH.md HBM section), or None. Names are matched on (function, leading template integers)."""
     try:
         with open(PMC_TRAFFIC) as f:
-            return json.load(f).get(mangled(kernel), {}).get("hbm_bytes_per_launch")
+            table = json.load(f)
     except (OSError, ValueError):
         return None
+    fn, nums = _kernel_key(kernel)
+    for k, v in table.items():
+        kfn, knums = _kernel_key(k)
+        if kfn.startswith(fn) and nums and knums[:len(nums)] == nums:
+            return v.get("hbm_bytes_per_launch")
+    return None
 
 
 def cpu_baseline(u, sd, S, conf, budget_s):

@@ -128,8 +128,11 @@ typedef struct unina_op_info {
 int unina_op_count(const unina_engine_t *e);
 int unina_get_op_info(const unina_engine_t *e, int index, unina_op_info *info);
 
-/* Times every op of the forward with HIP events on `stream` (eager launches, `iters` repetitions each
- * after one warm-up); ms_per_op[i] = mean milliseconds of op i. Used by bench.py's roofline leg. */
+/* Times every op of the forward with HIP events on `stream`, INSIDE the frame sequence: each of the `iters`
+ * repetitions replays ops 0..i-1 and then times op i alone, so the op meets the cache state of a real frame (weights
+ * not L2-resident). Event-to-event time of a single launch: like rocprofv3's kernel duration it includes the
+ * dispatch cost (the two agree within a few percent). ms_per_op[i] = mean milliseconds of op i (0 for ops that run
+ * inside a fused block's launch). Used by bench.py's roofline leg. */
 int unina_profile_ops(unina_engine_t *e, int iters, float *ms_per_op, hipStream_t stream);
 
 /* Tile-configuration control of the implicit-GEMM conv kernel (autotuning, tests). cfg = -1 restores the heuristic.
@@ -137,7 +140,8 @@ int unina_profile_ops(unina_engine_t *e, int iters, float *ms_per_op, hipStream_
 int unina_conv_config_count(void);
 const char *unina_conv_config_name(int cfg);
 int unina_set_op_config(unina_engine_t *e, int op_index, int cfg);
-/* Times every fitting configuration of every conv op (`iters` launches each, HIP events on `stream`) and keeps the
+/* Times every fitting configuration of every conv op (`iters` launches each, in the frame sequence like
+ * unina_profile_ops, HIP events on `stream`) and keeps the
  * fastest -- the engine-build "tactic selection" the reference leaves to TensorRT (export_trt.py:459-468).
  * Needs "images" bound. Results are bit-identical under every configuration. */
 int unina_autotune(unina_engine_t *e, int iters, hipStream_t stream);

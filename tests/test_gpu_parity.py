@@ -407,6 +407,34 @@ def test_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
         e.close()
 
 
+def test_frame_graph_and_tiled_nms_match_the_plain_forms(pkg, sd7, torch_cuda, monkeypatch):
+    """Default per-frame path = ONE hipGraph launch (stem + forward + two-launch post-process whose NMS mask tiles run on
+    many CUs; the stem / post-process nodes are re-pointed per frame with hipGraphExecKernelNodeSetParams). It must
+    return exactly what separate launches with the one-workgroup post-process return -- also when thresholds and input
+    buffers change between frames, and when more than MAX_DETECTIONS cells pass (top-1024 selection)."""
+    from unina_yolo_dla_amd.engine import Engine
+    calls = [(1234, 0.5, 0.45, 0.1), (7, 0.5, 0.45, 0.1), (1234, 0.3, 0.6, 0.0), (9, 0.02, 0.45, 0.1), (1234, 0.5, 0.45, 0.1)]
+    frames = {s: _frame(pkg, torch_cuda, s, 640) for s in {c[0] for c in calls}}
+
+    def run():
+        e = Engine.from_state_dict(sd7)
+        try:
+            out = [e.infer(frames[s], c, i, q).tobytes() for s, c, i, q in calls]
+            return out, e.L.unina_fusion_groups(e.h)
+        finally:
+            e.close()
+
+    fast, groups = run()
+    assert groups == 8
+    monkeypatch.setenv("UNINA_FULL_GRAPH", "0")
+    monkeypatch.setenv("UNINA_POST_SPLIT", "0")
+    monkeypatch.setenv("UNINA_FUSE", "0")
+    plain, groups = run()
+    assert groups == 0
+    assert fast == plain
+    assert len(fast[3]) > len(fast[0]) and fast[0] == fast[4] and fast[0] != fast[1]
+
+
 def test_async_result_layout(pkg, eng640, torch_cuda):
     x = _frame(pkg, torch_cuda, 1234, 640)
     sync = eng640.infer(x)

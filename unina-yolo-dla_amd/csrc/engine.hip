@@ -254,7 +254,7 @@ int plan(unina_engine* e) {
       info.flops = 2.0 * info.m * info.n * 27;
       info.bytes = 4.0 * 3 * p.H * p.W + (double)dtype_size(odt) * info.m * p.Co;
       snprintf(info.kernel, sizeof info.kernel, "stem_conv_kernel<%s,%d>", odt == kF32 ? "f32" : "f16", p.Co);
-      info.grid = (info.m + 255) / 256;
+      info.grid = (2 * info.m + 255) / 256;
       info.block = 256;
     } else if (d.kind == kOpSppfPool) {
       PoolParams& p = op.pp;

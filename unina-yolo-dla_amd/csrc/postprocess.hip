@@ -189,24 +189,45 @@ __device__ __forceinline__ GpuDetection get(const Smem& s, int pos, int valid) {
 
 __device__ __forceinline__ int tri_off(int c, int nw) { return 64 * (c * nw - (c * (c - 1)) / 2); }
 
-// Sequential greedy pass over the suppression bitmap by ONE wave: walks the 64-row chunks in order and visits only
-// rows that suppress something; a row that was itself suppressed suppresses nothing. lane w (< kWords) owns word w.
+// Sequential greedy pass over the suppression bitmap by ONE wave. Only the walk along a chunk's own 64 rows is truly
+// serial (row r suppresses only if no earlier kept row suppressed it): that walk runs on the SCALAR unit over the
+// chunk's diagonal tile, whose row words sit one per lane and are fetched with v_readlane (a few cycles per row; the
+// earlier form paid an LDS read + two ds_bpermute per suppressing row). The rows that survive the walk then OR their
+// off-diagonal words into the later chunks' accumulators in parallel (LDS atomics). `removed` (LDS, kWords) is output.
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
 __device__ __forceinline__ void greedy_scan(const unsigned long long* mask, const unsigned long long* rownz,
                                             unsigned long long* removed, int nw, int lane) {
-  unsigned long long removed_reg = 0ull;
+  if (lane < kWords) removed[lane] = 0ull;
   for (int c = 0; c < nw; ++c) {
-    unsigned long long todo = rownz[c];
-    unsigned long long cur = __shfl(removed_reg, c);
     const int base = tri_off(c, nw), stride = nw - c;
+    const unsigned long long diag = mask[base + lane * stride];   // row `lane` of the diagonal tile (c, c)
+    unsigned long long todo = uniform64(rownz[c]);                // rows of this chunk with a non-empty mask
+    unsigned long long cur = uniform64(removed[c]);               // suppressed so far (by earlier chunks)
+    unsigned long long act = 0ull;                                // rows of this chunk that do suppress
     while (todo) {
       const int r = __ffsll((long long)todo) - 1;
       todo &= todo - 1ull;
-      if ((cur >> r) & 1ull) continue;  // row r was itself suppressed: it suppresses nothing
-      if (lane >= c && lane < nw) removed_reg |= mask[base + r * stride + (lane - c)];
-      cur = __shfl(removed_reg, c);
+      if ((cur >> r) & 1ull) continue;                            // row r was itself suppressed: it suppresses nothing
+      cur |= readlane64(diag, r);
+      act |= 1ull << r;
+    }
+    if (lane == 0) removed[c] = cur;
+    if ((act >> lane) & 1ull) {
+      for (int w = 1; w < stride; ++w) {
+        const unsigned long long m = mask[base + lane * stride + w];
+        if (m) atomicOr(&removed[c + w], m);
+      }
     }
   }
-  if (lane < kWords) removed[lane] = removed_reg;
 }
 
 // Records 0..n) sit in s.box / s.cc in enumeration order; on return they are in SORTED order (confidence descending,

@@ -10,18 +10,25 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // ---------------------------------------------------------------------------------------------- stem
 // Cin = 3 makes K = 27: far too thin for a matrix-core tile, and the op is HBM-bound anyway
-// (4.9 MB fp32 in, 6.6 MB fp16 out at 640^2 against 0.18 GFLOP). Plain fp32 FMAs, one thread per output pixel
-// and ALL output channels: a wave's 27 input loads each cover 64 neighbouring pixels (stride-2 fp32: every fetched
-// line is used), the 27x32 folded weights are LDS broadcast reads (ds_read_b128, same address in every lane), and
-// each lane stores its pixel's 64 contiguous NHWC bytes.
+// (4.9 MB fp32 in, 6.6 MB fp16 out at 640^2 against 0.18 GFLOP). Plain fp32 FMAs. TWO threads per output pixel,
+// each with half of the output channels: 3 200 waves at 640^2 spread evenly over the 1 024 SIMDs (one thread per
+// pixel gave 1.56 waves per SIMD, i.e. two uneven rounds), and the accumulators are float2 pairs so every FMA
+// instruction is a v_pk_fma_f32 (two channels per issue slot; element-wise, so each channel still sees exactly the
+// sequential fma chain k = 0..26 of the scalar form). A wave's 27 input loads each cover 32 neighbouring pixels
+// (stride-2 fp32, both threads of a pixel hit the same address), the 27 x CO folded weights are LDS reads with two
+// distinct addresses per wave, and each thread stores its pixel's CO/2 contiguous NHWC channels.
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
 template <typename T, int CO>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
+  constexpr int CH = CO / 2;  // channels per thread
   __shared__ __align__(16) float sw[27 * CO];
   __shared__ __align__(16) float sb[CO];
   for (int i = threadIdx.x; i < CO * 27; i += blockDim.x) sw[(i % 27) * CO + (i / 27)] = p.w[i];  // -> [k][co]
   for (int i = threadIdx.x; i < CO; i += blockDim.x) sb[i] = p.bias[i];
   __syncthreads();
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = g >> 1, c0 = (g & 1) * CH;
   if (m >= p.Ho * p.Wo) return;
   const int oy = m / p.Wo, ox = m - oy * p.Wo;
   float x[27];
@@ -38,34 +45,36 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
         x[(c * 3 + kh) * 3 + kw] = ok ? p.src[c * plane + (size_t)iy * p.W + ix] : 0.f;
       }
     }
-  float acc[CO];
+  floatx2 acc[CH / 2];
 #pragma unroll
-  for (int r = 0; r < CO; ++r) acc[r] = sb[r];
+  for (int r = 0; r < CH / 2; ++r) acc[r] = *reinterpret_cast<const floatx2*>(&sb[c0 + 2 * r]);
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
+    const floatx2 xk = {x[k], x[k]};
 #pragma unroll
-    for (int r = 0; r < CO; r += 4) {
-      const float4 w4 = *reinterpret_cast<const float4*>(&sw[k * CO + r]);
-      acc[r + 0] = __builtin_fmaf(x[k], w4.x, acc[r + 0]);
-      acc[r + 1] = __builtin_fmaf(x[k], w4.y, acc[r + 1]);
-      acc[r + 2] = __builtin_fmaf(x[k], w4.z, acc[r + 2]);
-      acc[r + 3] = __builtin_fmaf(x[k], w4.w, acc[r + 3]);
+    for (int r = 0; r < CH / 2; r += 2) {
+      const float4 w4 = *reinterpret_cast<const float4*>(&sw[k * CO + c0 + 2 * r]);
+      acc[r] = __builtin_elementwise_fma(xk, floatx2{w4.x, w4.y}, acc[r]);
+      acc[r + 1] = __builtin_elementwise_fma(xk, floatx2{w4.z, w4.w}, acc[r + 1]);
     }
   }
-  T* d = static_cast<T*>(p.dst) + (size_t)m * p.dst_ld;
+  T* d = static_cast<T*>(p.dst) + (size_t)m * p.dst_ld + c0;
   constexpr int V = 16 / sizeof(T);  // elements per 16-byte store
   typedef T vec_t __attribute__((ext_vector_type(V)));
 #pragma unroll
-  for (int r = 0; r < CO; r += V) {
+  for (int r = 0; r < CH; r += V) {
     vec_t hv;
 #pragma unroll
-    for (int q = 0; q < V; ++q) hv[q] = (T)(acc[r + q] > 0.f ? acc[r + q] : 0.f);
+    for (int q = 0; q < V; ++q) {
+      const float a = acc[(r + q) >> 1][(r + q) & 1];
+      hv[q] = (T)(a > 0.f ? a : 0.f);
+    }
     *reinterpret_cast<vec_t*>(d + r) = hv;
   }
 }
 
 hipError_t stem_desc(const StemParams& p, LaunchDesc* out) {
-  out->grid = dim3((p.Ho * p.Wo + 255) / 256);
+  out->grid = dim3((2 * p.Ho * p.Wo + 255) / 256);   // two threads per output pixel
   out->block = dim3(256);
   out->shmem = 0;
   if (p.Co == 32 && p.dtype == kF16) out->func = reinterpret_cast<const void*>(&stem_conv_kernel<half_t, 32>);
@@ -139,18 +148,28 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolParams p) {
     for (int i = 0; i < V; ++i) r[i] = a[i] > b[i] ? a[i] : b[i];
     return r;
   };
+  // Rows / columns outside the image are CLAMPED to the border instead of skipped: the border row (column) always
+  // lies inside the clipped window, so the duplicate never changes a maximum -- and without the per-row branches the
+  // 13 loads are independent and issued back to back (with them they serialised: 13 x L2 latency per thread).
+  (void)lo;
   for (int t = threadIdx.x; t < nvec; t += blockDim.x) {
     const int xx = t / NV, cv = t % NV;
-    vec_t m5 = lo, m9 = lo, m13 = lo;
+    vec_t v[13];
 #pragma unroll
     for (int dy = -6; dy <= 6; ++dy) {
-      const int yy = y + dy;
-      if (yy < 0 || yy >= p.H) continue;
-      const vec_t v = *reinterpret_cast<const vec_t*>(x + ((size_t)yy * p.W + xx) * p.ld + cv * V);
-      m13 = vmax(m13, v);
-      if (dy >= -4 && dy <= 4) m9 = vmax(m9, v);
-      if (dy >= -2 && dy <= 2) m5 = vmax(m5, v);
+      int yy = y + dy;
+      yy = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+      v[dy + 6] = *reinterpret_cast<const vec_t*>(x + ((size_t)yy * p.W + xx) * p.ld + cv * V);
     }
+    vec_t m5 = v[6];
+#pragma unroll
+    for (int d = 1; d <= 2; ++d) m5 = vmax(m5, vmax(v[6 - d], v[6 + d]));
+    vec_t m9 = m5;
+#pragma unroll
+    for (int d = 3; d <= 4; ++d) m9 = vmax(m9, vmax(v[6 - d], v[6 + d]));
+    vec_t m13 = m9;
+#pragma unroll
+    for (int d = 5; d <= 6; ++d) m13 = vmax(m13, vmax(v[6 - d], v[6 + d]));
     v5[t] = m5;
     v9[t] = m9;
     v13[t] = m13;
@@ -158,15 +177,17 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolParams p) {
   __syncthreads();
   for (int t = threadIdx.x; t < nvec; t += blockDim.x) {
     const int xx = t / NV, cv = t % NV;
-    vec_t o5 = lo, o9 = lo, o13 = lo;
+    auto col = [&](int dx) {
+      int x2 = xx + dx;
+      x2 = x2 < 0 ? 0 : (x2 >= p.W ? p.W - 1 : x2);
+      return x2 * NV + cv;
+    };
+    vec_t o5 = v5[col(0)], o9 = v9[col(0)], o13 = v13[col(0)];
 #pragma unroll
-    for (int dx = -6; dx <= 6; ++dx) {
-      const int x2 = xx + dx;
-      if (x2 < 0 || x2 >= p.W) continue;
-      const int idx = x2 * NV + cv;
-      o13 = vmax(o13, v13[idx]);
-      if (dx >= -4 && dx <= 4) o9 = vmax(o9, v9[idx]);
-      if (dx >= -2 && dx <= 2) o5 = vmax(o5, v5[idx]);
+    for (int d = 1; d <= 6; ++d) {
+      o13 = vmax(o13, vmax(v13[col(-d)], v13[col(d)]));
+      if (d <= 4) o9 = vmax(o9, vmax(v9[col(-d)], v9[col(d)]));
+      if (d <= 2) o5 = vmax(o5, vmax(v5[col(-d)], v5[col(d)]));
     }
     T* o = base + ((size_t)y * p.W + xx) * p.ld + p.coff + c0 + cv * V;
     *reinterpret_cast<vec_t*>(o + p.C) = o5;
