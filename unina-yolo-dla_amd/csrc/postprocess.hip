@@ -189,76 +189,76 @@ __device__ __forceinline__ GpuDetection get(const Smem& s, int pos, int valid) {
 
 __device__ __forceinline__ int tri_off(int c, int nw) { return 64 * (c * nw - (c * (c - 1)) / 2); }
 
-// Sequential greedy pass over the suppression bitmap by ONE wave. Only the walk along a chunk's own 64 rows is truly
-// serial (row r suppresses only if no earlier kept row suppressed it): that walk runs on the SCALAR unit over the
-// chunk's diagonal tile, whose row words sit one per lane and are fetched with v_readlane (a few cycles per row; the
-// earlier form paid an LDS read + two ds_bpermute per suppressing row). The rows that survive the walk then OR their
-// off-diagonal words into the later chunks' accumulators in parallel (LDS atomics). `removed` (LDS, kWords) is output.
-__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-  return ((unsigned long long)hi << 32) | lo;
-}
-__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
-  return ((unsigned long long)hi << 32) | lo;
-}
+// Sequential greedy pass over the suppression bitmap by ONE wave: walks the 64-row chunks in order and visits only
+// rows that suppress something; a row that was itself suppressed suppresses nothing. lane w (< kWords) owns word w.
+// (A variant that walks a chunk's diagonal tile on the scalar unit with v_readlane and merges the off-diagonal words
+// with LDS atomics measured slower: 9.0 vs 4.4 us at n = 489.)
 __device__ __forceinline__ void greedy_scan(const unsigned long long* mask, const unsigned long long* rownz,
                                             unsigned long long* removed, int nw, int lane) {
-  if (lane < kWords) removed[lane] = 0ull;
+  unsigned long long removed_reg = 0ull;
   for (int c = 0; c < nw; ++c) {
+    unsigned long long todo = rownz[c];
+    unsigned long long cur = __shfl(removed_reg, c);
     const int base = tri_off(c, nw), stride = nw - c;
-    const unsigned long long diag = mask[base + lane * stride];   // row `lane` of the diagonal tile (c, c)
-    unsigned long long todo = uniform64(rownz[c]);                // rows of this chunk with a non-empty mask
-    unsigned long long cur = uniform64(removed[c]);               // suppressed so far (by earlier chunks)
-    unsigned long long act = 0ull;                                // rows of this chunk that do suppress
     while (todo) {
       const int r = __ffsll((long long)todo) - 1;
       todo &= todo - 1ull;
-      if ((cur >> r) & 1ull) continue;                            // row r was itself suppressed: it suppresses nothing
-      cur |= readlane64(diag, r);
-      act |= 1ull << r;
-    }
-    if (lane == 0) removed[c] = cur;
-    if ((act >> lane) & 1ull) {
-      for (int w = 1; w < stride; ++w) {
-        const unsigned long long m = mask[base + lane * stride + w];
-        if (m) atomicOr(&removed[c + w], m);
-      }
+      if ((cur >> r) & 1ull) continue;  // row r was itself suppressed: it suppresses nothing
+      if (lane >= c && lane < nw) removed_reg |= mask[base + r * stride + (lane - c)];
+      cur = __shfl(removed_reg, c);
     }
   }
+  if (lane < kWords) removed[lane] = removed_reg;
 }
 
 // Records 0..n) sit in s.box / s.cc in enumeration order; on return they are in SORTED order (confidence descending,
-// ties by enumeration order), padded to a multiple of 64 with never-suppressed dummies. Rank sort: thread i counts
-// the keys larger than its own with broadcast LDS reads (no barriers).
+// ties by enumeration order), padded to a multiple of 64 with never-suppressed dummies. The 64-bit keys
+// (confidence bits << 32 | ~enumeration position: all distinct, so the order is total and deterministic) are sorted
+// by a bitonic network in LDS -- O(n log^2 n) work spread over the block; the earlier rank sort (every thread counts
+// the keys above its own) was O(n^2) VALU work on one CU: 9.4 us at n = 700, 20.6 us at n = 1024 -- and each record
+// is then fetched from the enumeration position its key carries.
 __device__ void rank_sort_records(Smem& s, int n) {
   const int tid = threadIdx.x;
-  // keys; entries n..n8) are zero so that the fixed-trip, unrolled scans below never count them
-  const int n8 = (n + 7) & ~7;
-  if (tid < n8)
-    s.keys[tid] = tid < n ? (((unsigned long long)__float_as_uint(s.cc[tid].x) << 32) | (0xFFFFFFFFu - (unsigned)tid)) : 0ull;
-  __syncthreads();
-  float4 mybox;
-  float2 mycc;
-  int rank = 0;
-  if (tid < n) {
-    const unsigned long long mine = s.keys[tid];
-    mybox = s.box[tid];
-    mycc = s.cc[tid];
-    for (int j = 0; j < n8; j += 8) {  // 8 broadcast LDS reads in flight per wave
-      unsigned long long k[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) k[u] = s.keys[j + u];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) rank += k[u] > mine;
+  int N = 64;
+  while (N < n) N <<= 1;   // power of two >= n, <= kMaxDet == kT
+  static_assert(kTriWords >= kT, "s.mask doubles as the second key buffer");
+  // Every thread holds one key in a register (threads >= N hold 0 and only ever meet each other). Compare-exchange
+  // partners tid ^ j with j < 64 sit in the same wave: those 45 of the 55 steps (N = 1024) are register shuffles with
+  // no barrier; the 10 steps with j >= 64 go through LDS, ping-ponging between s.keys and s.mask (free at this point)
+  // so that each costs ONE barrier.
+  unsigned long long key = tid < n ? (((unsigned long long)__float_as_uint(s.cc[tid].x) << 32) | (0xFFFFFFFFu - (unsigned)tid)) : 0ull;
+  unsigned long long* buf[2] = {s.keys, s.mask};
+  int pb = 0;
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      unsigned long long other;
+      if (j >= 64) {
+        buf[pb][tid] = key;
+        __syncthreads();
+        other = buf[pb][tid ^ j];
+        pb ^= 1;
+      } else {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)key, j), hi = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), j);
+        other = ((unsigned long long)hi << 32) | lo;
+      }
+      const bool take_max = ((tid & j) == 0) == ((tid & k) == 0);   // lower index of a descending pair keeps the larger key
+      key = take_max ? (key > other ? key : other) : (key < other ? key : other);
     }
   }
   __syncthreads();
+  s.keys[tid] = key;
+  __syncthreads();
+  float4 mybox;
+  float2 mycc;
   if (tid < n) {
-    s.box[rank] = mybox;
-    s.cc[rank] = mycc;
+    const int pos = (int)(0xFFFFFFFFu - (unsigned)s.keys[tid]);
+    mybox = s.box[pos];
+    mycc = s.cc[pos];
+  }
+  __syncthreads();
+  if (tid < n) {
+    s.box[tid] = mybox;
+    s.cc[tid] = mycc;
   }
   // pad the sorted arrays up to the next multiple of 64 with records that can never be suppressed (class -1)
   const int n64 = (n + 63) & ~63;
@@ -515,6 +515,7 @@ __global__ __launch_bounds__(kTileThreads) void nms_tiles_kernel(const PostParam
     }
   }
   if (!arrive_and_check_last(p.ticket2, &s.is_last)) return;
+  if (p.stamps && tid == 0) p.stamps[4] = wall_clock64();
 
   // ---- last block: scan + compaction + output ----
   for (int k = tid; k < 64 * ntiles; k += kTileThreads) s.mask[k] = p.ws_mask[k];
@@ -527,6 +528,7 @@ __global__ __launch_bounds__(kTileThreads) void nms_tiles_kernel(const PostParam
   __syncthreads();
   if (tid < 64) greedy_scan(s.mask, s.rownz, s.removed, nw, lane);
   __syncthreads();
+  if (p.stamps && tid == 0) p.stamps[5] = wall_clock64();
   int base = 0;
   for (int i0 = 0; i0 < n; i0 += kTileThreads) {
     const int i = i0 + tid;
