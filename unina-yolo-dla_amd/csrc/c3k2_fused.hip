@@ -27,6 +27,7 @@
 #include "kernels.h"
 #include "block_pipeline.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -241,18 +242,42 @@ struct Class {
 #define C3K2(H_, TH, TW, NB, CIN, NW, D) \
   {H_, NB, CIN, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D>}
 const Class kClasses[] = {
-    C3K2(32, 8, 16, 1, 64, 8, 4),      // backbone.stage1_block        160^2 at 640
-    C3K2(32, 8, 16, 1, 128, 8, 4),     // neck.fpn_c3k2_2
-    C3K2(64, 8, 8, 2, 128, 8, 8),      // backbone.stage2_c3k2          80^2
-    C3K2(64, 8, 8, 1, 256, 8, 8),      // neck.fpn_c3k2_1
-    C3K2(64, 8, 8, 1, 192, 8, 8),      // neck.pan_c3k2_1
-    C3K2(128, 4, 8, 2, 256, 8, 16),    // backbone.stage3_c3k2          40^2
-    C3K2(128, 4, 8, 1, 384, 8, 16),    // neck.pan_c3k2_2
+    // tiles chosen by end-to-end A/B at 640^2 (profiles/r01): twice the workgroups of the first choice (8x16 / 8x8 /
+    // 4x8) cost more halo recompute but cut the serial frame by ~10 us at equal throughput
+    C3K2(32, 8, 8, 1, 64, 8, 4),       // backbone.stage1_block        160^2 at 640: 400 workgroups
+    C3K2(32, 8, 8, 1, 128, 8, 4),      // neck.fpn_c3k2_2
+    C3K2(64, 4, 8, 2, 128, 8, 8),      // backbone.stage2_c3k2          80^2: 200
+    C3K2(64, 4, 8, 1, 256, 8, 8),      // neck.fpn_c3k2_1
+    C3K2(64, 4, 8, 1, 192, 8, 8),      // neck.pan_c3k2_1
+    C3K2(128, 4, 4, 2, 256, 8, 16),    // backbone.stage3_c3k2          40^2: 100
+    C3K2(128, 4, 4, 1, 384, 8, 16),    // neck.pan_c3k2_2
+    // alternatives for A/B experiments, bit masks 1 = h 32, 2 = h 64, 4 = h 128:
+    // UNINA_C3K2_ALT: larger tiles (half the workgroups, less halo recompute)
+    C3K2(32, 8, 16, 1, 64, 8, 4),
+    C3K2(32, 8, 16, 1, 128, 8, 4),
+    C3K2(64, 8, 8, 2, 128, 8, 8),
+    C3K2(64, 8, 8, 1, 256, 8, 8),
+    C3K2(64, 8, 8, 1, 192, 8, 8),
+    C3K2(128, 4, 8, 2, 256, 8, 16),
+    C3K2(128, 4, 8, 1, 384, 8, 16),
+    // UNINA_C3K2_ALT2: smaller still
+    C3K2(32, 4, 8, 1, 64, 8, 4),
+    C3K2(32, 4, 8, 1, 128, 8, 4),
+    C3K2(64, 4, 4, 2, 128, 8, 8),
+    C3K2(64, 4, 4, 1, 256, 8, 8),
+    C3K2(64, 4, 4, 1, 192, 8, 8),
+    C3K2(128, 4, 4, 2, 256, 8, 16),
+    C3K2(128, 4, 4, 1, 384, 8, 16),
 };
+constexpr int kPrimaryClasses = 7;
 #undef C3K2
 const Class* find_class(int hid, int nb, int cin) {
-  for (const Class& c : kClasses)
-    if (c.hid == hid && c.nb == nb && c.cin == cin) return &c;
+  static const int alt1 = getenv("UNINA_C3K2_ALT") ? atoi(getenv("UNINA_C3K2_ALT")) : 0;
+  static const int alt2 = getenv("UNINA_C3K2_ALT2") ? atoi(getenv("UNINA_C3K2_ALT2")) : 0;
+  const int bit = hid == 32 ? 1 : (hid == 64 ? 2 : 4);
+  const int set = (alt1 & bit) ? 1 : ((alt2 & bit) ? 2 : 0);
+  for (int i = set * kPrimaryClasses; i < (set + 1) * kPrimaryClasses; ++i)
+    if (kClasses[i].hid == hid && kClasses[i].nb == nb && kClasses[i].cin == cin) return &kClasses[i];
   return nullptr;
 }
 constexpr int kMaxLds = 160 * 1024;

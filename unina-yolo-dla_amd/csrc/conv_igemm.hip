@@ -774,6 +774,10 @@ const CfgInfo kCfg[3][kCfgCount] = {
         REGQ(5, 80, 16, 128, 4, 16),                  // kCfgRegq5x80n16c128   (P3 head layers: 80x80 maps)
         REGQ(5, 40, 32, 256, 8, 16),                  // kCfgRegq5x40n32c256
         REGQ(10, 40, 16, 128, 4, 16),                 // kCfgRegq10x40n16c128
+        // one wave per channel subtile (no wave re-loads another's weight blocks), deeper queue
+        REGQ(8, 8, 64, 256, 4, 32),                   // kCfgRegq8x8n64c256w4
+        REGQ(8, 16, 64, 128, 4, 32),                  // kCfgRegq8x16n64c128w4
+        REGQ(8, 8, 128, 256, 8, 24),                  // kCfgRegq8x8n128c256
     },
     {
         CFG(float, "f32", 64, 64, 64, 2, 2, 4),
@@ -804,7 +808,7 @@ const CfgInfo kCfg[3][kCfgCount] = {
         HALO(float, "f32", 8, 16, 64, 128, 2, 2, 4),
         CFG(float, "f32", 32, 64, 128, 1, 4, 4),
         CFG(float, "f32", 64, 64, 128, 2, 2, 4),
-        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,     // register-queue kernels are fp16 only
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,     // register-queue kernels are fp16 only
     },
     {
         CFG(signed char, "i8", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
@@ -835,7 +839,7 @@ const CfgInfo kCfg[3][kCfgCount] = {
         HALO(signed char, "i8", 8, 16, 64, 128, 2, 2, 4), // kCfgHalo8x16n64k128
         CFG(signed char, "i8", 32, 64, 128, 1, 4, 4),     // kCfg32x64k128
         CFG(signed char, "i8", 64, 64, 128, 2, 2, 4),     // kCfg64x64k128
-        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
     },
 };
 #undef CFG

@@ -64,6 +64,7 @@ enum ConvConfig : int {
   kCfg32x64k128, kCfg64x64k128,
   kCfgRegq8x16n64c128, kCfgRegq8x8n64c128, kCfgRegq8x8n64c256, kCfgRegq8x8n32c256, kCfgRegq8x16n64c64, kCfgRegq8x16n32c128,
   kCfgRegq5x40n16c256, kCfgRegq5x80n16c128, kCfgRegq5x40n32c256, kCfgRegq10x40n16c128,
+  kCfgRegq8x8n64c256w4, kCfgRegq8x16n64c128w4, kCfgRegq8x8n128c256,
   kCfgCount
 };
 struct ConvLaunch {
