@@ -621,10 +621,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
 // the weight-heavy head layers at 80^2 / 40^2 (590 KB / 2.4 MB of weights per launch) are bound by exactly that.
 // fp16 only; Cin is a template parameter (the K loop is unrolled at compile time so queue slots are registers).
 // Same MFMA, same K order (tap-major, 32 channels per block), same epilogue as the other kernels: bit-identical.
-template <int TH, int TW, int BN, int CIN, int NW, int D>
+template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1>
 __global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
   typedef Elem<half_t> E;
-  constexpr int BM = TH * TW, R0W = TW + 2, R0H = TH + 2, NT = NW * 64, CB = CIN / 32, KB = 9 * CB;
+  // S = stride (1 or 2): the patch is the (S*TH + 2 or S*TH + 1) x (...) input footprint of the tile
+  constexpr int BM = TH * TW, R0W = S * (TW - 1) + 3, R0H = S * (TH - 1) + 3, NT = NW * 64, CB = CIN / 32, KB = 9 * CB;
   constexpr int NS = BN / 16, WVM = NW / NS, MS = (BM + 15) / 16, WM_T = (MS + WVM - 1) / WVM;
   static_assert(NW % NS == 0 && WM_T >= 1 && KB >= D, "tile");
 
@@ -652,8 +653,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
   };
 
   constexpr Img X = make_img(0, CIN / 8);
-  load_patch<R0H, R0W, CIN, NT>(conv_smem, static_cast<const half_t*>(p.src) + sg.src_coff, p.src_ld, p.H, p.W, ty0 - 1,
-                                tx0 - 1, p.zeros, wid, lane);
+  load_patch<R0H, R0W, CIN, NT>(conv_smem, static_cast<const half_t*>(p.src) + sg.src_coff, p.src_ld, p.H, p.W, S * ty0 - 1,
+                                S * tx0 - 1, p.zeros, wid, lane);
   static_for<0, D>(fetch);
   EpiConsts<1> ec;
   load_epi_consts<1>(sg, nb0 + wn * 16, lq, ec);
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
   for (int i = 0; i < WM_T; ++i) {
     int pp = (wm * WM_T + i) * 16 + l15;
     pp = pp < BM ? pp : BM - 1;                     // subtiles past the tile: any valid pixel (never stored)
-    row0[i] = (pp / TW) * R0W + pp % TW;
+    row0[i] = S * ((pp / TW) * R0W + pp % TW);
   }
   auto baddr = [&](int i, auto kc) {
     constexpr int kb = decltype(kc)::value, tap = kb / CB, cb = kb - tap * CB, th3 = tap / 3;
@@ -709,6 +710,7 @@ struct CfgInfo {
   int th, tw;          // halo / register-queue kernels: spatial tile (0 = im2col kernel)
   int cin = 0;         // register-queue kernel: the input channel count it is instantiated for (0 = any)
   int nthreads = 256;
+  int stride = 1;      // register-queue kernel: conv stride it is instantiated for
 };
 
 constexpr size_t stage_bytes(int bm, int bn) { return (size_t)bm * (bn * 4 + 16); }  // epilogue staging tile (fp32 worst case)
@@ -728,8 +730,11 @@ constexpr size_t smem_of() {
 
 #define REGQ(TH, TW, BN, CIN, NW, D)                                                                 \
   {(TH) * (TW), BN, 32, 3, "conv3x3_regq<f16," #TH "x" #TW "," #BN "," #CIN "," #NW "w>",                \
-   conv3x3_regq<TH, TW, BN, CIN, NW, D>, 0, TH, TW, CIN, (NW) * 64}
-#define NOCFG {0, 0, 0, 0, "n/a", nullptr, 0, 0, 0, -1, 0}
+   conv3x3_regq<TH, TW, BN, CIN, NW, D>, 0, TH, TW, CIN, (NW) * 64, 1}
+#define REGQ2(TH, TW, BN, CIN, NW, D)                                                                \
+  {(TH) * (TW), BN, 32, 3, "conv3x3_regq<f16," #TH "x" #TW "," #BN "," #CIN "," #NW "w,s2>",             \
+   conv3x3_regq<TH, TW, BN, CIN, NW, D, 2>, 0, TH, TW, CIN, (NW) * 64, 2}
+#define NOCFG {0, 0, 0, 0, "n/a", nullptr, 0, 0, 0, -1, 0, 0}
 
 // [dtype][config]; BK is in fp16-equivalent k (KSUB = BK/32 fragment blocks): a K-step covers BK channels in fp16
 // and BK/2 channels in fp32.
@@ -778,6 +783,13 @@ const CfgInfo kCfg[3][kCfgCount] = {
         REGQ(8, 8, 64, 256, 4, 32),                   // kCfgRegq8x8n64c256w4
         REGQ(8, 16, 64, 128, 4, 32),                  // kCfgRegq8x16n64c128w4
         REGQ(8, 8, 128, 256, 8, 24),                  // kCfgRegq8x8n128c256
+        // stride 2 (stage convs, PAN down-sampling convs)
+        REGQ2(8, 8, 64, 64, 8, 16),                   // kCfgRegqS2_8x8n64c64     (stage2_conv, down1)
+        REGQ2(8, 16, 64, 64, 8, 16),                  // kCfgRegqS2_8x16n64c64
+        REGQ2(8, 8, 64, 128, 8, 16),                  // kCfgRegqS2_8x8n64c128    (stage3_conv, down2)
+        REGQ2(4, 8, 64, 128, 8, 16),                  // kCfgRegqS2_4x8n64c128
+        REGQ2(8, 16, 64, 32, 8, 8),                   // kCfgRegqS2_8x16n64c32    (stage1_conv)
+        REGQ2(8, 8, 32, 128, 8, 16),                  // kCfgRegqS2_8x8n32c128
     },
     {
         CFG(float, "f32", 64, 64, 64, 2, 2, 4),
@@ -809,6 +821,7 @@ const CfgInfo kCfg[3][kCfgCount] = {
         CFG(float, "f32", 32, 64, 128, 1, 4, 4),
         CFG(float, "f32", 64, 64, 128, 2, 2, 4),
         NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,     // register-queue kernels are fp16 only
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
     },
     {
         CFG(signed char, "i8", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
@@ -840,11 +853,13 @@ const CfgInfo kCfg[3][kCfgCount] = {
         CFG(signed char, "i8", 32, 64, 128, 1, 4, 4),     // kCfg32x64k128
         CFG(signed char, "i8", 64, 64, 128, 2, 2, 4),     // kCfg64x64k128
         NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
     },
 };
 #undef CFG
 #undef HALO
 #undef REGQ
+#undef REGQ2
 #undef NOCFG
 
 inline int block_k(int dtype) { return dtype == kF32 ? 16 : (dtype == kI8 ? 64 : 32); }
@@ -853,7 +868,8 @@ inline size_t esize(const ConvParams& p) { return p.dtype == kF32 ? 4 : (p.dtype
 inline size_t smem_for(const ConvParams& p, const CfgInfo& c) {
   if (!c.th) return c.smem;
   if (c.cin) {  // register-queue kernel: patch (+ < 1 KiB overrun of its last DMA instruction) or the epilogue staging tile
-    const size_t patch = (((size_t)(c.th + 2) * (c.tw + 2) * c.cin * 2 + 1023) & ~(size_t)1023) + 1024;
+    const size_t ph = c.stride * (c.th - 1) + 3, pw = c.stride * (c.tw - 1) + 3;
+    const size_t patch = ((ph * pw * c.cin * 2 + 1023) & ~(size_t)1023) + 1024;
     return max_sz(patch, stage_bytes((c.bm + 15) & ~15, c.bn));
   }
   const size_t patch = (size_t)(c.th + 2) * (c.tw + 2) * p.Cin * esize(p);
@@ -885,7 +901,7 @@ bool conv_config_valid(const ConvParams& p, int cfg) {
   const CfgInfo& c = kCfg[p.dtype][cfg];
   if (!c.fn) return false;
   if (c.cin) {  // register-queue kernel: 3x3 / stride 1 on exactly its Cin, fp16 in; every slice at least one tile wide
-    if (p.dtype != kF16 || p.Cin != c.cin || p.ksize != 3 || p.stride != 1 || p.pad != 1 || smem_for(p, c) > kMaxLds) return false;
+    if (p.dtype != kF16 || p.Cin != c.cin || p.ksize != 3 || p.stride != c.stride || p.pad != 1 || smem_for(p, c) > kMaxLds) return false;
     for (int s = 0; s < p.nseg; ++s)
       if (((p.seg[s].n_count + 15) & ~15) < c.bn) return false;
     return true;
