@@ -54,6 +54,8 @@ def lib() -> C.CDLL:
         L.uo_sd_free.argtypes = [C.c_void_p]
         L.uo_forward.restype = C.c_void_p
         L.uo_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.uo_forward_qat.restype = C.c_void_p
+        L.uo_forward_qat.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.uo_run_get.restype = C.POINTER(C.c_float)
         L.uo_run_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.uo_run_count.argtypes = [C.c_void_p]
@@ -106,12 +108,16 @@ class StateDict:
 
 
 def forward(sd: StateDict, x: np.ndarray, num_classes: int = 4, base_channels: int = 32, lite_p2: bool = False,
-            keep_all: bool = False, nthreads: int = 0) -> Dict[str, np.ndarray]:
-    """x: [1,3,H,W] or [3,H,W] fp32. Returns {name: [C,H,W] fp32}; the six heads are always present."""
+            keep_all: bool = False, nthreads: int = 0, variant: str = "A") -> Dict[str, np.ndarray]:
+    """x: [1,3,H,W] or [3,H,W] fp32. Returns {name: [C,H,W] fp32}; the six heads are always present.
+    variant "A" = model.py's graph, "B" = qat.py's (state_dict with qat.py key names)."""
     L = lib()
     x = np.ascontiguousarray(x, dtype=np.float32).reshape(3, x.shape[-2], x.shape[-1])
-    run = L.uo_forward(sd.h, x.ctypes.data, x.shape[1], x.shape[2], num_classes, base_channels, int(lite_p2),
-                       int(keep_all), nthreads)
+    if variant == "B":
+        run = L.uo_forward_qat(sd.h, x.ctypes.data, x.shape[1], x.shape[2], num_classes, base_channels, int(keep_all), nthreads)
+    else:
+        run = L.uo_forward(sd.h, x.ctypes.data, x.shape[1], x.shape[2], num_classes, base_channels, int(lite_p2),
+                           int(keep_all), nthreads)
     if not run:
         raise RuntimeError(L.uo_last_error().decode())
     try:

@@ -569,6 +569,112 @@ uo_run *uo_forward(const uo_statedict *sd, const float *x, int H, int W, int num
   return r;
 }
 
+/* DetectionHead branch of the QAT model: head_pN_cls / head_pN_reg are nn.Sequential(QuantConvBlock 3x3,
+ * QuantConvBlock 3x3, nn.Conv2d 1x1)  (qat.py:411-440) -- same arithmetic as model.py:289-303, flat names. */
+static ten head_seq(net *n, const char *seq, ten x, int nout, const char *out_name) {
+  char s[256];
+  snprintf(s, sizeof s, "%s.0", seq);
+  ten t = conv_block(n, s, x, x.c, 3, 1);
+  if (n->r->failed) return t;
+  snprintf(s, sizeof s, "%s.1", seq);
+  t = conv_block(n, s, t, x.c, 3, 1);
+  if (n->r->failed) return t;
+  snprintf(s, sizeof s, "%s.2", seq);
+  const float *w = param(n, s, "weight", nout * x.c), *b = param(n, s, "bias", nout);
+  if (n->r->failed) return t;
+  ten y = conv2d(n->r, t, w, b, nout, 1, 1);
+  keep(n->r, out_name, y, 1);
+  return y;
+}
+
+/* UNINA_YOLO_DLA_QAT.forward (qat.py:443-491) in float: the model the reference's QAT checkpoints belong to
+ * (graph (B): stride-32 stage + SPPF at 16x base channels, three FPN levels, PAN concat on the FUSED p4).
+ * Without pytorch-quantization the reference itself runs exactly this (QuantConvBlock falls back to nn.Conv2d,
+ * qat.py:249-254; QuantBottleneck adds x unquantised, qat.py:290-292). */
+uo_run *uo_forward_qat(const uo_statedict *sd, const float *x, int H, int W, int num_classes, int base_channels,
+                       int keep_all, int nthreads) {
+  if (g_slab_live) {
+    set_err("uo_forward_qat: previous run not freed (one live run at a time)");
+    return NULL;
+  }
+  if (H % 32 || W % 32) {
+    set_err("H and W must be multiples of 32");
+    return NULL;
+  }
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+  (void)nthreads;
+#endif
+  size_t need = (size_t)H * W * 480 * (size_t)(base_channels > 32 ? base_channels / 32 : 1) * sizeof(float) + (64u << 20);
+  if (need > g_slab_cap) {
+    free(g_slab);
+    g_slab = NULL;
+    if (posix_memalign((void **)&g_slab, 64, need)) {
+      g_slab_cap = 0;
+      set_err("oracle: cannot allocate %zu bytes", need);
+      return NULL;
+    }
+    memset(g_slab, 0, need);
+    g_slab_cap = need;
+  }
+  g_slab_used = 0;
+  g_slab_live = 1;
+
+  uo_run *r = calloc(1, sizeof *r);
+  r->keep_all = keep_all;
+  net n = {r, sd};
+  const int c1 = base_channels, c2 = c1 * 2, c3 = c1 * 4, c4 = c1 * 8, c5 = c1 * 16;
+
+  ten in = new_ten(r, 3, H, W);
+  if (r->failed) return r;
+  memcpy(in.d, x, sizeof(float) * 3 * (size_t)H * W);
+
+#define CHK if (r->failed) return r
+  /* backbone (qat.py:445-458) */
+  ten t = conv_block(&n, "stem", in, c1, 3, 2); CHK;
+  t = conv_block(&n, "stage1_conv", t, c2, 3, 2); CHK;
+  ten p2 = c3k2(&n, "stage1_c3k2", t, c2, 1); CHK;
+  t = conv_block(&n, "stage2_conv", p2, c3, 3, 2); CHK;
+  ten p3 = c3k2(&n, "stage2_c3k2", t, c3, 2); CHK;
+  t = conv_block(&n, "stage3_conv", p3, c4, 3, 2); CHK;
+  ten p4 = c3k2(&n, "stage3_c3k2", t, c4, 2); CHK;
+  t = conv_block(&n, "stage4_conv", p4, c5, 3, 2); CHK;
+  ten p5 = sppf(&n, "stage4_sppf", t, c5); CHK;
+
+  /* neck, top-down (qat.py:461-470) */
+  ten pr[2];
+  t = conv_block(&n, "lateral_p4", p5, c4, 1, 1); CHK;
+  pr[0] = up2(&n, "up_p5", t); pr[1] = p4; CHK;
+  t = cat(&n, "cat_fpn1", pr, 2); CHK;
+  ten p4f = c3k2(&n, "fpn_c3k2_1", t, c4, 1); CHK;
+  t = conv_block(&n, "lateral_p3", p4f, c3, 1, 1); CHK;
+  pr[0] = up2(&n, "up_p4", t); pr[1] = p3; CHK;
+  t = cat(&n, "cat_fpn2", pr, 2); CHK;
+  ten p3f = c3k2(&n, "fpn_c3k2_2", t, c3, 1); CHK;
+  t = conv_block(&n, "lateral_p2", p3f, c2, 1, 1); CHK;
+  pr[0] = up2(&n, "up_p3", t); pr[1] = p2; CHK;
+  t = cat(&n, "cat_fpn3", pr, 2); CHK;
+  ten p2f = c3k2(&n, "fpn_c3k2_3", t, c2, 1); CHK;
+  /* bottom-up (qat.py:473-477) */
+  pr[0] = conv_block(&n, "down1", p2f, c2, 3, 2); pr[1] = p3f; CHK;
+  t = cat(&n, "cat_pan1", pr, 2); CHK;
+  ten p3o = c3k2(&n, "pan_c3k2_1", t, c3, 1); CHK;
+  pr[0] = conv_block(&n, "down2", p3o, c3, 3, 2); pr[1] = p4f; /* the FUSED p4 (qat.py:476) */ CHK;
+  t = cat(&n, "cat_pan2", pr, 2); CHK;
+  ten p4o = c3k2(&n, "pan_c3k2_2", t, c4, 1); CHK;
+
+  /* heads (qat.py:480-489) */
+  head_seq(&n, "head_p2_cls", p2f, num_classes, "p2_cls"); CHK;
+  head_seq(&n, "head_p2_reg", p2f, 4, "p2_reg"); CHK;
+  head_seq(&n, "head_p3_cls", p3o, num_classes, "p3_cls"); CHK;
+  head_seq(&n, "head_p3_reg", p3o, 4, "p3_reg"); CHK;
+  head_seq(&n, "head_p4_cls", p4o, num_classes, "p4_cls"); CHK;
+  head_seq(&n, "head_p4_reg", p4o, 4, "p4_reg");
+#undef CHK
+  return r;
+}
+
 const float *uo_run_get(const uo_run *r, const char *name, int *c, int *h, int *w) {
   if (!r || r->failed) return NULL;
   for (int i = 0; i < r->n; ++i)

@@ -2,7 +2,8 @@
  * unina_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
  *
  * A plain-C fp32 restatement of the reference's algorithm for the hot path:
- *   - forward graph:  /root/reference/unina_yolo_dla/model.py:23-365
+ *   - forward graph:  /root/reference/unina_yolo_dla/model.py:23-365  (graph (A));
+ *                     /root/reference/unina_yolo_dla/qat.py:225-491     (graph (B), the QAT model, in float)
  *   - decode + NMS:   ros2_ws/src/perception/include/postprocess.hpp:28-145 (CPU twin)
  *                     ros2_ws/src/perception/src/gpu_postprocess.cu:62-83,102-251 (GPU deltas)
  *
@@ -35,6 +36,11 @@ typedef struct uo_run uo_run;
  * six heads "p2_cls".."p4_reg" are kept. nthreads<=0: OpenMP default. */
 uo_run *uo_forward(const uo_statedict *sd, const float *x, int H, int W, int num_classes,
                    int base_channels, int lite_p2, int keep_all, int nthreads);
+/* Graph (B): UNINA_YOLO_DLA_QAT.forward (qat.py:443-491) in float (the reference's own behaviour without
+ * pytorch-quantization); module names as in qat.py ("stem", "stage1_c3k2.cv1", "head_p2_cls.0", ...), synthetic
+ * names "up_p5/up_p4/up_p3", "cat_fpn1..3", "cat_pan1..2", "<sppf>.pool1..3". H, W multiples of 32. */
+uo_run *uo_forward_qat(const uo_statedict *sd, const float *x, int H, int W, int num_classes,
+                       int base_channels, int keep_all, int nthreads);
 const float *uo_run_get(const uo_run *r, const char *name, int *c, int *h, int *w);
 int uo_run_count(const uo_run *r);
 const char *uo_run_name(const uo_run *r, int i);

@@ -251,6 +251,7 @@ const Class kClasses[] = {
     C3K2(64, 4, 8, 1, 192, 8, 8),      // neck.pan_c3k2_1
     C3K2(128, 4, 4, 2, 256, 8, 16),    // backbone.stage3_c3k2          40^2: 100
     C3K2(128, 4, 4, 1, 384, 8, 16),    // neck.pan_c3k2_2
+    C3K2(128, 4, 4, 1, 512, 8, 16),    // graph (B) fpn_c3k2_1 (qat.py:397)
     // alternatives for A/B experiments, bit masks 1 = h 32, 2 = h 64, 4 = h 128:
     // UNINA_C3K2_ALT: larger tiles (half the workgroups, less halo recompute)
     C3K2(32, 8, 16, 1, 64, 8, 4),
@@ -269,14 +270,15 @@ const Class kClasses[] = {
     C3K2(128, 4, 4, 2, 256, 8, 16),
     C3K2(128, 4, 4, 1, 384, 8, 16),
 };
-constexpr int kPrimaryClasses = 7;
+constexpr int kPrimaryClasses = 8, kAltClasses = 7;
 #undef C3K2
 const Class* find_class(int hid, int nb, int cin) {
   static const int alt1 = getenv("UNINA_C3K2_ALT") ? atoi(getenv("UNINA_C3K2_ALT")) : 0;
   static const int alt2 = getenv("UNINA_C3K2_ALT2") ? atoi(getenv("UNINA_C3K2_ALT2")) : 0;
   const int bit = hid == 32 ? 1 : (hid == 64 ? 2 : 4);
   const int set = (alt1 & bit) ? 1 : ((alt2 & bit) ? 2 : 0);
-  for (int i = set * kPrimaryClasses; i < (set + 1) * kPrimaryClasses; ++i)
+  const int first = set == 0 ? 0 : kPrimaryClasses + (set - 1) * kAltClasses, count = set == 0 ? kPrimaryClasses : kAltClasses;
+  for (int i = first; i < first + count; ++i)
     if (kClasses[i].hid == hid && kClasses[i].nb == nb && kClasses[i].cin == cin) return &kClasses[i];
   return nullptr;
 }

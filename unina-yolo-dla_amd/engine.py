@@ -158,18 +158,19 @@ class Engine:
     @classmethod
     def from_state_dict(cls, sd: Dict[str, np.ndarray], graph: Optional[Graph] = None, device: int = 0,
                         path: Optional[str] = None, precision: int = _export.FP16,
-                        amax: Optional[Dict[str, float]] = None) -> "Engine":
+                        amax: Optional[Dict[str, float]] = None,
+                        weight_amax: Optional[Dict[str, float]] = None) -> "Engine":
         """export_trt.py's role + load: folds/fuses `sd` into an engine file (temporary unless `path`) and loads it.
         INT8 needs `amax` (calibrate_amax below)."""
         if path is None:
             fd, tmp = tempfile.mkstemp(suffix=".une")
             os.close(fd)
             try:
-                _export.export_engine(sd, tmp, graph, precision, amax)
+                _export.export_engine(sd, tmp, graph, precision, amax, weight_amax)
                 return cls(tmp, device)
             finally:
                 os.unlink(tmp)
-        _export.export_engine(sd, path, graph, precision, amax)
+        _export.export_engine(sd, path, graph, precision, amax, weight_amax)
         return cls(path, device)
 
     def _check(self, rc: int):

@@ -134,7 +134,8 @@ def fold_bn(sd: Dict[str, np.ndarray], module: str):
 
 
 # FP16 carve-outs of the reference's QAT recipe (train.py:779, qat.py:700-753): module-path prefixes kept in float
-INT8_CARVE_OUT = ("backbone.stem", "backbone.stage1_conv", "head_p2")
+INT8_CARVE_OUT = ("backbone.stem", "backbone.stage1_conv", "head_p2",      # graph (A) module paths
+                  "stem", "stage1_conv")                                  # graph (B) (qat.py) module paths
 
 
 def quantize_sym(x: np.ndarray, scale: float) -> np.ndarray:
@@ -144,11 +145,13 @@ def quantize_sym(x: np.ndarray, scale: float) -> np.ndarray:
 
 class EngineBuilder:
     def __init__(self, sd: Dict[str, np.ndarray], graph: Optional[Graph] = None, precision: int = FP16,
-                 amax: Optional[Dict[str, float]] = None):
+                 amax: Optional[Dict[str, float]] = None, weight_amax: Optional[Dict[str, float]] = None):
         """precision: FP16 (fp16 weights + activations, v_mfma_f32_16x16x32_f16), FP32 (fp32 everywhere,
         v_mfma_f32_16x16x4_f32: meets the north-star tolerance outright at 1/16 of the fp16 matrix rate), or INT8
         (per-tensor symmetric int8 activations AND weights as in qat.py:91-126, v_mfma_i32_16x16x64_i8, with the
-        reference's FP16 carve-outs; needs `amax`: buffer name -> calibrated |activation| maximum, see calibrate())."""
+        reference's FP16 carve-outs; needs `amax`: buffer name -> calibrated |activation| maximum, see calibrate() or,
+        for a QAT checkpoint, amax_from_qat()). `weight_amax`: optional conv module -> weight range from a checkpoint's
+        `_weight_quantizer._amax` (default: max |W| of the conv, which is what a max calibrator stores)."""
         if precision not in (FP16, FP32, INT8):
             raise NotImplementedError("precision must be FP16, FP32 or INT8")
         if precision == INT8 and amax is None:
@@ -156,6 +159,7 @@ class EngineBuilder:
         self.sd = sd
         self.precision = precision
         self.amax = amax
+        self.weight_amax = weight_amax or {}
         self.wdtype = np.float32 if precision == FP32 else np.float16
         self.act_dtype = BUF_F32_NHWC if precision == FP32 else BUF_F16
         self.g = graph or Graph()
@@ -164,7 +168,10 @@ class EngineBuilder:
         self.buffers: List[list] = []   # [name, h, w, c, dtype, flags, scale]
         self.ops: List[Op] = []
         self.blob = bytearray()
-        self._lower()
+        if self.g.variant == "A":
+            self._lower()
+        else:
+            self._lower_b()
         if precision == INT8:
             self._quantize_pass()
         self._finalize()
@@ -232,18 +239,94 @@ class EngineBuilder:
         self.conv([(f"{name}.cv3", 0, dst, 0)], cat, 2 * hid, 1)
 
     def head(self, name: str, feat: View, out_cls: int, out_reg: int):
-        """DetectionHead (model.py:274-303) -> 3 launches (both branches per launch)."""
+        """DetectionHead (model.py:274-303; qat.py:411-440) -> 3 launches (both branches per launch)."""
         h, w = self._hw(feat.buf)
         c = feat.c
         h0 = self.buf(f"{name}.h0", h, w, 2 * c)
         h1 = self.buf(f"{name}.h1", h, w, 2 * c)
-        self.conv([(f"{name}.cls_branch.0", feat.coff, View(h0, 0, c), 0),
-                   (f"{name}.reg_branch.0", feat.coff, View(h0, c, c), 0)], feat.buf, c, 3)
-        self.conv([(f"{name}.cls_branch.1", 0, View(h1, 0, c), 0),
-                   (f"{name}.reg_branch.1", c, View(h1, c, c), 0)], h0, c, 3)
-        self.conv([(f"{name}.cls_branch.2", 0, View(out_cls, 0, self.g.num_classes), SEG_PLANAR_F32),
-                   (f"{name}.reg_branch.2", c, View(out_reg, 0, 4), SEG_PLANAR_F32)], h1, c, 1,
+        cls, reg = (f"{name}.cls_branch", f"{name}.reg_branch") if self.g.variant == "A" else (f"{name}_cls", f"{name}_reg")
+        self.conv([(f"{cls}.0", feat.coff, View(h0, 0, c), 0),
+                   (f"{reg}.0", feat.coff, View(h0, c, c), 0)], feat.buf, c, 3)
+        self.conv([(f"{cls}.1", 0, View(h1, 0, c), 0),
+                   (f"{reg}.1", c, View(h1, c, c), 0)], h0, c, 3)
+        self.conv([(f"{cls}.2", 0, View(out_cls, 0, self.g.num_classes), SEG_PLANAR_F32),
+                   (f"{reg}.2", c, View(out_reg, 0, 4), SEG_PLANAR_F32)], h1, c, 1,
                   relu=False, bn=False)
+
+    def sppf(self, name: str, src: View, dst: View):
+        """SPPF_DLA (model.py:113-132; qat.py:328-345): cv1 -> ONE pool op (y1,y2,y3) -> cv2 over the 4-way concat."""
+        h, w = self._hw(src.buf)
+        hid = src.c // 2
+        sp = self.buf(f"{name}.cat", h, w, 4 * hid)
+        self.conv([(f"{name}.cv1", src.coff, View(sp, 0, hid), 0)], src.buf, src.c, 1)
+        pool = Op(OP_SPPF_POOL, f"{name}.pool1+pool2+pool3", sp, hid, 5, 1, 0, None, (h, w), (h, w))
+        pool.segs.append(Seg(f"{name}.pool", 0, 3 * hid, View(sp, hid, 3 * hid)))
+        self.ops.append(pool)
+        self.conv([(f"{name}.cv2", 0, dst, 0)], sp, 4 * hid, 1)
+
+    def stem(self, name: str, images: int, dst: View):
+        H, W = self._hw(images)
+        w, b = fold_bn(self.sd, name)
+        c1 = dst.c
+        op = Op(OP_STEM, name, images, 3, 3, 2, 1, None, (H, W), (H // 2, W // 2))
+        seg = Seg(name, 0, c1, dst, 0, n_pad=c1)
+        seg.w_raw, seg.fold, seg.bias = w.reshape(c1, 27), np.ones(c1), b      # stem: folded fp32 [O][(c,kh,kw)]
+        op.segs.append(seg)
+        self.ops.append(op)
+
+    # ---- graph (B): UNINA_YOLO_DLA_QAT.forward (qat.py:443-491) -------------------------------------------
+    def _lower_b(self):
+        g = self.g
+        bc = g.base_channels
+        c1, c2, c3, c4, c5 = bc, 2 * bc, 4 * bc, 8 * bc, 16 * bc
+        H, W = g.in_h, g.in_w
+        images = self.buf("images", H, W, 3, BUF_F32_NCHW_IN, BUF_INPUT)
+        outs = {}
+        for name, s in zip(OUTPUT_NAMES, (4, 4, 8, 8, 16, 16)):
+            c = g.num_classes if name.endswith("cls") else 4
+            outs[name] = self.buf(name, H // s, W // s, c, BUF_F32_PLANAR, BUF_OUTPUT)
+        # concat buffers (orders: qat.py:464,467,470,473,476)
+        fpn1 = self.buf("cat_fpn1", H // 16, W // 16, c4 + c4)     # [p5_up | p4]
+        fpn2 = self.buf("cat_fpn2", H // 8, W // 8, c3 + c3)       # [p4_up | p3]
+        fpn3 = self.buf("cat_fpn3", H // 4, W // 4, c2 + c2)       # [p3_up | p2]
+        pan1 = self.buf("cat_pan1", H // 8, W // 8, c2 + c3)       # [p2_down | p3_fused]
+        pan2 = self.buf("cat_pan2", H // 16, W // 16, c3 + c4)     # [p3_down | p4_fused]
+        p2, p3, p4 = View(fpn3, c2, c2), View(fpn2, c3, c3), View(fpn1, c4, c4)
+        p3_fused, p4_fused = View(pan1, c2, c3), View(pan2, c3, c4)
+
+        stem = self.view("stem", H // 2, W // 2, c1)
+        self.stem("stem", images, stem)
+        s1 = self.view("stage1_conv", H // 4, W // 4, c2)
+        self.conv([("stage1_conv", 0, s1, 0)], stem.buf, c1, 3, 2)
+        self.c3k2("stage1_c3k2", s1, p2, 1)
+        s2 = self.view("stage2_conv", H // 8, W // 8, c3)
+        self.conv([("stage2_conv", p2.coff, s2, 0)], p2.buf, c2, 3, 2)
+        self.c3k2("stage2_c3k2", s2, p3, 2)
+        s3 = self.view("stage3_conv", H // 16, W // 16, c4)
+        self.conv([("stage3_conv", p3.coff, s3, 0)], p3.buf, c3, 3, 2)
+        self.c3k2("stage3_c3k2", s3, p4, 2)
+        s4 = self.view("stage4_conv", H // 32, W // 32, c5)
+        self.conv([("stage4_conv", p4.coff, s4, 0)], p4.buf, c4, 3, 2)
+        p5 = self.view("stage4_sppf", H // 32, W // 32, c5)
+        self.sppf("stage4_sppf", s4, p5)
+
+        self.conv([("lateral_p4", 0, View(fpn1, 0, c4), SEG_UP2)], p5.buf, c5, 1)
+        self.c3k2("fpn_c3k2_1", View(fpn1, 0, 2 * c4), p4_fused, 1)
+        self.conv([("lateral_p3", p4_fused.coff, View(fpn2, 0, c3), SEG_UP2)], p4_fused.buf, c4, 1)
+        self.c3k2("fpn_c3k2_2", View(fpn2, 0, 2 * c3), p3_fused, 1)
+        self.conv([("lateral_p2", p3_fused.coff, View(fpn3, 0, c2), SEG_UP2)], p3_fused.buf, c3, 1)
+        p2_fused = self.view("p2_fused", H // 4, W // 4, c2)
+        self.c3k2("fpn_c3k2_3", View(fpn3, 0, 2 * c2), p2_fused, 1)
+        self.conv([("down1", 0, View(pan1, 0, c2), 0)], p2_fused.buf, c2, 3, 2)
+        p3_out = self.view("p3_out", H // 8, W // 8, c3)
+        self.c3k2("pan_c3k2_1", View(pan1, 0, c2 + c3), p3_out, 1)
+        self.conv([("down2", 0, View(pan2, 0, c3), 0)], p3_out.buf, c3, 3, 2)
+        p4_out = self.view("p4_out", H // 16, W // 16, c4)
+        self.c3k2("pan_c3k2_2", View(pan2, 0, c3 + c4), p4_out, 1)
+
+        self.head("head_p2", p2_fused, outs["p2_cls"], outs["p2_reg"])
+        self.head("head_p3", p3_out, outs["p3_cls"], outs["p3_reg"])
+        self.head("head_p4", p4_out, outs["p4_cls"], outs["p4_reg"])
 
     # ---- the network ---------------------------------------------------------------------------
     def _lower(self):
@@ -392,7 +475,7 @@ class EngineBuilder:
                 bk = np.zeros((sg.n_pad,), dtype=np.float32)
                 bk[:sg.n_count] = sg.bias.astype(np.float32)
                 if int8:
-                    sg.w_scale = max(float(np.abs(sg.w_raw).max()), 1e-12) / 127.0
+                    sg.w_scale = max(float(self.weight_amax.get(sg.module, np.abs(sg.w_raw).max())), 1e-12) / 127.0
                     wk = np.zeros((sg.n_pad, K), dtype=np.int8)
                     wk[:sg.n_count] = quantize_sym(sg.w_raw, sg.w_scale)
                     mk = np.zeros((sg.n_pad,), dtype=np.float32)
@@ -452,11 +535,48 @@ def calibrate(named_buffers_per_frame, percentile: Optional[float] = None) -> Di
 
 
 def export_engine(sd: Dict[str, np.ndarray], path: str, graph: Optional[Graph] = None,
-                  precision: int = FP16, amax: Optional[Dict[str, float]] = None) -> EngineBuilder:
+                  precision: int = FP16, amax: Optional[Dict[str, float]] = None,
+                  weight_amax: Optional[Dict[str, float]] = None) -> EngineBuilder:
     """state_dict (reference key names) -> engine file. Returns the builder (op table for inspection)."""
-    b = EngineBuilder(sd, graph, precision, amax)
+    b = EngineBuilder(sd, graph, precision, amax, weight_amax)
     b.save(path)
     return b
+
+
+def amax_from_qat(sd: Dict[str, np.ndarray], graph: Graph, quant: dict,
+                  fallback: Optional[Dict[str, float]] = None) -> Dict[str, float]:
+    """Activation ranges for an INT8 engine taken from a QAT checkpoint's own quantizers (statedict.from_qat_checkpoint):
+    the reference puts ONE input quantizer on every QuantConv2d (qat.py:109-124, 245-248), the engine keeps ONE scale per
+    activation buffer (a concat buffer feeds one conv, sibling convs such as C3k2's cv1 / cv2 share their input), so a
+    buffer takes the LARGEST range of the convs that read it (no clipping that the checkpoint's quantizers would not do).
+    Buffers no checkpoint quantizer speaks for (e.g. a residual-only tensor) come from `fallback` (a calibrate() result)."""
+    b = EngineBuilder(sd, graph)                         # fp16 table: which conv module reads which buffer
+    out: Dict[str, float] = dict(fallback or {})
+    seen = set()
+    for op in b.ops:
+        if op.kind != OP_CONV:
+            continue
+        name = b.buffers[op.src_buf][0]
+        for sg in op.segs:
+            a = quant.get("input_amax", {}).get(sg.module)
+            if a is not None:
+                out[name] = max(a, out[name]) if name in seen else a
+                seen.add(name)
+    return out
+
+
+def export_qat_checkpoint(ck: Dict[str, np.ndarray], path: str, in_h: int = 640, in_w: int = 640, num_classes: int = 4,
+                          base_channels: int = 32, fallback_amax: Optional[Dict[str, float]] = None) -> EngineBuilder:
+    """A `UNINA_YOLO_DLA_QAT` checkpoint (qat.py key names, quantizer `_amax` entries included) -> INT8 engine file of
+    graph (B), using the checkpoint's own activation / weight ranges; without quantizer entries (a float checkpoint of
+    the QAT topology) -> fp16 engine."""
+    from . import statedict
+    weights, quant = statedict.from_qat_checkpoint(ck)
+    g = Graph(num_classes=num_classes, base_channels=base_channels, in_h=in_h, in_w=in_w, variant="B")
+    if not quant["input_amax"]:
+        return export_engine(weights, path, g, FP16)
+    amax = amax_from_qat(weights, g, quant, fallback_amax)
+    return export_engine(weights, path, g, INT8, amax, quant["weight_amax"])
 
 
 def read_engine_header(path: str) -> dict:

@@ -1,8 +1,11 @@
-"""Topology of the detector forward graph ("graph (A)") as a plain node list.
+"""Topology of the detector forward graphs as plain node lists.
 
-This is the build's own description of what the reference's
-``UNINA_YOLO_DLA.forward`` computes (reference: unina_yolo_dla/model.py:308-365,
-blocks at model.py:23-147, backbone :152-219, neck :224-269, head :274-303).
+variant "A" (default): what the reference's ``UNINA_YOLO_DLA.forward`` computes (reference:
+unina_yolo_dla/model.py:308-365, blocks at model.py:23-147, backbone :152-219, neck :224-269, head :274-303).
+variant "B": the reference's QAT model ``UNINA_YOLO_DLA_QAT`` (unina_yolo_dla/qat.py:350-491) -- same blocks, but a
+stride-32 stage (stage4_conv + SPPF at 16x base channels, qat.py:391-392), a third FPN level (qat.py:396-403), the PAN's
+last concat on the FUSED p4 (qat.py:474) and flat module names (``stem``, ``stage1_c3k2``, ``head_p2_cls.0`` ...): the
+layout its checkpoints (qat.py state_dicts) come in. Same output contract.
 Nothing here executes arithmetic: the node list is consumed by
 
 * ``synth.py``   -- to enumerate parameter names / shapes (state_dict keys match
@@ -42,16 +45,25 @@ class Graph:
     """Builder + container. ``nodes[i]`` is in topological (forward) order."""
 
     def __init__(self, num_classes: int = 4, base_channels: int = 32, lite_p2: bool = False,
-                 in_h: int = 640, in_w: int = 640):
-        if in_h % 16 or in_w % 16:
-            raise ValueError("input H and W must be multiples of 16 (three stride-2 stages + x2 upsample/concat)")
+                 in_h: int = 640, in_w: int = 640, variant: str = "A"):
+        if variant not in ("A", "B"):
+            raise ValueError("variant must be 'A' (model.py) or 'B' (qat.py)")
+        m = 16 if variant == "A" else 32
+        if in_h % m or in_w % m:
+            raise ValueError(f"input H and W must be multiples of {m} (stride-2 stages + x2 upsample/concat)")
+        if variant == "B" and lite_p2:
+            raise ValueError("lite_p2 exists only in graph (A) (model.py:184-190)")
         self.num_classes = num_classes
         self.base_channels = base_channels
         self.lite_p2 = lite_p2
+        self.variant = variant
         self.in_h, self.in_w = in_h, in_w
         self.nodes: List[Node] = []
         self.outputs: List[int] = []          # p2_cls, p2_reg, p3_cls, p3_reg, p4_cls, p4_reg
-        self._build()
+        if variant == "A":
+            self._build()
+        else:
+            self._build_b()
 
     # -- primitive emitters -------------------------------------------------
     def _add(self, n: Node) -> int:
@@ -125,10 +137,13 @@ class Graph:
     def head(self, name: str, x: int):
         c, _, _ = self._shape(x)
         outs = []
-        for br, nout in (("cls_branch", self.num_classes), ("reg_branch", 4)):
-            t = self.conv(f"{name}.{br}.0", x, c, k=3)
-            t = self.conv(f"{name}.{br}.1", t, c, k=3)
-            outs.append(self.convout(f"{name}.{br}.2", t, nout))
+        for br, nout in (("cls", self.num_classes), ("reg", 4)):
+            # graph (A): DetectionHead.cls_branch / .reg_branch (model.py:289-299); graph (B): head_pN_cls / head_pN_reg
+            # Sequentials (qat.py:411-440)
+            prefix = f"{name}.{br}_branch" if self.variant == "A" else f"{name}_{br}"
+            t = self.conv(f"{prefix}.0", x, c, k=3)
+            t = self.conv(f"{prefix}.1", t, c, k=3)
+            outs.append(self.convout(f"{prefix}.2", t, nout))
         return outs
 
     # -- the network (model.py:205-219, 252-269, 357-365) --------------------
@@ -159,6 +174,33 @@ class Graph:
         # NOTE: the last concat takes the PRE-SPPF p4 (model.py:254,267)
         p4_out = self.c3k2("neck.pan_c3k2_2", self.cat("neck.cat_pan2", [p3_down, p4]), c4, n=1)
 
+        for hname, feat in (("head_p2", p2_fused), ("head_p3", p3_out), ("head_p4", p4_out)):
+            self.outputs += self.head(hname, feat)
+
+    # -- graph (B): UNINA_YOLO_DLA_QAT (qat.py:381-491) ------------------------
+    def _build_b(self):
+        bc = self.base_channels
+        c1, c2, c3, c4, c5 = bc, bc * 2, bc * 4, bc * 8, bc * 16
+        x = self.conv("stem", -1, c1, k=3, s=2)
+        x = self.conv("stage1_conv", x, c2, k=3, s=2)
+        p2 = self.c3k2("stage1_c3k2", x, c2, n=1)
+        x = self.conv("stage2_conv", p2, c3, k=3, s=2)
+        p3 = self.c3k2("stage2_c3k2", x, c3, n=2)
+        x = self.conv("stage3_conv", p3, c4, k=3, s=2)
+        p4 = self.c3k2("stage3_c3k2", x, c4, n=2)
+        x = self.conv("stage4_conv", p4, c5, k=3, s=2)
+        p5_sppf = self.sppf("stage4_sppf", x, c5)
+
+        p5_up = self.up2("up_p5", self.conv("lateral_p4", p5_sppf, c4, k=1))
+        p4_fused = self.c3k2("fpn_c3k2_1", self.cat("cat_fpn1", [p5_up, p4]), c4, n=1)        # qat.py:464
+        p4_up = self.up2("up_p4", self.conv("lateral_p3", p4_fused, c3, k=1))
+        p3_fused = self.c3k2("fpn_c3k2_2", self.cat("cat_fpn2", [p4_up, p3]), c3, n=1)        # qat.py:467
+        p3_up = self.up2("up_p3", self.conv("lateral_p2", p3_fused, c2, k=1))
+        p2_fused = self.c3k2("fpn_c3k2_3", self.cat("cat_fpn3", [p3_up, p2]), c2, n=1)        # qat.py:470
+        p2_down = self.conv("down1", p2_fused, c2, k=3, s=2)
+        p3_out = self.c3k2("pan_c3k2_1", self.cat("cat_pan1", [p2_down, p3_fused]), c3, n=1)  # qat.py:473
+        p3_down = self.conv("down2", p3_out, c3, k=3, s=2)
+        p4_out = self.c3k2("pan_c3k2_2", self.cat("cat_pan2", [p3_down, p4_fused]), c4, n=1)  # qat.py:476 (FUSED p4)
         for hname, feat in (("head_p2", p2_fused), ("head_p3", p3_out), ("head_p4", p4_out)):
             self.outputs += self.head(hname, feat)
 

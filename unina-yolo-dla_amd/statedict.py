@@ -44,3 +44,46 @@ def load(path: str) -> Dict[str, np.ndarray]:
             n = int(np.prod(dims)) if nd else 1
             out[name] = np.frombuffer(f.read(4 * n), dtype="<f4").reshape(dims).copy()
     return out
+
+
+# ---- checkpoints of the reference's QAT model (graph (B), unina_yolo_dla/qat.py) ----------------------------
+_QUANT_MARKS = ("._input_quantizer.", "._weight_quantizer.", "._output_quantizer.", ".residual_quantizer.")
+
+
+def from_qat_checkpoint(ck: Dict[str, np.ndarray]):
+    """{key: array} of a `UNINA_YOLO_DLA_QAT` state_dict (qat.py:350-491; loaded elsewhere with a non-executing loader,
+    e.g. ``torch.load(p, weights_only=True)`` -> ``{k: v.numpy()}``)  ->  (weights, quant).
+
+    `weights` keeps exactly the parameter keys graph (B) needs (conv / BN / head conv tensors, fp32): an optional
+    ``module.`` prefix is dropped, BatchNorm ``num_batches_tracked`` and every quantizer entry are removed (the name
+    rules of qat.py:554-563, 657-673: pytorch-quantization nests `_input_quantizer` / `_weight_quantizer` under the
+    conv, `residual_quantizer` under the bottleneck). `quant` collects the calibrated ranges those entries carry:
+    ``{"input_amax": {conv module: amax}, "weight_amax": {conv module: amax}, "residual_amax": {bottleneck: amax}}``
+    (per-tensor: QuantDescriptor(axis=None), qat.py:109-124)."""
+    weights: Dict[str, np.ndarray] = {}
+    quant = {"input_amax": {}, "weight_amax": {}, "residual_amax": {}}
+    for key, val in ck.items():
+        k = key[7:] if key.startswith("module.") else key
+        if k.endswith("num_batches_tracked"):
+            continue
+        if any(m in k + "." for m in _QUANT_MARKS):
+            if k.endswith("._amax"):
+                a = float(np.max(np.abs(np.asarray(val, dtype=np.float64))))
+                if "._input_quantizer." in k:
+                    quant["input_amax"][k.split(".conv._input_quantizer.")[0]] = a
+                elif "._weight_quantizer." in k:
+                    quant["weight_amax"][k.split(".conv._weight_quantizer.")[0]] = a
+                elif ".residual_quantizer." in k:
+                    quant["residual_amax"][k.split(".residual_quantizer.")[0]] = a
+            continue
+        weights[k] = np.asarray(val, dtype=np.float32)
+    return weights, quant
+
+
+def detect_variant(sd: Dict[str, np.ndarray]) -> str:
+    """'A' for model.py key names (``backbone.stem.conv.weight``), 'B' for qat.py's (``stem.conv.weight``)."""
+    if "backbone.stem.conv.weight" in sd:
+        return "A"
+    if "stem.conv.weight" in sd and "stage4_conv.conv.weight" in sd:
+        return "B"
+    raise ValueError("state_dict matches neither graph (A) (model.py) nor graph (B) (qat.py)")

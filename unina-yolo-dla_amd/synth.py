@@ -35,7 +35,7 @@ _CALIB_PATH = os.path.join(os.path.dirname(__file__), "synth_calib.json")
 
 
 def calib_key(seed: int, g: Graph) -> str:
-    return f"seed{seed}_nc{g.num_classes}_bc{g.base_channels}_lite{int(g.lite_p2)}"
+    return f"seed{seed}_nc{g.num_classes}_bc{g.base_channels}_lite{int(g.lite_p2)}" + ("" if g.variant == "A" else f"_{g.variant}")
 
 
 def load_calib() -> Dict[str, Dict[str, float]]:
