@@ -39,11 +39,13 @@ namespace {
 
 // step 0: cv1|cv2 (K = CIN, N = 2h); odd steps: bottleneck 1x1 (K = h, N = h); even steps: bottleneck 3x3 (K = 9h,
 // N = h); last step: cv3 (K = 2h, N = 2h). A wave owns one channel subtile, or ns / NW of them when ns > NW.
-template <int H_, int NB, int CIN, int NW>
+// TAIL = 1 appends the lateral 1x1 conv (2h -> h, + nearest x2 upsample in its store) that follows an FPN block.
+template <int H_, int NB, int CIN, int NW, int TAIL>
 struct C3k2Plan {
-  static constexpr int N = 2 + 2 * NB;
-  static constexpr int kb(int s) { return s == 0 ? CIN / 32 : (s == N - 1 ? 2 * H_ / 32 : ((s & 1) ? H_ / 32 : 9 * H_ / 32)); }
-  static constexpr int ns(int s) { return (s == 0 || s == N - 1) ? 2 * H_ / 16 : H_ / 16; }
+  static constexpr int CV3 = 1 + 2 * NB;        // index of the cv3 step
+  static constexpr int N = 2 + 2 * NB + TAIL;
+  static constexpr int kb(int s) { return s == 0 ? CIN / 32 : (s >= CV3 ? 2 * H_ / 32 : ((s & 1) ? H_ / 32 : 9 * H_ / 32)); }
+  static constexpr int ns(int s) { return (s == 0 || s == CV3) ? 2 * H_ / 16 : H_ / 16; }
   static constexpr int wnt(int s) { return ns(s) <= NW ? 1 : ns(s) / NW; }
 };
 
@@ -54,10 +56,10 @@ extern __shared__ __align__(16) unsigned char c3_smem[];
 // NW waves per workgroup (roles per step: Steps::waves_n / wnt / waves_m); D = weight prefetch depth in 1-KiB blocks
 // per wave. There is no wave-uniform branch around any global load: the kernel is straight-line code, so the
 // compiler's counted s_waitcnt vmcnt keeps D loads in flight across every step boundary.
-template <int H_, int TH, int TW, int NB, int CIN, int NW, int D>
+template <int H_, int TH, int TW, int NB, int CIN, int NW, int D, int TAIL = 0>
 __global__ __launch_bounds__(NW * 64) void c3k2_fused_kernel(const C3k2Params p) {
   static_assert(NB == 1 || NB == 2, "bottleneck count");
-  typedef StepTable<C3k2Plan<H_, NB, CIN, NW>, NW> ST;
+  typedef StepTable<C3k2Plan<H_, NB, CIN, NW, TAIL>, NW> ST;
   static_assert(ST::valid(), "wave roles");
   static_assert((NW & (NW - 1)) == 0 && NW >= 2 && NW <= 16, "waves per workgroup");
   constexpr int R0W = TW + 2 * NB, P0 = (TH + 2 * NB) * R0W;   // input / first-level region (tile + NB-pixel halo)
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(NW * 64) void c3k2_fused_kernel(const C3k2Params p)
   constexpr int ROWB = 2 * H_ * 2 + 16;  // staged output row: 2h halfs + 16 bytes of padding (bank spread)
   unsigned char* stage = smem + p.off_stage;
   const float* bias_3 = bias_lds + 2 * H_ * (1 + NB);
-  run_step(STEP(ST::N - 1, PT),
+  run_step(STEP(1 + 2 * NB, PT),
       [&](int sub, auto kc) {
         constexpr int kb = decltype(kc)::value;
         int pp = sub * 16 + l15;
@@ -219,7 +221,6 @@ __global__ __launch_bounds__(NW * 64) void c3k2_fused_kernel(const C3k2Params p)
         for (int r = 0; r < 4; ++r) hv[r] = (half_t)v[r];
         *reinterpret_cast<half4*>(stage + pp * ROWB + n * 2) = hv;
       });
-#undef STEP
   typedef float vec16 __attribute__((ext_vector_type(4)));  // 16 opaque bytes
   constexpr int CPR = 2 * H_ * 2 / 16;                      // 16-byte chunks per output pixel
   for (int c = threadIdx.x; c < PT * CPR; c += NT) {
@@ -229,57 +230,79 @@ __global__ __launch_bounds__(NW * 64) void c3k2_fused_kernel(const C3k2Params p)
       *reinterpret_cast<vec16*>(p.dst + (size_t)(oy * p.W + ox) * p.dst_ld + ch * 8) =
           *reinterpret_cast<const vec16*>(stage + pp * ROWB + ch * 16);
   }
+
+  if constexpr (TAIL) {
+    // ---- tail: lateral 1x1 (model.py:256,259: ConvBlock 2h -> h) on the block's output, still in the staging image,
+    //      then nearest x2 upsample (model.py:145-147) in the store: each pixel's h channels go to its 2x2 block ----
+    const Img YS = Img{p.off_stage, ROWB / 16, 0, 0};        // the staging image is linear: pitch ROWB, no swizzle
+    constexpr int ROWT = H_ * 2 + 16;
+    unsigned char* tout = smem + p.off_tail;
+    const float* bias_t = bias_lds + 2 * H_ * (2 + NB);
+    run_step(STEP(2 + 2 * NB, PT),
+        [&](int sub, auto kc) {
+          int pp = sub * 16 + l15;
+          pp = pp < PT ? pp : PT - 1;
+          return YS.addr(pp, decltype(kc)::value * 4 + lq);
+        },
+        [&](int sub, int n, const floatx4& acc) {
+          const int pp = sub * 16 + l15;
+          if (pp >= PT) return;
+          const floatx4 v = bias_relu(acc, bias_t, n);
+          half4 hv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hv[r] = (half_t)v[r];
+          *reinterpret_cast<half4*>(tout + pp * ROWT + n * 2) = hv;
+        });
+    constexpr int CPT = H_ * 2 / 16;
+    const size_t px = (size_t)p.dst2_ld, row = (size_t)(2 * p.W) * px;
+    for (int c = threadIdx.x; c < PT * CPT; c += NT) {
+      const int pp = c / CPT, ch = c - pp * CPT;
+      const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
+      if (oy < p.H && ox < p.W) {
+        const vec16 v = *reinterpret_cast<const vec16*>(tout + pp * ROWT + ch * 16);
+        half_t* d = p.dst2 + ((size_t)(2 * oy) * (2 * p.W) + 2 * ox) * px + ch * 8;
+        *reinterpret_cast<vec16*>(d) = v;
+        *reinterpret_cast<vec16*>(d + px) = v;
+        *reinterpret_cast<vec16*>(d + row) = v;
+        *reinterpret_cast<vec16*>(d + row + px) = v;
+      }
+    }
+  }
+#undef STEP
 }
 
 // ------------------------------------------------------------------------------------------------- host side
 namespace {
 
 struct Class {
-  int hid, nb, cin, th, tw, nw;
+  int hid, nb, cin, tail, th, tw, nw;
   const char* name;
   void (*fn)(const C3k2Params);
 };
 #define C3K2(H_, TH, TW, NB, CIN, NW, D) \
-  {H_, NB, CIN, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D>}
+  {H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0>}
+#define C3K2T(H_, TH, TW, NB, CIN, NW, D) \
+  {H_, NB, CIN, 1, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,lat>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 1>}
 const Class kClasses[] = {
-    // tiles chosen by end-to-end A/B at 640^2 (profiles/r01): twice the workgroups of the first choice (8x16 / 8x8 /
-    // 4x8) cost more halo recompute but cut the serial frame by ~10 us at equal throughput
+    // Tiles chosen by end-to-end A/B at 640^2: twice the workgroups of the first choice (8x16 / 8x8 / 4x8) cost more
+    // halo recompute but cut the serial frame by ~10 us at equal throughput; one step smaller still (4x8 / 4x4 / 4x4)
+    // lost 4-6 % throughput; deeper weight queues (D x2, x1.5) changed nothing.
     C3K2(32, 8, 8, 1, 64, 8, 4),       // backbone.stage1_block        160^2 at 640: 400 workgroups
     C3K2(32, 8, 8, 1, 128, 8, 4),      // neck.fpn_c3k2_2
     C3K2(64, 4, 8, 2, 128, 8, 8),      // backbone.stage2_c3k2          80^2: 200
     C3K2(64, 4, 8, 1, 256, 8, 8),      // neck.fpn_c3k2_1
+    C3K2T(64, 4, 8, 1, 256, 8, 8),     // neck.fpn_c3k2_1 + neck.lateral_p2 (+ x2 upsample)
     C3K2(64, 4, 8, 1, 192, 8, 8),      // neck.pan_c3k2_1
     C3K2(128, 4, 4, 2, 256, 8, 16),    // backbone.stage3_c3k2          40^2: 100
     C3K2(128, 4, 4, 1, 384, 8, 16),    // neck.pan_c3k2_2
     C3K2(128, 4, 4, 1, 512, 8, 16),    // graph (B) fpn_c3k2_1 (qat.py:397)
-    // alternatives for A/B experiments, bit masks 1 = h 32, 2 = h 64, 4 = h 128:
-    // UNINA_C3K2_ALT: larger tiles (half the workgroups, less halo recompute)
-    C3K2(32, 8, 16, 1, 64, 8, 4),
-    C3K2(32, 8, 16, 1, 128, 8, 4),
-    C3K2(64, 8, 8, 2, 128, 8, 8),
-    C3K2(64, 8, 8, 1, 256, 8, 8),
-    C3K2(64, 8, 8, 1, 192, 8, 8),
-    C3K2(128, 4, 8, 2, 256, 8, 16),
-    C3K2(128, 4, 8, 1, 384, 8, 16),
-    // UNINA_C3K2_ALT2: smaller still
-    C3K2(32, 4, 8, 1, 64, 8, 4),
-    C3K2(32, 4, 8, 1, 128, 8, 4),
-    C3K2(64, 4, 4, 2, 128, 8, 8),
-    C3K2(64, 4, 4, 1, 256, 8, 8),
-    C3K2(64, 4, 4, 1, 192, 8, 8),
-    C3K2(128, 4, 4, 2, 256, 8, 16),
-    C3K2(128, 4, 4, 1, 384, 8, 16),
+    C3K2T(128, 4, 4, 1, 512, 8, 16),   // graph (B) fpn_c3k2_1 + lateral_p3
 };
-constexpr int kPrimaryClasses = 8, kAltClasses = 7;
 #undef C3K2
-const Class* find_class(int hid, int nb, int cin) {
-  static const int alt1 = getenv("UNINA_C3K2_ALT") ? atoi(getenv("UNINA_C3K2_ALT")) : 0;
-  static const int alt2 = getenv("UNINA_C3K2_ALT2") ? atoi(getenv("UNINA_C3K2_ALT2")) : 0;
-  const int bit = hid == 32 ? 1 : (hid == 64 ? 2 : 4);
-  const int set = (alt1 & bit) ? 1 : ((alt2 & bit) ? 2 : 0);
-  const int first = set == 0 ? 0 : kPrimaryClasses + (set - 1) * kAltClasses, count = set == 0 ? kPrimaryClasses : kAltClasses;
-  for (int i = first; i < first + count; ++i)
-    if (kClasses[i].hid == hid && kClasses[i].nb == nb && kClasses[i].cin == cin) return &kClasses[i];
+#undef C3K2T
+const Class* find_class(int hid, int nb, int cin, int tail) {
+  for (const Class& c : kClasses)
+    if (c.hid == hid && c.nb == nb && c.cin == cin && c.tail == tail) return &c;
   return nullptr;
 }
 constexpr int kMaxLds = 160 * 1024;
@@ -295,23 +318,23 @@ hipError_t c3k2_init() {
   return hipSuccess;
 }
 
-bool c3k2_supported(int hid, int nb, int cin) {
+bool c3k2_supported(int hid, int nb, int cin, int tail) {
   C3k2Params p;
   memset(&p, 0, sizeof p);
-  p.hid = hid; p.nb = nb; p.Cin = cin; p.H = p.W = 64;
+  p.hid = hid; p.nb = nb; p.Cin = cin; p.tail = tail; p.H = p.W = 64;
   return c3k2_layout(&p);
 }
 
 // Fills tile geometry and the LDS layout of `p` (needs hid, nb, Cin, H, W). False = no such class / no fit.
 bool c3k2_layout(C3k2Params* p) {
-  const Class* c = find_class(p->hid, p->nb, p->Cin);
+  const Class* c = find_class(p->hid, p->nb, p->Cin, p->tail);
   if (!c) return false;
   const int h = p->hid, nb = p->nb;
   const int p0 = (c->th + 2 * nb) * (c->tw + 2 * nb), p1 = (c->th + 2) * (c->tw + 2), pt = c->th * c->tw;
   p->tiles_x = (p->W + c->tw - 1) / c->tw;
   p->tiles_y = (p->H + c->th - 1) / c->th;
   p->tiles_x_magic = div_magic((unsigned)p->tiles_x);
-  p->n_bias = 2 * h * (2 + nb);
+  p->n_bias = 2 * h * (2 + nb) + (p->tail ? h : 0);
   const int x_bytes = align_up(p0 * p->Cin * 2, 1024) + 1024;  // the last patch DMA instruction may overrun by < 1 KiB
   const int t_bytes = p0 * h * 2, u1_bytes = nb == 2 ? p1 * h * 2 : 0, u2_bytes = pt * h * 2;
   const int stage_bytes = pt * (2 * h * 2 + 16);
@@ -327,7 +350,10 @@ bool c3k2_layout(C3k2Params* p) {
   p->off_u1 = off + align_up(head, 16);
   p->off_u2 = p->off_u1 + align_up(u1_bytes, 16);
   off += align_up(a_bytes, 1024);
-  p->off_y = off; off += align_up(p0 * 2 * h * 2, 1024);
+  p->off_y = off;
+  p->off_tail = off;                                          // the tail's output tile replaces a | b (dead after cv3)
+  const int y_bytes = p0 * 2 * h * 2, tail_bytes = p->tail ? pt * (h * 2 + 16) : 0;
+  off += align_up(y_bytes > tail_bytes ? y_bytes : tail_bytes, 1024);
   p->smem_bytes = off;
   return off <= kMaxLds;
 }
@@ -355,13 +381,13 @@ void block_pack(const C3k2Conv* convs, int nconv, std::vector<unsigned char>* st
 }
 
 // C3k2 convs in execution order: cv1|cv2, {b.cv1, b.cv2} x nb, cv3.
-bool c3k2_pack(int hid, int nb, int cin, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias) {
-  if (!find_class(hid, nb, cin)) return false;
-  const int nconv = 2 + 2 * nb;
+bool c3k2_pack(int hid, int nb, int cin, int tail, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias) {
+  if (!find_class(hid, nb, cin, tail)) return false;
+  const int ncv3 = 1 + 2 * nb, nconv = 2 + 2 * nb + (tail ? 1 : 0);
   for (int ci = 0; ci < nconv; ++ci) {
     const C3k2Conv& cv = convs[ci];
-    const int want_n = (ci == 0 || ci == nconv - 1) ? 2 * hid : hid;
-    const int want_k = ci == 0 ? cin : (ci == nconv - 1 ? 2 * hid : ((ci & 1) ? hid : 9 * hid));
+    const int want_n = (ci == 0 || ci == ncv3) ? 2 * hid : hid;
+    const int want_k = ci == 0 ? cin : (ci >= ncv3 ? 2 * hid : ((ci & 1) ? hid : 9 * hid));
     if (cv.n[0] + cv.n[1] != want_n || cv.K != want_k || cv.n[0] % 16 || cv.n[1] % 16) return false;
   }
   block_pack(convs, nconv, stream, bias);
@@ -369,19 +395,19 @@ bool c3k2_pack(int hid, int nb, int cin, const C3k2Conv* convs, std::vector<unsi
 }
 
 hipError_t c3k2_launch(const C3k2Params& p, hipStream_t stream) {
-  const Class* c = find_class(p.hid, p.nb, p.Cin);
+  const Class* c = find_class(p.hid, p.nb, p.Cin, p.tail);
   if (!c) return hipErrorInvalidValue;
   hipLaunchKernelGGL(c->fn, dim3(p.tiles_x * p.tiles_y, 1, 1), dim3(c->nw * 64, 1, 1), p.smem_bytes, stream, p);
   return hipGetLastError();
 }
 
-const char* c3k2_kernel_name(int hid, int nb, int cin) {
-  const Class* c = find_class(hid, nb, cin);
+const char* c3k2_kernel_name(int hid, int nb, int cin, int tail) {
+  const Class* c = find_class(hid, nb, cin, tail);
   return c ? c->name : "c3k2_fused<?>";
 }
 
-int c3k2_block_threads(int hid, int nb, int cin) {
-  const Class* c = find_class(hid, nb, cin);
+int c3k2_block_threads(int hid, int nb, int cin, int tail) {
+  const Class* c = find_class(hid, nb, cin, tail);
   return c ? c->nw * 64 : 0;
 }
 

@@ -45,6 +45,7 @@ struct PlannedOp {
   int fuse_kind = 0;        // role 1: 1 = C3k2 block (c3k2_fused.hip), 2 = DetectionHead (head_fused.hip)
   HeadParams hp;
   int group_last = -1;      // role 1: index of the group's last op (cv3 / the head's output convs)
+  int tail_op = -1;         // role 1, C3k2: index of the lateral 1x1 (+ x2 upsample) that runs as the block kernel's last step
   int hid = 0, nb = 0;      // role 1: hidden width, bottleneck count
   uint64_t stream_off = 0, fbias_off = 0;   // role 1: blob offsets of the packed stage stream / concatenated biases
   C3k2Params fp;
@@ -349,11 +350,19 @@ int plan(unina_engine* e) {
     f.zeros = e->d_zeros;
     f.hid = op.hid;
     f.nb = op.nb;
+    if (op.tail_op >= 0) {
+      const SegDesc& ts = e->ops[op.tail_op].d.seg[0];
+      const Buffer& tb = e->bufs[ts.dst_buf];
+      f.tail = 1;
+      f.dst2 = static_cast<half_t*>(tb.ptr) + ts.dst_coff;
+      f.dst2_ld = (int)tb.d.c;
+    }
     if (!c3k2_layout(&f)) return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: fused C3k2 block does not fit", i);
     if (!e->fuse) continue;
     unina_op_info& info = op.info;
     double flops = 0, wbytes = 0;
-    for (int k = (int)i; k <= op.group_last; ++k) {
+    const int last_op = op.tail_op >= 0 ? op.tail_op : op.group_last;
+    for (int k = (int)i; k <= last_op; ++k) {
       flops += e->ops[k].info.flops;
       wbytes += 2.0 * e->ops[k].info.n * e->ops[k].info.k + 4.0 * e->ops[k].info.n;
       if (k > (int)i) {
@@ -365,12 +374,13 @@ int plan(unina_engine* e) {
       }
     }
     info.flops = flops;
-    info.bytes = 2.0 * f.H * f.W * f.Cin + wbytes + 2.0 * f.H * f.W * 2 * f.hid;   // input once, weights once, output once
+    info.bytes = 2.0 * f.H * f.W * f.Cin + wbytes + 2.0 * f.H * f.W * 2 * f.hid +   // input once, weights once, output once
+                 (f.tail ? 2.0 * 4 * f.H * f.W * f.hid : 0.0);                        // (+ the up-sampled lateral output)
     info.n = 2 * f.hid;
     info.k = 0;
     info.grid = f.tiles_x * f.tiles_y;
-    info.block = c3k2_block_threads(f.hid, f.nb, f.Cin);
-    snprintf(info.kernel, sizeof info.kernel, "%s", c3k2_kernel_name(f.hid, f.nb, f.Cin));
+    info.block = c3k2_block_threads(f.hid, f.nb, f.Cin, f.tail);
+    snprintf(info.kernel, sizeof info.kernel, "%s", c3k2_kernel_name(f.hid, f.nb, f.Cin, f.tail));
     snprintf(info.name, sizeof info.name, "%.*s[c3k2 x%d]", (int)(strchr(a.name, '+') ? strchr(a.name, '+') - a.name - 4 : 60), a.name, f.nb);
   }
   e->plan_dirty = false;
@@ -420,6 +430,10 @@ void op_regions(const unina_engine* e, size_t i, std::vector<Region>* reads, std
     reads->push_back({(int)d.src_buf, (int)d.seg[0].src_coff, (int)(d.seg[0].src_coff + d.cin)});
     for (uint32_t s = 0; s < last.nseg; ++s)
       writes->push_back({(int)last.seg[s].dst_buf, (int)last.seg[s].dst_coff, (int)(last.seg[s].dst_coff + last.seg[s].n_count)});
+    if (e->ops[i].tail_op >= 0) {
+      const SegDesc& ts = e->ops[e->ops[i].tail_op].d.seg[0];
+      writes->push_back({(int)ts.dst_buf, (int)ts.dst_coff, (int)(ts.dst_coff + ts.n_count)});
+    }
     return;
   }
   if (d.kind == kOpSppfPool) {
@@ -569,6 +583,18 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     if (e->bufs[z.seg[0].dst_buf].d.dtype != kBufF16Nhwc || z.seg[0].dst_coff % 8 || e->bufs[z.seg[0].dst_buf].d.c % 8) continue;
     if (a.in_h != z.out_h || a.in_w != z.out_w) continue;
     if (!c3k2_supported((int)h, nb, (int)a.cin)) continue;
+    // an FPN block is followed by its lateral conv (model.py:256,259: ConvBlock 1x1, 2h -> h) whose store does the
+    // nearest x2 upsample: it becomes the block kernel's last step when that class exists
+    size_t jt = j;   // last op of the group incl. the tail
+    if (j + 1 < n) {
+      const OpDesc& t = e->ops[j + 1].d;
+      if (t.kind == kOpConv && t.ksize == 1 && t.stride == 1 && t.relu && t.nseg == 1 && t.res_buf < 0 && t.seg[0].flags == kSegUp2 &&
+          !t.seg[0].m_off && t.seg[0].n_pad == t.seg[0].n_count && t.cin == 2 * h && t.seg[0].n_count == h &&
+          t.src_buf == z.seg[0].dst_buf && t.seg[0].src_coff == z.seg[0].dst_coff &&
+          e->bufs[t.seg[0].dst_buf].d.dtype == kBufF16Nhwc && t.seg[0].dst_coff % 8 == 0 && e->bufs[t.seg[0].dst_buf].d.c % 8 == 0 &&
+          t.seg[0].dst_buf != z.seg[0].dst_buf && c3k2_supported((int)h, nb, (int)a.cin, 1))
+        jt = j + 1;
+    }
     // the group's intermediates must be private to it, and must not be its own input or output
     bool priv = true;
     for (uint32_t b : inter) {
@@ -584,7 +610,7 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     if (!priv) continue;
     // pack
     std::vector<C3k2Conv> convs;
-    for (size_t k = i; k <= j; ++k) {
+    for (size_t k = i; k <= jt; ++k) {
       const OpDesc& o = e->ops[k].d;
       C3k2Conv cv;
       memset(&cv, 0, sizeof cv);
@@ -598,7 +624,7 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     }
     std::vector<unsigned char> stream;
     std::vector<float> bias;
-    if (!c3k2_pack((int)h, nb, (int)a.cin, convs.data(), &stream, &bias)) continue;
+    if (!c3k2_pack((int)h, nb, (int)a.cin, jt > j ? 1 : 0, convs.data(), &stream, &bias)) continue;
     blob->resize((blob->size() + 255) & ~(size_t)255);
     const uint64_t so = blob->size();
     blob->insert(blob->end(), stream.begin(), stream.end());
@@ -613,9 +639,10 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     head.nb = nb;
     head.stream_off = so;
     head.fbias_off = bo;
-    for (size_t k = i + 1; k <= j; ++k) e->ops[k].fuse_role = 2;
+    head.tail_op = jt > j ? (int)jt : -1;
+    for (size_t k = i + 1; k <= jt; ++k) e->ops[k].fuse_role = 2;
     ++e->n_groups;
-    i = j;
+    i = jt;
   }
 }
 

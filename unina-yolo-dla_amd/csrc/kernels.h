@@ -94,11 +94,14 @@ struct C3k2Params {
   const float* bias;             // concatenated folded biases, same order
   const void* zeros;             // >= 16 bytes of zeros in HBM
   int hid, nb;                   // hidden width h = Cout/2, number of bottlenecks
+  int tail;                      // 1: the lateral 1x1 conv (2h -> h) + nearest x2 upsample that follows runs as a last step
+  half_t* dst2;                  // tail output (2H x 2W pixels), channel offset applied
+  int dst2_ld;
   // filled by c3k2_layout():
   int n_bias;
   int tiles_x, tiles_y;
   unsigned tiles_x_magic;
-  int off_bias, off_x, off_y, off_t, off_u1, off_u2, off_stage, smem_bytes;   // LDS layout (bytes)
+  int off_bias, off_x, off_y, off_t, off_u1, off_u2, off_stage, off_tail, smem_bytes;   // LDS layout (bytes)
 };
 struct C3k2Conv {                // one conv of the block as the exporter stored it (host pointers)
   const unsigned char* w[2];     // packed 1-KiB fragment blocks [n/16][K/32] per output slice (slice 1 only for cv1|cv2)
@@ -108,11 +111,11 @@ struct C3k2Conv {                // one conv of the block as the exporter stored
 };
 hipError_t c3k2_init();
 bool c3k2_layout(C3k2Params* p);
-bool c3k2_supported(int hid, int nb, int cin);
-bool c3k2_pack(int hid, int nb, int cin, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias);
+bool c3k2_supported(int hid, int nb, int cin, int tail = 0);
+bool c3k2_pack(int hid, int nb, int cin, int tail, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias);
 hipError_t c3k2_launch(const C3k2Params& p, hipStream_t stream);
-const char* c3k2_kernel_name(int hid, int nb, int cin);
-int c3k2_block_threads(int hid, int nb, int cin);
+const char* c3k2_kernel_name(int hid, int nb, int cin, int tail = 0);
+int c3k2_block_threads(int hid, int nb, int cin, int tail = 0);
 
 // Generic packer of the block kernels' weight stream: per conv, k-block-major [K/32][N/16] 1-KiB blocks (slice 0's
 // channel subtiles first), then the concatenated biases (n entries per slice).
