@@ -598,6 +598,7 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     // the group's intermediates must be private to it, and must not be its own input or output
     bool priv = true;
     for (uint32_t b : inter) {
+      if (e->bufs[b].d.dtype != kBufF16Nhwc) priv = false;   // (an INT8 engine's fp16 conv may still write an int8 buffer)
       if (b == a.src_buf || b == z.seg[0].dst_buf || (e->bufs[b].d.flags & (kBufInput | kBufOutput))) priv = false;
       for (size_t k = 0; k < n && priv; ++k) {
         if (k >= i && k <= j) continue;
@@ -673,6 +674,7 @@ void find_head_groups(unina_engine* e, std::vector<char>* blob) {
     if (!ok || e->bufs[a.src_buf].d.dtype != kBufF16Nhwc || !head_supported((int)C)) continue;
     if (a.in_h != c.out_h || a.in_w != c.out_w) continue;
     for (uint32_t hb : {h0, h1}) {
+      if (e->bufs[hb].d.dtype != kBufF16Nhwc) ok = false;
       if (hb == a.src_buf || (e->bufs[hb].d.flags & (kBufInput | kBufOutput))) ok = false;
       for (size_t k = 0; k < n && ok; ++k) {
         if (k >= i && k <= i + 2) continue;
@@ -964,7 +966,8 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   if (e->images_buf < 0) return bail(UNINA_ERR_FORMAT, "engine file lacks the images input buffer");
 
   // fusable C3k2 groups (fp16 engines): their packed weight streams are appended to the blob before upload
-  if (e->h.precision == kFp16) {
+  // (the matchers only accept all-fp16 groups: in an INT8 engine that is the carved-out P2 head, train.py:779)
+  if (e->h.precision == kFp16 || e->h.precision == kInt8) {
     find_c3k2_groups(e, &blob);
     find_head_groups(e, &blob);
     const char* fz = getenv("UNINA_FUSE");
@@ -1211,7 +1214,7 @@ int unina_debug_fusable_groups(const char* path) {
     for (uint32_t s = 0; s < o.d.nseg; ++s)
       if (o.d.seg[s].dst_buf >= e.h.n_buffers || o.d.seg[s].w_off > blob.size() || o.d.seg[s].b_off > blob.size()) return -UNINA_ERR_FORMAT;
   }
-  if (e.h.precision == kFp16) {
+  if (e.h.precision == kFp16 || e.h.precision == kInt8) {
     find_c3k2_groups(&e, &blob);
     find_head_groups(&e, &blob);
   }
