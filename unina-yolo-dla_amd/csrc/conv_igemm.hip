@@ -38,8 +38,7 @@ typedef float floatx4_t __attribute__((ext_vector_type(4)));
 // by-major tile order: every XCD then streams only its own N-tiles' weights through its L2 instead of all of them
 // (measured before the remap: 23 MB of fabric reads per P4 head conv for 4.8 MB of algorithmic bytes = the 2.4 MB
 // weight set fetched once per XCD). Bijective form of the CDNA guide's T1 remap; placement affects speed only.
-__device__ __forceinline__ void tile_of_block(const ConvParams& p, int* bx, int* by) {
-  const int nwg = gridDim.x, orig = blockIdx.x;
+__device__ __forceinline__ void tile_of_block(const ConvParams& p, int orig, int nwg, int* bx, int* by) {
   const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
   const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   *by = fast_div(v, p.gm_magic);
@@ -227,8 +226,10 @@ extern __shared__ __align__(16) unsigned char conv_smem[];
 
 // BK is counted in fragment blocks' worth of k: KSUB = BK/32 blocks per row-subtile per K-step, i.e. a K-step covers
 // KSUB*32 input channels in fp16 and KSUB*16 in fp32.
+// conv_glds_body: workgroup `bid` of `nwg` (a plain launch passes blockIdx.x / gridDim.x; conv_dual runs two convs'
+// workgroups side by side in one grid).
 template <typename T, int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
-__global__ __launch_bounds__(256) void conv_glds(const ConvParams p) {
+__device__ __forceinline__ void conv_glds_body(const ConvParams& p, int bid, int nwg) {
   static_assert(WAVES_M * WAVES_N == 4, "256-thread blocks");
   typedef Elem<T> E;
   typedef typename E::frag frag_t;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_glds(const ConvParams p) {
   const int l15 = lane & 15, lq = lane >> 4;
 
   int bx, by;
-  tile_of_block(p, &bx, &by);
+  tile_of_block(p, bid, nwg, &bx, &by);
   const int sidx = (p.nseg > 1 && by >= p.seg[1].tile0) ? 1 : 0;
   const ConvSeg& sg = p.seg[sidx];
   const int n_pad = (sg.n_count + 15) & ~15;
@@ -414,6 +415,11 @@ __global__ __launch_bounds__(256) void conv_glds(const ConvParams p) {
                                        [&](int pl) { const int m = m_blk + pl; return m < p.M ? m : -1; }, conv_smem);
 }
 
+template <typename T, int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(256) void conv_glds(const ConvParams p) {
+  conv_glds_body<T, BM, BN, BK, WAVES_M, WAVES_N, STAGES>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
 
 // ================================================================================================ 3x3 halo kernel
 // 3x3 / stride 1 / pad 1 convolution with the INPUT PATCH RESIDENT IN LDS. A workgroup owns a TH x TW tile of output
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
   const int l15 = lane & 15, lq = lane >> 4;
 
   int bx, by;
-  tile_of_block(p, &bx, &by);
+  tile_of_block(p, (int)blockIdx.x, (int)gridDim.x, &bx, &by);
   const int sidx = (p.nseg > 1 && by >= p.seg[1].tile0) ? 1 : 0;
   const ConvSeg& sg = p.seg[sidx];
   const int n_pad = (sg.n_count + 15) & ~15;
@@ -622,7 +628,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
 // fp16 only; Cin is a template parameter (the K loop is unrolled at compile time so queue slots are registers).
 // Same MFMA, same K order (tap-major, 32 channels per block), same epilogue as the other kernels: bit-identical.
 template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1>
-__global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
+__device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, int nwg) {
   typedef Elem<half_t> E;
   // S = stride (1 or 2): the patch is the (S*TH + 2 or S*TH + 1) x (...) input footprint of the tile
   constexpr int BM = TH * TW, R0W = S * (TW - 1) + 3, R0H = S * (TH - 1) + 3, NT = NW * 64, CB = CIN / 32, KB = 9 * CB;
@@ -634,7 +640,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
   const int wm = wid / NS, wn = wid % NS;
   const int l15 = lane & 15, lq = lane >> 4;
   int bx, by;
-  tile_of_block(p, &bx, &by);
+  tile_of_block(p, bid, nwg, &bx, &by);
   const int sidx = (p.nseg > 1 && by >= p.seg[1].tile0) ? 1 : 0;
   const ConvSeg& sg = p.seg[sidx];
   const int n_pad = (sg.n_count + 15) & ~15;
@@ -697,6 +703,28 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
                                            return (pl < BM && oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
                                          },
                                          conv_smem, NT);
+}
+
+template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1>
+__global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
+  conv3x3_regq_body<TH, TW, BN, CIN, NW, D, S>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ================================================================================================ dual launches
+// Two INDEPENDENT convs of the same kernel family in ONE grid: workgroups [0, na) run conv A, the rest conv B. The P3
+// and P4 head layers (model.py:361-365) are such pairs: each alone half-fills the chip (200 workgroups) and sits on the
+// ~11-14 us cold-weights + patch-wait + launch plateau; side by side they share one launch and fill
+// the CUs the other leaves idle. Same bodies, so results are bit-identical to the separate launches.
+// (launch bound 4 waves per SIMD = two 512-thread workgroups per CU: both convs' workgroups must be co-resident for the
+// side-by-side launch to overlap them -- with the 207 VGPRs of the stand-alone 8x16 body only one fits and the two halves
+// simply run one after the other; hence the shallower queue, D = 8)
+__global__ __launch_bounds__(512, 4) void conv_dual_head3x3(const ConvParams pa, const ConvParams pb, int na) {
+  if ((int)blockIdx.x < na) conv3x3_regq_body<8, 16, 64, 128, 8, 8, 1>(pa, (int)blockIdx.x, na);
+  else conv3x3_regq_body<8, 8, 64, 256, 8, 8, 1>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
+}
+__global__ __launch_bounds__(256) void conv_dual_head1x1(const ConvParams pa, const ConvParams pb, int na) {
+  if ((int)blockIdx.x < na) conv_glds_body<half_t, 128, 16, 64, 4, 1, 4>(pa, (int)blockIdx.x, na);
+  else conv_glds_body<half_t, 128, 16, 64, 4, 1, 4>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
 }
 
 // ---------------------------------------------------------------------------------------------- launch side
@@ -886,6 +914,10 @@ int n_tiles(const ConvParams& p, int bn) {
 }  // namespace
 
 hipError_t conv_init() {
+  for (const void* f : {reinterpret_cast<const void*>(conv_dual_head3x3), reinterpret_cast<const void*>(conv_dual_head1x1)}) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    if (e != hipSuccess) return e;
+  }
   for (int d = 0; d < 3; ++d)
     for (int c = 0; c < kCfgCount; ++c) {
       if (!kCfg[d][c].fn) continue;
@@ -955,9 +987,11 @@ ConvLaunch conv_plan(const ConvParams& p) {
   return conv_plan_with(p, cfg);
 }
 
-hipError_t conv_launch(const ConvParams& pin, const ConvLaunch& l, hipStream_t stream) {
-  ConvParams p = pin;
-  const CfgInfo& c = kCfg[p.dtype][l.cfg];
+namespace {
+// launch-time fields of a ConvParams for configuration `cfg` (tile counts, division magics, slice -> tile ranges)
+dim3 conv_prepare(ConvParams& p, int cfg) {
+  const CfgInfo& c = kCfg[p.dtype][cfg];
+  const ConvLaunch l = conv_plan_with(p, cfg);
   p.grid_m = (int)l.grid.x;
   p.gm_magic = div_magic(l.grid.x);
   p.wo_magic = div_magic((unsigned)p.Wo);
@@ -968,7 +1002,54 @@ hipError_t conv_launch(const ConvParams& pin, const ConvLaunch& l, hipStream_t s
     p.seg[s].tile0 = t;
     t += (((p.seg[s].n_count + 15) & ~15) + c.bn - 1) / c.bn;
   }
-  hipLaunchKernelGGL(c.fn, dim3(l.grid.x * l.grid.y, 1, 1), l.block, smem_for(p, c), stream, p);  // 1-D: see tile_of_block
+  return l.grid;
+}
+}  // namespace
+
+hipError_t conv_launch(const ConvParams& pin, const ConvLaunch& l, hipStream_t stream) {
+  ConvParams p = pin;
+  const CfgInfo& c = kCfg[p.dtype][l.cfg];
+  const dim3 g = conv_prepare(p, l.cfg);
+  hipLaunchKernelGGL(c.fn, dim3(g.x * g.y, 1, 1), l.block, smem_for(p, c), stream, p);  // 1-D: see tile_of_block
+  return hipGetLastError();
+}
+
+// ---- dual launches (conv_dual_head3x3 / conv_dual_head1x1) ----
+namespace {
+struct DualKind {
+  int cfg_a, cfg_b, threads;
+  const char* name;
+  void (*fn)(const ConvParams, const ConvParams, int);
+};
+const DualKind kDual[] = {
+    {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual<regq 8x16,64,128 | regq 8x8,64,256>", conv_dual_head3x3},
+    {kCfg128x16k64, kCfg128x16k64, 256, "conv_dual<glds 128,16,64 x2>", conv_dual_head1x1},
+};
+}  // namespace
+
+int conv_dual_match(const ConvParams& a, const ConvParams& b) {
+  if (a.dtype != kF16 || b.dtype != kF16 || a.stamps || b.stamps) return -1;
+  if (a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[0].cfg_a) && conv_config_valid(b, kDual[0].cfg_b)) return 0;
+  auto tiny = [](const ConvParams& p) {
+    for (int s = 0; s < p.nseg; ++s)
+      if (p.seg[s].n_count > 16) return false;
+    return p.ksize == 1 && p.stride == 1;
+  };
+  if (tiny(a) && tiny(b) && a.Cin != b.Cin && conv_config_valid(a, kDual[1].cfg_a) && conv_config_valid(b, kDual[1].cfg_b)) return 1;
+  return -1;
+}
+
+const char* conv_dual_name(int kind) { return kind >= 0 && kind < 2 ? kDual[kind].name : "?"; }
+
+hipError_t conv_dual_launch(int kind, const ConvParams& pa_in, const ConvParams& pb_in, hipStream_t stream, int* grid_out) {
+  if (kind < 0 || kind >= 2) return hipErrorInvalidValue;
+  const DualKind& k = kDual[kind];
+  ConvParams pa = pa_in, pb = pb_in;
+  const dim3 ga = conv_prepare(pa, k.cfg_a), gb = conv_prepare(pb, k.cfg_b);
+  const int na = (int)(ga.x * ga.y), nb = (int)(gb.x * gb.y);
+  const size_t sa = smem_for(pa, kCfg[kF16][k.cfg_a]), sb = smem_for(pb, kCfg[kF16][k.cfg_b]);
+  if (grid_out) *grid_out = na + nb;
+  hipLaunchKernelGGL(k.fn, dim3(na + nb, 1, 1), dim3(k.threads, 1, 1), max_sz(sa, sb), stream, pa, pb, na);
   return hipGetLastError();
 }
 

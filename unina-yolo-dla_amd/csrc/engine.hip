@@ -45,6 +45,9 @@ struct PlannedOp {
   int fuse_kind = 0;        // role 1: 1 = C3k2 block (c3k2_fused.hip), 2 = DetectionHead (head_fused.hip)
   HeadParams hp;
   int group_last = -1;      // role 1: index of the group's last op (cv3 / the head's output convs)
+  int dual_with = -1;       // >= 0: this conv and conv `dual_with` (independent, same kernel family) run as ONE grid
+  int dual_kind = -1;
+  bool dual_absorbed = false;   // runs inside an earlier op's dual launch
   int tail_op = -1;         // role 1, C3k2: index of the lateral 1x1 (+ x2 upsample) that runs as the block kernel's last step
   int hid = 0, nb = 0;      // role 1: hidden width, bottleneck count
   uint64_t stream_off = 0, fbias_off = 0;   // role 1: blob offsets of the packed stage stream / concatenated biases
@@ -151,6 +154,55 @@ void drop_graph(unina_engine* e) {
 }
 
 int engine_dtype(const unina_engine* e) { return e->h.precision == kFp32 ? kF32 : kF16; }
+
+// ---- dependency analysis over the op table (buffer id + channel range granularity) ----
+struct Region {
+  int buf, c0, c1;
+};
+bool overlaps(const Region& a, const Region& b) { return a.buf == b.buf && a.c0 < b.c1 && b.c0 < a.c1; }
+
+void op_regions(const unina_engine* e, size_t i, std::vector<Region>* reads, std::vector<Region>* writes) {
+  const OpDesc& d = e->ops[i].d;
+  reads->clear();
+  writes->clear();
+  if (e->fuse && e->ops[i].fuse_role == 2) return;
+  if (e->ops[i].dual_absorbed) return;
+  if (e->ops[i].dual_with >= 0) {   // the pair's reads / writes, at the leader's position
+    const int pair[2] = {(int)i, e->ops[i].dual_with};
+    for (int k : pair) {
+      const OpDesc& dk = e->ops[k].d;
+      for (uint32_t s = 0; s < dk.nseg; ++s) {
+        reads->push_back({(int)dk.src_buf, (int)dk.seg[s].src_coff, (int)(dk.seg[s].src_coff + dk.cin)});
+        writes->push_back({(int)dk.seg[s].dst_buf, (int)dk.seg[s].dst_coff, (int)(dk.seg[s].dst_coff + dk.seg[s].n_count)});
+      }
+    }
+    return;
+  }
+  if (e->fuse && e->ops[i].fuse_role == 1) {
+    const OpDesc& last = e->ops[e->ops[i].group_last].d;
+    reads->push_back({(int)d.src_buf, (int)d.seg[0].src_coff, (int)(d.seg[0].src_coff + d.cin)});
+    for (uint32_t s = 0; s < last.nseg; ++s)
+      writes->push_back({(int)last.seg[s].dst_buf, (int)last.seg[s].dst_coff, (int)(last.seg[s].dst_coff + last.seg[s].n_count)});
+    if (e->ops[i].tail_op >= 0) {
+      const SegDesc& ts = e->ops[e->ops[i].tail_op].d.seg[0];
+      writes->push_back({(int)ts.dst_buf, (int)ts.dst_coff, (int)(ts.dst_coff + ts.n_count)});
+    }
+    return;
+  }
+  if (d.kind == kOpSppfPool) {
+    const int c0 = (int)d.seg[0].src_coff, C = (int)d.cin;
+    reads->push_back({(int)d.src_buf, c0, c0 + C});
+    writes->push_back({(int)d.src_buf, c0 + C, c0 + 4 * C});
+    return;
+  }
+  for (uint32_t s = 0; s < d.nseg; ++s) {
+    const SegDesc& sd = d.seg[s];
+    const int cin = d.kind == kOpStem ? 3 : (int)d.cin;
+    reads->push_back({(int)d.src_buf, (int)sd.src_coff, (int)sd.src_coff + cin});
+    writes->push_back({(int)sd.dst_buf, (int)sd.dst_coff, (int)(sd.dst_coff + sd.n_count)});
+    if (d.res_buf >= 0) reads->push_back({d.res_buf, d.res_coff, d.res_coff + (int)sd.n_count});
+  }
+}
 
 // (Re)computes kernel parameters from the current buffer addresses. Element types are properties of the BUFFERS
 // (fp16 / fp32 / int8 NHWC): a conv runs in the type of its source buffer and converts to the type of each
@@ -383,6 +435,52 @@ int plan(unina_engine* e) {
     snprintf(info.kernel, sizeof info.kernel, "%s", c3k2_kernel_name(f.hid, f.nb, f.Cin, f.tail));
     snprintf(info.name, sizeof info.name, "%.*s[c3k2 x%d]", (int)(strchr(a.name, '+') ? strchr(a.name, '+') - a.name - 4 : 60), a.name, f.nb);
   }
+  // dual launches: pair independent convs of one kernel family (the P3 / P4 head layers) into one grid each. The later
+  // op moves to the earlier one's position, so nothing between them may feed it or touch what it writes.
+  for (auto& op : e->ops) {
+    op.dual_with = op.dual_kind = -1;
+    op.dual_absorbed = false;
+  }
+  if (e->fuse && !getenv("UNINA_NO_DUAL")) {
+    const size_t n = e->ops.size();
+    std::vector<Region> ri, wi, rj, wj;
+    for (size_t i = 0; i < n; ++i) {
+      PlannedOp& a = e->ops[i];
+      if (a.d.kind != kOpConv || a.fuse_role || a.dual_absorbed || a.dual_with >= 0 || a.cp.force_cfg >= 0) continue;
+      for (size_t j = i + 1; j < n; ++j) {
+        PlannedOp& b = e->ops[j];
+        if (b.d.kind != kOpConv || b.fuse_role || b.dual_absorbed || b.dual_with >= 0 || b.cp.force_cfg >= 0) continue;
+        const int kind = conv_dual_match(a.cp, b.cp);
+        if (kind < 0) continue;
+        op_regions(e, j, &rj, &wj);
+        bool legal = true;
+        for (size_t k = i; k < j && legal; ++k) {
+          op_regions(e, k, &ri, &wi);
+          for (const Region& w : wi) {
+            for (const Region& r : rj) legal = legal && !overlaps(w, r);
+            for (const Region& w2 : wj) legal = legal && !overlaps(w, w2);
+          }
+          for (const Region& r : ri)
+            for (const Region& w2 : wj) legal = legal && !overlaps(r, w2);
+        }
+        if (!legal) continue;
+        a.dual_with = (int)j;
+        a.dual_kind = kind;
+        b.dual_absorbed = true;
+        int grid = 0;
+        (void)grid;
+        a.info.flops += b.info.flops;
+        a.info.bytes += b.info.bytes;
+        a.info.grid += b.info.grid;
+        snprintf(a.info.kernel, sizeof a.info.kernel, "%s", conv_dual_name(kind));
+        b.info.flops = 0;
+        b.info.bytes = 0;
+        b.info.grid = 0;
+        snprintf(b.info.kernel, sizeof b.info.kernel, "(dual launch with op %zu)", i);
+        break;
+      }
+    }
+  }
   e->plan_dirty = false;
   drop_graph(e);
   return UNINA_OK;
@@ -391,6 +489,8 @@ int plan(unina_engine* e) {
 hipError_t launch_op(unina_engine* e, size_t i, hipStream_t s) {
   PlannedOp& op = e->ops[i];
   if (e->fuse && op.fuse_role == 1) return op.fuse_kind == 2 ? head_launch(op.hp, s) : c3k2_launch(op.fp, s);
+  if (op.dual_absorbed) return hipSuccess;
+  if (op.dual_with >= 0) return conv_dual_launch(op.dual_kind, op.cp, e->ops[op.dual_with].cp, s);
   if (e->fuse && op.fuse_role == 2) return hipSuccess;   // runs inside its group's launch
   switch (op.d.kind) {
     case kOpConv: return conv_launch(op.cp, op.cl, s);
@@ -412,43 +512,6 @@ int launch_all(unina_engine* e, hipStream_t s, int which = 0 /*0 all, 1 eager on
     if (err != hipSuccess) return fail(e, UNINA_ERR_HIP, "op %zu (%s): %s", i, e->ops[i].d.name, hipGetErrorString(err));
   }
   return UNINA_OK;
-}
-
-// ---- dependency analysis over the op table (buffer id + channel range granularity) ----
-struct Region {
-  int buf, c0, c1;
-};
-bool overlaps(const Region& a, const Region& b) { return a.buf == b.buf && a.c0 < b.c1 && b.c0 < a.c1; }
-
-void op_regions(const unina_engine* e, size_t i, std::vector<Region>* reads, std::vector<Region>* writes) {
-  const OpDesc& d = e->ops[i].d;
-  reads->clear();
-  writes->clear();
-  if (e->fuse && e->ops[i].fuse_role == 2) return;
-  if (e->fuse && e->ops[i].fuse_role == 1) {
-    const OpDesc& last = e->ops[e->ops[i].group_last].d;
-    reads->push_back({(int)d.src_buf, (int)d.seg[0].src_coff, (int)(d.seg[0].src_coff + d.cin)});
-    for (uint32_t s = 0; s < last.nseg; ++s)
-      writes->push_back({(int)last.seg[s].dst_buf, (int)last.seg[s].dst_coff, (int)(last.seg[s].dst_coff + last.seg[s].n_count)});
-    if (e->ops[i].tail_op >= 0) {
-      const SegDesc& ts = e->ops[e->ops[i].tail_op].d.seg[0];
-      writes->push_back({(int)ts.dst_buf, (int)ts.dst_coff, (int)(ts.dst_coff + ts.n_count)});
-    }
-    return;
-  }
-  if (d.kind == kOpSppfPool) {
-    const int c0 = (int)d.seg[0].src_coff, C = (int)d.cin;
-    reads->push_back({(int)d.src_buf, c0, c0 + C});
-    writes->push_back({(int)d.src_buf, c0 + C, c0 + 4 * C});
-    return;
-  }
-  for (uint32_t s = 0; s < d.nseg; ++s) {
-    const SegDesc& sd = d.seg[s];
-    const int cin = d.kind == kOpStem ? 3 : (int)d.cin;
-    reads->push_back({(int)d.src_buf, (int)sd.src_coff, (int)sd.src_coff + cin});
-    writes->push_back({(int)sd.dst_buf, (int)sd.dst_coff, (int)(sd.dst_coff + sd.n_count)});
-    if (d.res_buf >= 0) reads->push_back({d.res_buf, d.res_coff, d.res_coff + (int)sd.n_count});
-  }
 }
 
 // preds[j] = ops i < j that j must wait for (RAW, WAR, WAW), transitively reduced only trivially
@@ -1269,7 +1332,7 @@ int unina_autotune(unina_engine_t* e, int iters, hipStream_t stream) {
   HIPCHK(e, hipEventCreate(&a));
   HIPCHK(e, hipEventCreate(&b));
   for (size_t i = 0; i < e->ops.size(); ++i) {
-    if (e->ops[i].d.kind != kOpConv || (e->fuse && e->ops[i].fuse_role)) continue;
+    if (e->ops[i].d.kind != kOpConv || (e->fuse && e->ops[i].fuse_role) || e->ops[i].dual_with >= 0 || e->ops[i].dual_absorbed) continue;
     float best = 1e30f;
     int best_cfg = -1;
     for (int cfg = 0; cfg < (int)kCfgCount; ++cfg) {
@@ -1305,7 +1368,7 @@ int unina_profile_ops(unina_engine_t* e, int iters, float* ms_per_op, hipStream_
   HIPCHK(e, hipEventCreate(&a));
   HIPCHK(e, hipEventCreate(&b));
   for (size_t i = 0; i < e->ops.size(); ++i) {
-    if (e->fuse && e->ops[i].fuse_role == 2) {
+    if ((e->fuse && e->ops[i].fuse_role == 2) || e->ops[i].dual_absorbed) {
       ms_per_op[i] = 0.f;
       continue;
     }

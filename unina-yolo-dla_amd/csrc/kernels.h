@@ -79,6 +79,10 @@ ConvLaunch conv_plan(const ConvParams& p);               // heuristic (or p.forc
 ConvLaunch conv_plan_with(const ConvParams& p, int cfg);
 const char* conv_config_name(int cfg, int dtype = kF16);
 hipError_t conv_launch(const ConvParams& p, const ConvLaunch& l, hipStream_t stream);
+// Two independent convs of one kernel family as ONE grid (conv_igemm.hip, dual launches): kind >= 0 if the pair fits.
+int conv_dual_match(const ConvParams& a, const ConvParams& b);
+const char* conv_dual_name(int kind);
+hipError_t conv_dual_launch(int kind, const ConvParams& a, const ConvParams& b, hipStream_t stream, int* grid_out = nullptr);
 
 // ------------------------------------------------------------------------------------------------
 // Fused C3k2 block (model.py:76-110): cv1|cv2 -> n x Bottleneck(1x1, 3x3 + shortcut) -> cv3 in ONE launch, all
