@@ -391,8 +391,10 @@ def test_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
         x = _frame(pkg, torch_cuda, 1234, size)
         fused = {k: v.copy() for k, v in e.forward(x).items()}
         fused_bufs = {b: e.read_buffer(b) for b in BLOCK_OUTPUTS}
-        assert sum("c3k2_fused" in o["kernel"] for o in e.op_infos()) == 7
-        assert sum("head_fused" in o["kernel"] for o in e.op_infos()) == 1
+        kernels = [o["kernel"] for o in e.op_infos()]
+        assert sum("c3k2_fused" in k or "block_dual" in k for k in kernels) == 7    # (one block may share its grid with the head)
+        assert sum("head_fused" in k or "block_dual" in k for k in kernels) == 1
+        assert sum("conv_dual" in k for k in kernels) == 3                           # P3 | P4 head layers pairwise
         assert e.set_fusion(False) == 0
         plain = e.forward(x)
         for b in BLOCK_OUTPUTS:

@@ -22,6 +22,7 @@ UNITS = {
     "conv_igemm.hip": [],
     "c3k2_fused.hip": [],
     "head_fused.hip": [],
+    "block_dual.hip": [],
     "stem_pool.hip": [],
     "postprocess.hip": ["-ffp-contract=off"],   # box arithmetic must round like the reference's scalar code
     "preprocess.hip": ["-ffp-contract=off"],    # normalisation arithmetic rounds as written (oracle/preprocess_oracle.c)

@@ -1,0 +1,42 @@
+// block_dual.hip -- two INDEPENDENT block kernels side by side in one grid (same idea as conv_igemm.hip's dual launches).
+//
+// After the FPN the graph forks (model.py:262-269, 361-365): the P2 head needs only p2_fused, while the PAN path
+// down1 -> pan_c3k2_1 -> down2 -> pan_c3k2_2 leads to the P3 / P4 heads. head_fused (200 workgroups at 640^2, MFMA-heavy)
+// and c3k2_fused<128, ..., 384> = pan_c3k2_2 (100 workgroups, bound by its per-CU weight stream) are independent and
+// complementary: the block kernel's workgroups take the first block ids (it is on the critical path), the head's
+// follow; both bodies are the stand-alone kernels' (block_kernels.h), so results are bit-identical. Bounded to 4 waves
+// per SIMD so that two 512-thread workgroups share a CU.
+#include "block_kernels.h"
+
+namespace unina {
+
+using namespace dev;
+
+extern __shared__ __align__(16) unsigned char bd_smem[];
+
+__global__ __launch_bounds__(512, 4) void block_dual_c3k2_128x384_head64(const C3k2Params pc, const HeadParams ph, int nc) {
+  if ((int)blockIdx.x < nc) c3k2_fused_body<128, 4, 4, 1, 384, 8, 8, 0>(pc, (int)blockIdx.x, bd_smem);
+  else head_fused_body<64, 8, 16, 8, 4>(ph, (int)blockIdx.x - nc, bd_smem);
+}
+
+hipError_t block_dual_init() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(block_dual_c3k2_128x384_head64),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+bool block_dual_match(const C3k2Params& pc, const HeadParams& ph) {
+  return pc.hid == 128 && pc.nb == 1 && pc.Cin == 384 && pc.tail == 0 && ph.C == 64 &&
+         c3k2_tile_is(pc, 4, 4) && head_tile_is(ph, 8, 16);
+}
+
+const char* block_dual_name() { return "block_dual<c3k2 128,4x4,1,384 | head 64,8x16>"; }
+
+hipError_t block_dual_launch(const C3k2Params& pc, const HeadParams& ph, hipStream_t stream, int* grid_out) {
+  const int nc = pc.tiles_x * pc.tiles_y, nh = ph.tiles_x * ph.tiles_y;
+  const int smem = pc.smem_bytes > ph.smem_bytes ? pc.smem_bytes : ph.smem_bytes;
+  if (grid_out) *grid_out = nc + nh;
+  hipLaunchKernelGGL(block_dual_c3k2_128x384_head64, dim3(nc + nh, 1, 1), dim3(512, 1, 1), smem, stream, pc, ph, nc);
+  return hipGetLastError();
+}
+
+}  // namespace unina

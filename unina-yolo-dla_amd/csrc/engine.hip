@@ -167,7 +167,7 @@ void op_regions(const unina_engine* e, size_t i, std::vector<Region>* reads, std
   writes->clear();
   if (e->fuse && e->ops[i].fuse_role == 2) return;
   if (e->ops[i].dual_absorbed) return;
-  if (e->ops[i].dual_with >= 0) {   // the pair's reads / writes, at the leader's position
+  if (e->ops[i].dual_with >= 0 && !e->ops[i].fuse_role) {   // the pair's reads / writes, at the leader's position
     const int pair[2] = {(int)i, e->ops[i].dual_with};
     for (int k : pair) {
       const OpDesc& dk = e->ops[k].d;
@@ -186,6 +186,13 @@ void op_regions(const unina_engine* e, size_t i, std::vector<Region>* reads, std
     if (e->ops[i].tail_op >= 0) {
       const SegDesc& ts = e->ops[e->ops[i].tail_op].d.seg[0];
       writes->push_back({(int)ts.dst_buf, (int)ts.dst_coff, (int)(ts.dst_coff + ts.n_count)});
+    }
+    if (e->ops[i].dual_with >= 0) {   // block dual: the partner group's reads / writes happen here too
+      const PlannedOp& hb = e->ops[e->ops[i].dual_with];
+      const OpDesc& hl = e->ops[hb.group_last].d;
+      reads->push_back({(int)hb.d.src_buf, (int)hb.d.seg[0].src_coff, (int)(hb.d.seg[0].src_coff + hb.d.cin)});
+      for (uint32_t s = 0; s < hl.nseg; ++s)
+        writes->push_back({(int)hl.seg[s].dst_buf, (int)hl.seg[s].dst_coff, (int)(hl.seg[s].dst_coff + hl.seg[s].n_count)});
     }
     return;
   }
@@ -444,6 +451,38 @@ int plan(unina_engine* e) {
   if (e->fuse && !getenv("UNINA_NO_DUAL")) {
     const size_t n = e->ops.size();
     std::vector<Region> ri, wi, rj, wj;
+    // a fused C3k2 block and the fused head that does not depend on it (pan_c3k2_2 and head_p2): block_dual.hip
+    for (size_t i = 0; i < n; ++i) {
+      PlannedOp& a = e->ops[i];
+      if (a.fuse_role != 1 || a.fuse_kind != 1 || a.dual_with >= 0) continue;
+      for (size_t j = i + 1; j < n; ++j) {
+        PlannedOp& b = e->ops[j];
+        if (b.fuse_role != 1 || b.fuse_kind != 2 || b.dual_absorbed || !block_dual_match(a.fp, b.hp)) continue;
+        op_regions(e, j, &rj, &wj);
+        bool legal = true;
+        for (size_t k = i; k < j && legal; ++k) {
+          op_regions(e, k, &ri, &wi);
+          for (const Region& w : wi) {
+            for (const Region& r : rj) legal = legal && !overlaps(w, r);
+            for (const Region& w2 : wj) legal = legal && !overlaps(w, w2);
+          }
+          for (const Region& r : ri)
+            for (const Region& w2 : wj) legal = legal && !overlaps(r, w2);
+        }
+        if (!legal) continue;
+        a.dual_with = (int)j;
+        b.dual_absorbed = true;
+        a.info.flops += b.info.flops;
+        a.info.bytes += b.info.bytes;
+        a.info.grid += b.info.grid;
+        snprintf(a.info.kernel, sizeof a.info.kernel, "%s", block_dual_name());
+        b.info.flops = 0;
+        b.info.bytes = 0;
+        b.info.grid = 0;
+        snprintf(b.info.kernel, sizeof b.info.kernel, "(dual launch with op %zu)", i);
+        break;
+      }
+    }
     for (size_t i = 0; i < n; ++i) {
       PlannedOp& a = e->ops[i];
       if (a.d.kind != kOpConv || a.fuse_role || a.dual_absorbed || a.dual_with >= 0 || a.cp.force_cfg >= 0) continue;
@@ -488,8 +527,9 @@ int plan(unina_engine* e) {
 
 hipError_t launch_op(unina_engine* e, size_t i, hipStream_t s) {
   PlannedOp& op = e->ops[i];
-  if (e->fuse && op.fuse_role == 1) return op.fuse_kind == 2 ? head_launch(op.hp, s) : c3k2_launch(op.fp, s);
   if (op.dual_absorbed) return hipSuccess;
+  if (e->fuse && op.fuse_role == 1 && op.dual_with >= 0) return block_dual_launch(op.fp, e->ops[op.dual_with].hp, s);
+  if (e->fuse && op.fuse_role == 1) return op.fuse_kind == 2 ? head_launch(op.hp, s) : c3k2_launch(op.fp, s);
   if (op.dual_with >= 0) return conv_dual_launch(op.dual_kind, op.cp, e->ops[op.dual_with].cp, s);
   if (e->fuse && op.fuse_role == 2) return hipSuccess;   // runs inside its group's launch
   switch (op.d.kind) {
@@ -1054,6 +1094,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   LOADCHK(conv_init());
   LOADCHK(c3k2_init());
   LOADCHK(head_init());
+  LOADCHK(block_dual_init());
   LOADCHK(hipMalloc(&e->d_zeros, 256));
   LOADCHK(hipMemset(e->d_zeros, 0, 256));
   LOADCHK(hipMalloc(&e->d_arena, arena ? arena : 256));

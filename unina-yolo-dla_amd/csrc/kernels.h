@@ -152,6 +152,14 @@ hipError_t head_launch(const HeadParams& p, hipStream_t stream);
 const char* head_kernel_name(int c);
 int head_block_threads(int c);
 
+// A fused C3k2 block and a fused head that do not depend on each other, side by side in one grid (block_dual.hip).
+hipError_t block_dual_init();
+bool block_dual_match(const C3k2Params& pc, const HeadParams& ph);
+const char* block_dual_name();
+hipError_t block_dual_launch(const C3k2Params& pc, const HeadParams& ph, hipStream_t stream, int* grid_out = nullptr);
+bool c3k2_tile_is(const C3k2Params& p, int th, int tw);    // the tile the layout of `p` was computed for
+bool head_tile_is(const HeadParams& p, int th, int tw);
+
 // ------------------------------------------------------------------------------------------------
 // Stem: fp32 NCHW image -> 3x3/s2 conv (Cin=3) + bias + ReLU -> NHWC fp16
 // ------------------------------------------------------------------------------------------------
