@@ -229,7 +229,7 @@ def pmc_traffic(kernel: str):
     fn, nums = _kernel_key(kernel)
     for k, v in table.items():
         kfn, knums = _kernel_key(k)
-        if kfn.startswith(fn) and nums and knums[:len(nums)] == nums:
+        if (kfn.startswith(fn) and nums and knums[:len(nums)] == nums) or (kfn == fn and not knums):
             return v.get("hbm_bytes_per_launch")
     return None
 

@@ -394,7 +394,7 @@ def test_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
         kernels = [o["kernel"] for o in e.op_infos()]
         assert sum("c3k2_fused" in k or "block_dual" in k for k in kernels) == 7    # (one block may share its grid with the head)
         assert sum("head_fused" in k or "block_dual" in k for k in kernels) == 1
-        assert sum("conv_dual" in k for k in kernels) == 3                           # P3 | P4 head layers pairwise
+        assert sum(k.startswith("conv_dual") for k in kernels) == 3                           # P3 | P4 head layers pairwise
         assert e.set_fusion(False) == 0
         plain = e.forward(x)
         for b in BLOCK_OUTPUTS:
@@ -435,6 +435,26 @@ def test_frame_graph_and_tiled_nms_match_the_plain_forms(pkg, sd7, torch_cuda, m
     assert groups == 0
     assert fast == plain
     assert len(fast[3]) > len(fast[0]) and fast[0] == fast[4] and fast[0] != fast[1]
+
+
+def test_opt_in_stem_fusion_is_bit_identical(pkg, sd7, torch_cuda, monkeypatch):
+    """UNINA_STEM_FUSE=1: backbone.stem computed inside stage1_conv's launch (same fp32 fma chain into the LDS patch)."""
+    from unina_yolo_dla_amd.engine import Engine
+    x = _frame(pkg, torch_cuda, 1234, 640)
+
+    def run():
+        e = Engine.from_state_dict(sd7)
+        try:
+            return e.infer(x).tobytes(), e.forward(x), e.L.unina_fusion_groups(e.h)
+        finally:
+            e.close()
+
+    d0, h0, g0 = run()
+    monkeypatch.setenv("UNINA_STEM_FUSE", "1")
+    d1, h1, g1 = run()
+    assert (g0, g1) == (8, 9) and d0 == d1
+    for k in h0:
+        assert np.array_equal(h0[k], h1[k]), k
 
 
 def test_async_result_layout(pkg, eng640, torch_cuda):

@@ -29,7 +29,7 @@ bool block_dual_match(const C3k2Params& pc, const HeadParams& ph) {
          c3k2_tile_is(pc, 4, 4) && head_tile_is(ph, 8, 16);
 }
 
-const char* block_dual_name() { return "block_dual<c3k2 128,4x4,1,384 | head 64,8x16>"; }
+const char* block_dual_name() { return "block_dual_c3k2_128x384_head64<c3k2 128,4x4,1,384 | head 64,8x16>"; }
 
 hipError_t block_dual_launch(const C3k2Params& pc, const HeadParams& ph, hipStream_t stream, int* grid_out) {
   const int nc = pc.tiles_x * pc.tiles_y, nh = ph.tiles_x * ph.tiles_y;

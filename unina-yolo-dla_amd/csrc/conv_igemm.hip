@@ -41,8 +41,13 @@ typedef float floatx4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void tile_of_block(const ConvParams& p, int orig, int nwg, int* bx, int* by) {
   const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
   const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  *by = fast_div(v, p.gm_magic);
-  *bx = v - *by * p.grid_m;
+  if (p.xcd_m_major) {   // an XCD owns a contiguous range of PIXEL tiles (all channel tiles): its L2 holds its share of the input
+    *bx = fast_div(v, p.gn_magic);
+    *by = v - *bx * p.grid_n;
+  } else {               // ... of CHANNEL tiles (all pixel tiles): its L2 holds its share of the weights
+    *by = fast_div(v, p.gm_magic);
+    *bx = v - *by * p.grid_m;
+  }
 }
 
 __device__ __forceinline__ void stamp_entry(const ConvParams& p, long long t) {
@@ -627,8 +632,72 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
 // the weight-heavy head layers at 80^2 / 40^2 (590 KB / 2.4 MB of weights per launch) are bound by exactly that.
 // fp16 only; Cin is a template parameter (the K loop is unrolled at compile time so queue slots are registers).
 // Same MFMA, same K order (tap-major, 32 channels per block), same epilogue as the other kernels: bit-identical.
-template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1>
-__device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, int nwg) {
+// The fp32 stem (model.py:175: ConvBlock(3, c1, 3, stride 2) on the NCHW frame) computed straight into the patch image:
+// every patch pixel that lies inside the stem's output is the same sequential fma chain (k = 0..26 from the bias) as
+// stem_conv_kernel, two threads per pixel (half of the CO channels each, v_pk_fma_f32), ReLU, fp16 -- what the stem would
+// have stored to HBM; pixels outside are the conv's zero padding. `img` = LDS patch image of CO channels per pixel.
+template <int RH, int RW, int CO, int NT>
+__device__ __forceinline__ void stem_patch(unsigned char* smem, unsigned char* wlds, const StemParams& sp, int y0, int x0) {
+  typedef float floatx2 __attribute__((ext_vector_type(2)));
+  constexpr int CH = CO / 2;
+  constexpr Img X = make_img(0, CO / 8);
+  float* sw = reinterpret_cast<float*>(wlds);   // [27][CO] then [CO] biases
+  float* sb = sw + 27 * CO;
+  for (int i = threadIdx.x; i < CO * 27; i += NT) sw[(i % 27) * CO + (i / 27)] = sp.w[i];
+  for (int i = threadIdx.x; i < CO; i += NT) sb[i] = sp.bias[i];
+  __syncthreads();
+  const size_t plane = (size_t)sp.H * sp.W;
+  for (int g = threadIdx.x; g < 2 * RH * RW; g += NT) {
+    const int r = g >> 1, c0 = (g & 1) * CH;
+    const int ry = r / RW, rx = r - ry * RW;
+    const int oy = y0 + ry, ox = x0 + rx;        // stem-output coordinates of this patch pixel
+    floatx2 acc[CH / 2];
+    const bool inside = (unsigned)oy < (unsigned)sp.Ho && (unsigned)ox < (unsigned)sp.Wo;
+    if (inside) {
+      float x[27];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int iy = oy * 2 + kh - 1;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int ix = ox * 2 + kw - 1;
+            const bool ok = iy >= 0 && iy < sp.H && ix >= 0 && ix < sp.W;
+            x[(c * 3 + kh) * 3 + kw] = ok ? sp.src[c * plane + (size_t)iy * sp.W + ix] : 0.f;
+          }
+        }
+#pragma unroll
+      for (int q = 0; q < CH / 2; ++q) acc[q] = *reinterpret_cast<const floatx2*>(&sb[c0 + 2 * q]);
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        const floatx2 xk = {x[k], x[k]};
+#pragma unroll
+        for (int q = 0; q < CH / 2; q += 2) {
+          const float4 w4 = *reinterpret_cast<const float4*>(&sw[k * CO + c0 + 2 * q]);
+          acc[q] = __builtin_elementwise_fma(xk, floatx2{w4.x, w4.y}, acc[q]);
+          acc[q + 1] = __builtin_elementwise_fma(xk, floatx2{w4.z, w4.w}, acc[q + 1]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < CH / 2; ++q) acc[q] = floatx2{0.f, 0.f};
+    }
+#pragma unroll
+    for (int ch = 0; ch < CH / 8; ++ch) {
+      half8 hv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = acc[(ch * 8 + e) >> 1][(ch * 8 + e) & 1];
+        hv[e] = (half_t)(a > 0.f ? a : 0.f);
+      }
+      *reinterpret_cast<half8*>(smem + X.addr(r, c0 / 8 + ch)) = hv;
+    }
+  }
+}
+
+template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, bool STEM = false>
+__device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, int nwg, const StemParams* sp = nullptr) {
   typedef Elem<half_t> E;
   // S = stride (1 or 2): the patch is the (S*TH + 2 or S*TH + 1) x (...) input footprint of the tile
   constexpr int BM = TH * TW, R0W = S * (TW - 1) + 3, R0H = S * (TH - 1) + 3, NT = NW * 64, CB = CIN / 32, KB = 9 * CB;
@@ -659,9 +728,15 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
   };
 
   constexpr Img X = make_img(0, CIN / 8);
-  load_patch<R0H, R0W, CIN, NT>(conv_smem, static_cast<const half_t*>(p.src) + sg.src_coff, p.src_ld, p.H, p.W, S * ty0 - 1,
-                                S * tx0 - 1, p.zeros, wid, lane);
-  static_for<0, D>(fetch);
+  if constexpr (STEM) {
+    static_for<0, D>(fetch);   // weights first: they are in flight while the stem patch is computed
+    constexpr int PATCH = ((R0H * R0W * CIN * 2 + 1023) / 1024) * 1024;
+    stem_patch<R0H, R0W, CIN, NT>(conv_smem, conv_smem + PATCH, *sp, S * ty0 - 1, S * tx0 - 1);
+  } else {
+    load_patch<R0H, R0W, CIN, NT>(conv_smem, static_cast<const half_t*>(p.src) + sg.src_coff, p.src_ld, p.H, p.W, S * ty0 - 1,
+                                  S * tx0 - 1, p.zeros, wid, lane);
+    static_for<0, D>(fetch);
+  }
   EpiConsts<1> ec;
   load_epi_consts<1>(sg, nb0 + wn * 16, lq, ec);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
@@ -708,6 +783,16 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
 template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1>
 __global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
   conv3x3_regq_body<TH, TW, BN, CIN, NW, D, S>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// backbone.stem -> backbone.stage1_conv as ONE launch: the 3x3/s2 conv's input patch is the stem's output, computed in
+// place (stem_patch) instead of being written to HBM by one launch and DMA'd back by the next (6.6 MB each way at 640^2).
+struct StemConvParams {
+  StemParams stem;
+  ConvParams conv;
+};
+__global__ __launch_bounds__(512, 2) void stem_conv3x3s2_kernel(const StemConvParams p) {
+  conv3x3_regq_body<8, 16, 64, 32, 8, 8, 2, true>(p.conv, (int)blockIdx.x, (int)gridDim.x, &p.stem);
 }
 
 // ================================================================================================ dual launches
@@ -914,7 +999,8 @@ int n_tiles(const ConvParams& p, int bn) {
 }  // namespace
 
 hipError_t conv_init() {
-  for (const void* f : {reinterpret_cast<const void*>(conv_dual_head3x3), reinterpret_cast<const void*>(conv_dual_head1x1)}) {
+  for (const void* f : {reinterpret_cast<const void*>(conv_dual_head3x3), reinterpret_cast<const void*>(conv_dual_head1x1),
+                        reinterpret_cast<const void*>(stem_conv3x3s2_kernel)}) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (e != hipSuccess) return e;
   }
@@ -994,6 +1080,14 @@ dim3 conv_prepare(ConvParams& p, int cfg) {
   const ConvLaunch l = conv_plan_with(p, cfg);
   p.grid_m = (int)l.grid.x;
   p.gm_magic = div_magic(l.grid.x);
+  p.grid_n = (int)l.grid.y;
+  p.gn_magic = div_magic(l.grid.y);
+  {  // which operand should each XCD's L2 see only its share of? The other one is fetched by all 8 XCDs.
+    const double in_bytes = (double)esize(p) * p.H * p.W * p.Cin * ((p.nseg > 1 && p.seg[0].src_coff != p.seg[1].src_coff) ? p.nseg : 1);
+    double w_bytes = 0;
+    for (int s = 0; s < p.nseg; ++s) w_bytes += (double)esize(p) * ((p.seg[s].n_count + 15) & ~15) * p.ksize * p.ksize * p.Cin;
+    p.xcd_m_major = (l.grid.x >= 8 && in_bytes + 8.0 * w_bytes < 8.0 * in_bytes + w_bytes) ? 1 : 0;
+  }
   p.wo_magic = div_magic((unsigned)p.Wo);
   p.spt_magic = div_magic((unsigned)(p.Cin / kstep_of(p, c)));
   if (c.th) p.tx_magic = div_magic((unsigned)((p.Wo + c.tw - 1) / c.tw));
@@ -1014,6 +1108,37 @@ hipError_t conv_launch(const ConvParams& pin, const ConvLaunch& l, hipStream_t s
   return hipGetLastError();
 }
 
+// ---- stem + stage1_conv ----
+bool stemconv_supported(const StemParams& sp, const ConvParams& cp) {
+  if (sp.dtype != kF16 || sp.Co != 32 || cp.dtype != kF16 || cp.nseg != 1 || cp.res || cp.seg[0].up2 || cp.seg[0].dst_planar) return false;
+  if (cp.H != sp.Ho || cp.W != sp.Wo || cp.src_ld != 32 || cp.seg[0].src_coff != 0 || cp.stamps) return false;
+  return conv_config_valid(cp, kCfgRegqS2_8x16n64c32);
+}
+
+hipError_t stemconv_desc(const StemParams& sp, const ConvParams& cp_in, LaunchDesc* d, void* params_out /* StemConvParams */) {
+  StemConvParams* sc = static_cast<StemConvParams*>(params_out);
+  sc->stem = sp;
+  sc->conv = cp_in;
+  const dim3 g = conv_prepare(sc->conv, kCfgRegqS2_8x16n64c32);
+  d->func = reinterpret_cast<const void*>(&stem_conv3x3s2_kernel);
+  d->grid = dim3(g.x * g.y, 1, 1);
+  d->block = dim3(512, 1, 1);
+  const size_t patch = ((size_t)17 * 33 * 32 * 2 + 1023) / 1024 * 1024;
+  d->shmem = (unsigned)max_sz(patch + 28 * 32 * 4, stage_bytes(128, 64));
+  return hipSuccess;
+}
+
+size_t stemconv_params_bytes() { return sizeof(StemConvParams); }
+
+hipError_t stemconv_launch(const StemParams& sp, const ConvParams& cp, hipStream_t stream) {
+  StemConvParams sc;
+  LaunchDesc d;
+  hipError_t e = stemconv_desc(sp, cp, &d, &sc);
+  if (e != hipSuccess) return e;
+  void* args[] = {&sc};
+  return hipLaunchKernel(d.func, d.grid, d.block, args, d.shmem, stream);
+}
+
 // ---- dual launches (conv_dual_head3x3 / conv_dual_head1x1) ----
 namespace {
 struct DualKind {
@@ -1022,8 +1147,8 @@ struct DualKind {
   void (*fn)(const ConvParams, const ConvParams, int);
 };
 const DualKind kDual[] = {
-    {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual<regq 8x16,64,128 | regq 8x8,64,256>", conv_dual_head3x3},
-    {kCfg128x16k64, kCfg128x16k64, 256, "conv_dual<glds 128,16,64 x2>", conv_dual_head1x1},
+    {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3<regq 8x16,64,128 | regq 8x8,64,256>", conv_dual_head3x3},
+    {kCfg128x16k64, kCfg128x16k64, 256, "conv_dual_head1x1<glds 128,16,64 x2>", conv_dual_head1x1},
 };
 }  // namespace
 

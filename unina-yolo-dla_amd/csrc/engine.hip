@@ -178,6 +178,12 @@ void op_regions(const unina_engine* e, size_t i, std::vector<Region>* reads, std
     }
     return;
   }
+  if (e->fuse && e->ops[i].fuse_role == 1 && e->ops[i].fuse_kind == 3) {
+    const SegDesc& out = e->ops[e->ops[i].group_last].d.seg[0];
+    reads->push_back({(int)d.src_buf, 0, 3});
+    writes->push_back({(int)out.dst_buf, (int)out.dst_coff, (int)(out.dst_coff + out.n_count)});
+    return;
+  }
   if (e->fuse && e->ops[i].fuse_role == 1) {
     const OpDesc& last = e->ops[e->ops[i].group_last].d;
     reads->push_back({(int)d.src_buf, (int)d.seg[0].src_coff, (int)(d.seg[0].src_coff + d.cin)});
@@ -348,6 +354,28 @@ int plan(unina_engine* e) {
   for (size_t i = 0; i < e->ops.size(); ++i) {
     PlannedOp& op = e->ops[i];
     if (op.fuse_role != 1) continue;
+    if (op.fuse_kind == 3) {
+      PlannedOp& cv = e->ops[op.group_last];
+      if (!stemconv_supported(op.sp, cv.cp)) {   // other channel widths / precisions: the two ops stay separate launches
+        op.fuse_role = 0;
+        cv.fuse_role = 0;
+        --e->n_groups;
+        continue;
+      }
+      if (!e->fuse) continue;
+      op.info.flops += cv.info.flops;
+      op.info.bytes = 4.0 * 3 * op.sp.H * op.sp.W + 2.0 * cv.cp.M * cv.info.n + 2.0 * cv.info.n * cv.info.k;
+      op.info.grid = (cv.cp.Ho + 7) / 8 * ((cv.cp.Wo + 15) / 16) * ((cv.info.n + 63) / 64);
+      op.info.block = 512;
+      op.info.m = cv.info.m; op.info.n = cv.info.n; op.info.k = cv.info.k;
+      snprintf(op.info.kernel, sizeof op.info.kernel, "stem_conv3x3s2_kernel<8x16,64,32>");
+      snprintf(op.info.name, sizeof op.info.name, "%s+%s", op.d.name, cv.d.name);
+      cv.info.flops = 0;
+      cv.info.bytes = 0;
+      cv.info.grid = 0;
+      snprintf(cv.info.kernel, sizeof cv.info.kernel, "(fused into op %zu)", i);
+      continue;
+    }
     if (op.fuse_kind == 2) {
       const OpDesc& a = op.d;
       const OpDesc& z = e->ops[op.group_last].d;
@@ -529,6 +557,7 @@ hipError_t launch_op(unina_engine* e, size_t i, hipStream_t s) {
   PlannedOp& op = e->ops[i];
   if (op.dual_absorbed) return hipSuccess;
   if (e->fuse && op.fuse_role == 1 && op.dual_with >= 0) return block_dual_launch(op.fp, e->ops[op.dual_with].hp, s);
+  if (e->fuse && op.fuse_role == 1 && op.fuse_kind == 3) return stemconv_launch(op.sp, e->ops[op.group_last].cp, s);
   if (e->fuse && op.fuse_role == 1) return op.fuse_kind == 2 ? head_launch(op.hp, s) : c3k2_launch(op.fp, s);
   if (op.dual_with >= 0) return conv_dual_launch(op.dual_kind, op.cp, e->ops[op.dual_with].cp, s);
   if (e->fuse && op.fuse_role == 2) return hipSuccess;   // runs inside its group's launch
@@ -899,11 +928,26 @@ int launch_full(unina_engine* e, const PostParams& pp, hipStream_t stream) {
     int rc = capture_full(e, pp);
     if (rc != UNINA_OK) return rc;
   } else {
-    const StemParams& sp = e->ops[e->stem_op].sp;
+    const PlannedOp& so = e->ops[e->stem_op];
+    const StemParams& sp = so.sp;
     if (memcmp(&sp, &e->f_stem, sizeof sp)) {
       LaunchDesc d;
-      HIPCHK(e, stem_desc(sp, &d));
-      HIPCHK(e, set_node(e->fexec, e->stem_node, d, sp));
+      if (e->fuse && so.fuse_role == 1 && so.fuse_kind == 3) {   // the stem lives inside the stem+conv kernel
+        std::vector<unsigned char> sc(stemconv_params_bytes());
+        HIPCHK(e, stemconv_desc(sp, e->ops[so.group_last].cp, &d, sc.data()));
+        void* args[] = {sc.data()};
+        hipKernelNodeParams np;
+        memset(&np, 0, sizeof np);
+        np.func = const_cast<void*>(d.func);
+        np.gridDim = d.grid;
+        np.blockDim = d.block;
+        np.sharedMemBytes = d.shmem;
+        np.kernelParams = args;
+        HIPCHK(e, hipGraphExecKernelNodeSetParams(e->fexec, e->stem_node, &np));
+      } else {
+        HIPCHK(e, stem_desc(sp, &d));
+        HIPCHK(e, set_node(e->fexec, e->stem_node, d, sp));
+      }
       e->f_stem = sp;
     }
     if (memcmp(&pp, &e->f_post, sizeof pp)) {
@@ -942,6 +986,40 @@ int time_in_sequence(unina_engine* e, size_t i, int iters, hipStream_t stream, h
   }
   *ms_out = total / (float)iters;
   return UNINA_OK;
+}
+
+// backbone.stem followed by the 3x3/s2 conv that is its only reader: one launch (conv_igemm.hip: stem_conv3x3s2_kernel).
+// Shape support is checked at plan time (stemconv_supported); here only the wiring. OPT-IN (UNINA_STEM_FUSE=1): it is
+// bit-identical and saves a launch plus the stem's 6.6 MB round trip, but measured no faster at 640^2 (0.278 vs 0.277 ms:
+// the in-kernel stem is three rounds of latency-bound fp32 image loads per workgroup), so the separate launches stay.
+void find_stem_group(unina_engine* e) {
+  const char* sf = getenv("UNINA_STEM_FUSE");
+  if (!sf || sf[0] != '1') return;
+  for (size_t i = 0; i + 1 < e->ops.size(); ++i) {
+    const OpDesc& st = e->ops[i].d;
+    const OpDesc& cv = e->ops[i + 1].d;
+    if (st.kind != kOpStem || e->ops[i].fuse_role || e->ops[i + 1].fuse_role) continue;
+    const uint32_t sb = st.seg[0].dst_buf;
+    if (cv.kind != kOpConv || cv.ksize != 3 || cv.stride != 2 || !cv.relu || cv.nseg != 1 || cv.res_buf >= 0 || cv.seg[0].flags ||
+        cv.seg[0].m_off || cv.src_buf != sb || cv.seg[0].src_coff != 0 || st.seg[0].dst_coff != 0 || cv.cin != st.seg[0].n_count ||
+        e->bufs[sb].d.c != cv.cin || e->bufs[sb].d.dtype != kBufF16Nhwc || e->bufs[cv.seg[0].dst_buf].d.dtype != kBufF16Nhwc)
+      continue;
+    bool priv = !(e->bufs[sb].d.flags & (kBufInput | kBufOutput));
+    for (size_t k = 0; k < e->ops.size() && priv; ++k) {
+      if (k == i || k == i + 1) continue;
+      const OpDesc& o = e->ops[k].d;
+      if (o.src_buf == sb || o.res_buf == (int)sb) priv = false;
+      for (uint32_t s = 0; s < o.nseg; ++s)
+        if (o.seg[s].dst_buf == sb) priv = false;
+    }
+    if (!priv) continue;
+    e->ops[i].fuse_role = 1;
+    e->ops[i].fuse_kind = 3;
+    e->ops[i].group_last = (int)i + 1;
+    e->ops[i + 1].fuse_role = 2;
+    ++e->n_groups;
+    return;
+  }
 }
 
 int find_buffer(const unina_engine* e, const char* name) {
@@ -1073,6 +1151,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   if (e->h.precision == kFp16 || e->h.precision == kInt8) {
     find_c3k2_groups(e, &blob);
     find_head_groups(e, &blob);
+    find_stem_group(e);
     const char* fz = getenv("UNINA_FUSE");
     e->fuse = e->n_groups > 0 && !(fz && fz[0] == '0');
   }
@@ -1321,6 +1400,7 @@ int unina_debug_fusable_groups(const char* path) {
   if (e.h.precision == kFp16 || e.h.precision == kInt8) {
     find_c3k2_groups(&e, &blob);
     find_head_groups(&e, &blob);
+    find_stem_group(&e);
   }
   return e.n_groups;
 }

@@ -49,6 +49,9 @@ struct ConvParams {
   const void* zeros;   // >= 16 bytes of zeros in HBM: source of out-of-image taps / tile tails
   int force_cfg;       // >= 0: use this tile configuration (autotuner / tests); -1: heuristic
   int grid_m;          // number of M tiles (filled at launch): the 1-D grid is re-mapped XCD-aware in the kernel
+  int grid_n;          // number of N tiles (filled at launch)
+  int xcd_m_major;     // 1: an XCD owns a range of pixel tiles (input-heavy ops), 0: a range of channel tiles (weight-heavy)
+  unsigned gn_magic;
   unsigned gm_magic, wo_magic, spt_magic, tx_magic;  // ceil(2^32/d) for d = grid_m, Wo, K-steps per tap, spatial tiles per row (0: d == 1), filled at launch
   int debug_mode;      // debug ablations (results invalid): 1 = no loads inside the K loop, 2 = no LDS reads/MFMA, 3 = MFMA without LDS reads
   long long* stamps;   // debug: s_memtime stamps of workgroup (0,0) (nullptr = off): start, prologue issued, first data, loop end, end
@@ -180,6 +183,12 @@ struct LaunchDesc {
   unsigned shmem;
 };
 hipError_t stem_desc(const StemParams& p, LaunchDesc* out);
+// backbone.stem + the 3x3/s2 conv that follows it as ONE launch (conv_igemm.hip: stem_conv3x3s2_kernel)
+struct ConvParams;
+bool stemconv_supported(const StemParams& sp, const ConvParams& cp);
+size_t stemconv_params_bytes();
+hipError_t stemconv_desc(const StemParams& sp, const ConvParams& cp, LaunchDesc* d, void* params_out);
+hipError_t stemconv_launch(const StemParams& sp, const ConvParams& cp, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // SPPF pool pyramid: y1 = pool5(x), y2 = pool5(y1), y3 = pool5(y2) (== 5x5, 9x9, 13x13 clipped windows of x)
