@@ -25,6 +25,8 @@
 #include "kernels.h"
 #include "block_pipeline.h"
 
+#include <cstdlib>
+
 namespace unina {
 
 using namespace dev;
@@ -696,13 +698,14 @@ __device__ __forceinline__ void stem_patch(unsigned char* smem, unsigned char* w
   }
 }
 
-template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, bool STEM = false>
+// WN = 16-channel subtiles per wave (each activation fragment then feeds WN MFMAs: halves the LDS reads per MFMA at 2).
+template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, bool STEM = false, int WN = 1>
 __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, int nwg, const StemParams* sp = nullptr) {
   typedef Elem<half_t> E;
   // S = stride (1 or 2): the patch is the (S*TH + 2 or S*TH + 1) x (...) input footprint of the tile
   constexpr int BM = TH * TW, R0W = S * (TW - 1) + 3, R0H = S * (TH - 1) + 3, NT = NW * 64, CB = CIN / 32, KB = 9 * CB;
-  constexpr int NS = BN / 16, WVM = NW / NS, MS = (BM + 15) / 16, WM_T = (MS + WVM - 1) / WVM;
-  static_assert(NW % NS == 0 && WM_T >= 1 && KB >= D, "tile");
+  constexpr int NS = BN / 16 / WN, WVM = NW / NS, MS = (BM + 15) / 16, WM_T = (MS + WVM - 1) / WVM;   // NS = waves along the channels
+  static_assert((BN / 16) % WN == 0 && NW % NS == 0 && WM_T >= 1 && KB * WN >= D, "tile");
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -718,13 +721,18 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
   const int tyi = fast_div(bx, p.tx_magic), txi = bx - tyi * tiles_x;
   const int ty0 = tyi * TH, tx0 = txi * TW;
 
-  int nsub = (nb0 >> 4) + wn;                       // this wave's channel subtile (tail tiles: clamp, never stored)
-  nsub = nsub * 16 < n_pad ? nsub : (n_pad >> 4) - 1;
-  const unsigned char* wptr = static_cast<const unsigned char*>(sg.w) + (size_t)nsub * KB * 1024 + (4 * l15 + (lq ^ swz_g(l15))) * 16;
+  // this wave's channel subtiles wn*WN .. +WN (tail tiles: clamp, never stored); queue element g = (k-block g / WN, subtile g % WN)
+  const unsigned char* wptr[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    int nsub = (nb0 >> 4) + wn * WN + j;
+    nsub = nsub * 16 < n_pad ? nsub : (n_pad >> 4) - 1;
+    wptr[j] = static_cast<const unsigned char*>(sg.w) + (size_t)nsub * KB * 1024 + (4 * l15 + (lq ^ swz_g(l15))) * 16;
+  }
   half8 q[D];
   auto fetch = [&](auto gc) {
     constexpr int g = decltype(gc)::value;
-    if constexpr (g < KB) q[g % D] = *reinterpret_cast<const half8*>(wptr + g * 1024);
+    if constexpr (g < KB * WN) q[g % D] = *reinterpret_cast<const half8*>(wptr[g % WN] + (g / WN) * 1024);
   };
 
   constexpr Img X = make_img(0, CIN / 8);
@@ -737,8 +745,8 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
                                   S * tx0 - 1, p.zeros, wid, lane);
     static_for<0, D>(fetch);
   }
-  EpiConsts<1> ec;
-  load_epi_consts<1>(sg, nb0 + wn * 16, lq, ec);
+  EpiConsts<WN> ec;
+  load_epi_consts<WN>(sg, nb0 + wn * (WN * 16), lq, ec);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
   lds_barrier();
 
@@ -753,26 +761,31 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
     constexpr int kb = decltype(kc)::value, tap = kb / CB, cb = kb - tap * CB, th3 = tap / 3;
     return X.addr(row0[i] + th3 * R0W + (tap - th3 * 3), cb * 4 + lq);
   };
-  typename E::acc_t acc[1][WM_T];
+  typename E::acc_t acc[WN][WM_T];
   half8 b[2][WM_T];
 #pragma unroll
   for (int i = 0; i < WM_T; ++i) {
-    acc[0][i] = typename E::acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[j][i] = typename E::acc_t{0, 0, 0, 0};
     b[0][i] = *reinterpret_cast<const half8*>(conv_smem + baddr(i, std::integral_constant<int, 0>{}));
   }
   static_for<0, KB>([&](auto kc) {
     constexpr int kb = decltype(kc)::value;
-    const half8 a = q[kb % D];
-    fetch(std::integral_constant<int, kb + D>{});
+    half8 a[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) a[j] = q[(kb * WN + j) % D];
+    static_for<0, WN>([&](auto jc) { fetch(std::integral_constant<int, kb * WN + decltype(jc)::value + D>{}); });
     if constexpr (kb + 1 < KB) {
 #pragma unroll
       for (int i = 0; i < WM_T; ++i) b[(kb + 1) & 1][i] = *reinterpret_cast<const half8*>(conv_smem + baddr(i, std::integral_constant<int, kb + 1>{}));
     }
 #pragma unroll
-    for (int i = 0; i < WM_T; ++i) acc[0][i] = E::mma(a, b[kb & 1][i], acc[0][i]);
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int i = 0; i < WM_T; ++i) acc[j][i] = E::mma(a[j], b[kb & 1][i], acc[j][i]);
   });
 
-  conv_epilogue<half_t, BM, BN, WM_T, 1>(p, sg, acc, ec, wm, wn, nb0, l15, lq,
+  conv_epilogue<half_t, BM, BN, WM_T, WN>(p, sg, acc, ec, wm, wn, nb0, l15, lq,
                                          [&](int pl) {
                                            const int oy = ty0 + pl / TW, ox = tx0 + pl % TW;
                                            return (pl < BM && oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
@@ -780,9 +793,9 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
                                          conv_smem, NT);
 }
 
-template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1>
+template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, int WN = 1>
 __global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
-  conv3x3_regq_body<TH, TW, BN, CIN, NW, D, S>(p, (int)blockIdx.x, (int)gridDim.x);
+  conv3x3_regq_body<TH, TW, BN, CIN, NW, D, S, false, WN>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // backbone.stem -> backbone.stage1_conv as ONE launch: the 3x3/s2 conv's input patch is the stem's output, computed in
@@ -806,6 +819,12 @@ __global__ __launch_bounds__(512, 2) void stem_conv3x3s2_kernel(const StemConvPa
 __global__ __launch_bounds__(512, 4) void conv_dual_head3x3(const ConvParams pa, const ConvParams pb, int na) {
   if ((int)blockIdx.x < na) conv3x3_regq_body<8, 16, 64, 128, 8, 8, 1>(pa, (int)blockIdx.x, na);
   else conv3x3_regq_body<8, 8, 64, 256, 8, 8, 1>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
+}
+// Variant with 128-channel workgroup tiles and two subtiles per wave (half the LDS fragment reads per MFMA): 100 + 100
+// workgroups, one per CU.
+__global__ __launch_bounds__(512) void conv_dual_head3x3_w2(const ConvParams pa, const ConvParams pb, int na) {
+  if ((int)blockIdx.x < na) conv3x3_regq_body<8, 16, 128, 128, 8, 16, 1, false, 2>(pa, (int)blockIdx.x, na);
+  else conv3x3_regq_body<8, 8, 128, 256, 8, 16, 1, false, 2>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
 }
 __global__ __launch_bounds__(256) void conv_dual_head1x1(const ConvParams pa, const ConvParams pb, int na) {
   if ((int)blockIdx.x < na) conv_glds_body<half_t, 128, 16, 64, 4, 1, 4>(pa, (int)blockIdx.x, na);
@@ -844,6 +863,9 @@ constexpr size_t smem_of() {
 #define REGQ(TH, TW, BN, CIN, NW, D)                                                                 \
   {(TH) * (TW), BN, 32, 3, "conv3x3_regq<f16," #TH "x" #TW "," #BN "," #CIN "," #NW "w>",                \
    conv3x3_regq<TH, TW, BN, CIN, NW, D>, 0, TH, TW, CIN, (NW) * 64, 1}
+#define REGQW(TH, TW, BN, CIN, NW, D)                                                                \
+  {(TH) * (TW), BN, 32, 3, "conv3x3_regq<f16," #TH "x" #TW "," #BN "," #CIN "," #NW "w,wn2>",            \
+   conv3x3_regq<TH, TW, BN, CIN, NW, D, 1, 2>, 0, TH, TW, CIN, (NW) * 64, 1}
 #define REGQ2(TH, TW, BN, CIN, NW, D)                                                                \
   {(TH) * (TW), BN, 32, 3, "conv3x3_regq<f16," #TH "x" #TW "," #BN "," #CIN "," #NW "w,s2>",             \
    conv3x3_regq<TH, TW, BN, CIN, NW, D, 2>, 0, TH, TW, CIN, (NW) * 64, 2}
@@ -903,6 +925,9 @@ const CfgInfo kCfg[3][kCfgCount] = {
         REGQ2(4, 8, 64, 128, 8, 16),                  // kCfgRegqS2_4x8n64c128
         REGQ2(8, 16, 64, 32, 8, 8),                   // kCfgRegqS2_8x16n64c32    (stage1_conv)
         REGQ2(8, 8, 32, 128, 8, 16),                  // kCfgRegqS2_8x8n32c128
+        // two channel subtiles per wave: each activation fragment feeds two MFMAs
+        REGQW(8, 16, 128, 128, 8, 16),                // kCfgRegqW8x16n128c128
+        REGQW(8, 8, 128, 256, 8, 16),                 // kCfgRegqW8x8n128c256
     },
     {
         CFG(float, "f32", 64, 64, 64, 2, 2, 4),
@@ -934,7 +959,7 @@ const CfgInfo kCfg[3][kCfgCount] = {
         CFG(float, "f32", 32, 64, 128, 1, 4, 4),
         CFG(float, "f32", 64, 64, 128, 2, 2, 4),
         NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,     // register-queue kernels are fp16 only
-        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
     },
     {
         CFG(signed char, "i8", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
@@ -966,13 +991,14 @@ const CfgInfo kCfg[3][kCfgCount] = {
         CFG(signed char, "i8", 32, 64, 128, 1, 4, 4),     // kCfg32x64k128
         CFG(signed char, "i8", 64, 64, 128, 2, 2, 4),     // kCfg64x64k128
         NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
-        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
     },
 };
 #undef CFG
 #undef HALO
 #undef REGQ
 #undef REGQ2
+#undef REGQW
 #undef NOCFG
 
 inline int block_k(int dtype) { return dtype == kF32 ? 16 : (dtype == kI8 ? 64 : 32); }
@@ -1000,6 +1026,7 @@ int n_tiles(const ConvParams& p, int bn) {
 
 hipError_t conv_init() {
   for (const void* f : {reinterpret_cast<const void*>(conv_dual_head3x3), reinterpret_cast<const void*>(conv_dual_head1x1),
+                        reinterpret_cast<const void*>(conv_dual_head3x3_w2),
                         reinterpret_cast<const void*>(stem_conv3x3s2_kernel)}) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (e != hipSuccess) return e;
@@ -1149,11 +1176,14 @@ struct DualKind {
 const DualKind kDual[] = {
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3<regq 8x16,64,128 | regq 8x8,64,256>", conv_dual_head3x3},
     {kCfg128x16k64, kCfg128x16k64, 256, "conv_dual_head1x1<glds 128,16,64 x2>", conv_dual_head1x1},
+    {kCfgRegqW8x16n128c128, kCfgRegqW8x8n128c256, 512, "conv_dual_head3x3_w2<regq 8x16,128,128,wn2 | regq 8x8,128,256,wn2>", conv_dual_head3x3_w2},
 };
 }  // namespace
 
 int conv_dual_match(const ConvParams& a, const ConvParams& b) {
   if (a.dtype != kF16 || b.dtype != kF16 || a.stamps || b.stamps) return -1;
+  static const bool w2 = getenv("UNINA_DUAL_W2") && getenv("UNINA_DUAL_W2")[0] == '1';
+  if (w2 && a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[2].cfg_a) && conv_config_valid(b, kDual[2].cfg_b)) return 2;
   if (a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[0].cfg_a) && conv_config_valid(b, kDual[0].cfg_b)) return 0;
   auto tiny = [](const ConvParams& p) {
     for (int s = 0; s < p.nseg; ++s)
@@ -1164,10 +1194,10 @@ int conv_dual_match(const ConvParams& a, const ConvParams& b) {
   return -1;
 }
 
-const char* conv_dual_name(int kind) { return kind >= 0 && kind < 2 ? kDual[kind].name : "?"; }
+const char* conv_dual_name(int kind) { return kind >= 0 && kind < 3 ? kDual[kind].name : "?"; }
 
 hipError_t conv_dual_launch(int kind, const ConvParams& pa_in, const ConvParams& pb_in, hipStream_t stream, int* grid_out) {
-  if (kind < 0 || kind >= 2) return hipErrorInvalidValue;
+  if (kind < 0 || kind >= 3) return hipErrorInvalidValue;
   const DualKind& k = kDual[kind];
   ConvParams pa = pa_in, pb = pb_in;
   const dim3 ga = conv_prepare(pa, k.cfg_a), gb = conv_prepare(pb, k.cfg_b);
