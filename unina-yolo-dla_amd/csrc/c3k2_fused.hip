@@ -63,7 +63,7 @@ const Class kClasses[] = {
     C3K2(64, 4, 8, 1, 256, 8, 8),      // neck.fpn_c3k2_1
     C3K2T(64, 4, 8, 1, 256, 8, 8),     // neck.fpn_c3k2_1 + neck.lateral_p2 (+ x2 upsample)
     C3K2(64, 4, 8, 1, 192, 8, 8),      // neck.pan_c3k2_1
-    C3K2(128, 4, 4, 2, 256, 8, 16),    // backbone.stage3_c3k2          40^2: 100
+    C3K2(128, 4, 4, 2, 256, 8, 16),    // backbone.stage3_c3k2          40^2: 100  (16 waves: 27 vs 20 us)
     C3K2(128, 4, 4, 1, 384, 8, 16),    // neck.pan_c3k2_2
     C3K2(128, 4, 4, 1, 512, 8, 16),    // graph (B) fpn_c3k2_1 (qat.py:397)
     C3K2T(128, 4, 4, 1, 512, 8, 16),   // graph (B) fpn_c3k2_1 + lateral_p3
