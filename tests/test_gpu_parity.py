@@ -409,6 +409,42 @@ def test_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
         e.close()
 
 
+@pytest.mark.parametrize("size", [128, 640, 96])
+def test_int8_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
+    """INT8 engines: the five all-int8 C3k2 blocks as int8 block kernels (csrc/block_kernels.h with EltI8: LDS images
+    hold int8 codes, v_mfma_i32_16x16x64_i8, the per-op kernels' fma / ReLU / shortcut / round-half-even epilogue with
+    the same per-tensor scales) vs the per-conv launches: int32 accumulation is exact, so every code must agree."""
+    from unina_yolo_dla_amd import export
+    from unina_yolo_dla_amd.engine import Engine, calibrate_amax
+    g = pkg.graph.Graph(in_h=size, in_w=size)
+    amax = calibrate_amax(sd7, g, [pkg.rng.frame(5000 + i, size, size) for i in range(2)])
+    e = Engine.from_state_dict(sd7, g, precision=export.INT8, amax=amax)
+    try:
+        assert e.L.unina_fusion_groups(e.h) == 6              # 5 int8 blocks + the carved-out fp16 P2 head
+        x = _frame(pkg, torch_cuda, 1234, size)
+        fused = {k: v.copy() for k, v in e.forward(x).items()}
+        bufs = ("neck.cat_fpn1", "neck.cat_pan1", "neck.cat_pan2", "p3_out", "p4_out")
+        names = [b[0] for b in export.EngineBuilder(sd7, g, export.INT8, amax).buffers]
+        bufs = tuple(b for b in bufs if b in names)
+        assert len(bufs) == 5
+        fused_bufs = {b: e.read_buffer(b) for b in bufs}
+        kernels = [o["kernel"] for o in e.op_infos()]
+        assert sum("c3k2_fused<i8" in k or "block_dual_c3k2i8" in k for k in kernels) == 5, kernels
+        assert e.set_fusion(False) == 0
+        plain = e.forward(x)
+        for b in bufs:
+            assert np.array_equal(fused_bufs[b], e.read_buffer(b)), b
+        for k in plain:
+            assert np.array_equal(fused[k], plain[k]), k
+        assert e.set_fusion(True) == 6
+        d1 = e.infer(x, 0.5, 0.45, 0.1)
+        e.set_fusion(False)
+        d0 = e.infer(x, 0.5, 0.45, 0.1)
+        assert len(d0) == len(d1) and d0.tobytes() == d1.tobytes()
+    finally:
+        e.close()
+
+
 def test_frame_graph_and_tiled_nms_match_the_plain_forms(pkg, sd7, torch_cuda, monkeypatch):
     """Default per-frame path = ONE hipGraph launch (stem + forward + two-launch post-process whose NMS mask tiles run on
     many CUs; the stem / post-process nodes are re-pointed per frame with hipGraphExecKernelNodeSetParams). It must

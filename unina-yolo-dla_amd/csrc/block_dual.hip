@@ -19,23 +19,38 @@ __global__ __launch_bounds__(512, 4) void block_dual_c3k2_128x384_head64(const C
   else head_fused_body<64, 8, 16, 8, 4>(ph, (int)blockIdx.x - nc, bd_smem);
 }
 
+// INT8 engines: the same pair with pan_c3k2_2 as an int8 block (the P2 head stays fp16: train.py:779 carve-out)
+__global__ __launch_bounds__(512, 4) void block_dual_c3k2i8_128x384_head64(const C3k2Params pc, const HeadParams ph, int nc) {
+  if ((int)blockIdx.x < nc) c3k2_fused_body<128, 4, 4, 1, 384, 8, 8, 0, EltI8>(pc, (int)blockIdx.x, bd_smem);
+  else head_fused_body<64, 8, 16, 8, 4>(ph, (int)blockIdx.x - nc, bd_smem);
+}
+
 hipError_t block_dual_init() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(block_dual_c3k2_128x384_head64),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(block_dual_c3k2_128x384_head64),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(block_dual_c3k2i8_128x384_head64),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 bool block_dual_match(const C3k2Params& pc, const HeadParams& ph) {
-  return pc.hid == 128 && pc.nb == 1 && pc.Cin == 384 && pc.tail == 0 && ph.C == 64 &&
+  return (pc.dtype == kF16 || pc.dtype == kI8) && pc.hid == 128 && pc.nb == 1 && pc.Cin == 384 && pc.tail == 0 && ph.C == 64 &&
          c3k2_tile_is(pc, 4, 4) && head_tile_is(ph, 8, 16);
 }
 
-const char* block_dual_name() { return "block_dual_c3k2_128x384_head64<c3k2 128,4x4,1,384 | head 64,8x16>"; }
+const char* block_dual_name(int dtype) {
+  return dtype == kI8 ? "block_dual_c3k2i8_128x384_head64<c3k2 i8,128,4x4,1,384 | head 64,8x16>"
+                      : "block_dual_c3k2_128x384_head64<c3k2 128,4x4,1,384 | head 64,8x16>";
+}
 
 hipError_t block_dual_launch(const C3k2Params& pc, const HeadParams& ph, hipStream_t stream, int* grid_out) {
   const int nc = pc.tiles_x * pc.tiles_y, nh = ph.tiles_x * ph.tiles_y;
   const int smem = pc.smem_bytes > ph.smem_bytes ? pc.smem_bytes : ph.smem_bytes;
   if (grid_out) *grid_out = nc + nh;
-  hipLaunchKernelGGL(block_dual_c3k2_128x384_head64, dim3(nc + nh, 1, 1), dim3(512, 1, 1), smem, stream, pc, ph, nc);
+  if (pc.dtype == kI8)
+    hipLaunchKernelGGL(block_dual_c3k2i8_128x384_head64, dim3(nc + nh, 1, 1), dim3(512, 1, 1), smem, stream, pc, ph, nc);
+  else
+    hipLaunchKernelGGL(block_dual_c3k2_128x384_head64, dim3(nc + nh, 1, 1), dim3(512, 1, 1), smem, stream, pc, ph, nc);
   return hipGetLastError();
 }
 

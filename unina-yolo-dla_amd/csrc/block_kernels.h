@@ -11,30 +11,42 @@ namespace dev {
 // step 0: cv1|cv2 (K = CIN, N = 2h); odd steps: bottleneck 1x1 (K = h, N = h); even steps: bottleneck 3x3 (K = 9h,
 // N = h); last step: cv3 (K = 2h, N = 2h). A wave owns one channel subtile, or ns / NW of them when ns > NW.
 // TAIL = 1 appends the lateral 1x1 conv (2h -> h, + nearest x2 upsample in its store) that follows an FPN block.
-template <int H_, int NB, int CIN, int NW, int TAIL>
+// KBLK = k per weight block (32 fp16 / 64 int8).
+template <int H_, int NB, int CIN, int NW, int TAIL, int KBLK = 32>
 struct C3k2Plan {
   static constexpr int CV3 = 1 + 2 * NB;        // index of the cv3 step
   static constexpr int N = 2 + 2 * NB + TAIL;
-  static constexpr int kb(int s) { return s == 0 ? CIN / 32 : (s >= CV3 ? 2 * H_ / 32 : ((s & 1) ? H_ / 32 : 9 * H_ / 32)); }
+  static constexpr int kb(int s) { return s == 0 ? CIN / KBLK : (s >= CV3 ? 2 * H_ / KBLK : ((s & 1) ? H_ / KBLK : 9 * H_ / KBLK)); }
   static constexpr int ns(int s) { return (s == 0 || s == CV3) ? 2 * H_ / 16 : H_ / 16; }
   static constexpr int wnt(int s) { return ns(s) <= NW ? 1 : ns(s) / NW; }
+  static constexpr int nch(int s) { return 16 * ns(s); }              // output channels of step s
+  static constexpr int cfirst(int s) {                                 // channels of all earlier steps
+    int t = 0;
+    for (int i = 0; i < s; ++i) t += nch(i);
+    return t;
+  }
 };
 
 
 // NW waves per workgroup (roles per step: Steps::waves_n / wnt / waves_m); D = weight prefetch depth in 1-KiB blocks
 // per wave. There is no wave-uniform branch around any global load: the kernel is straight-line code, so the
 // compiler's counted s_waitcnt vmcnt keeps D loads in flight across every step boundary.
-template <int H_, int TH, int TW, int NB, int CIN, int NW, int D, int TAIL = 0>
+// E = EltH (fp16 engines and carve-outs) or EltI8 (INT8 engines: every tensor of the block is an int8 code image with
+// its per-tensor scale; the epilogues re-quantise exactly as the per-op kernels do, conv_igemm.hip conv_epilogue).
+template <int H_, int TH, int TW, int NB, int CIN, int NW, int D, int TAIL = 0, typename E = EltH>
 __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, unsigned char* smem) {
   static_assert(NB == 1 || NB == 2, "bottleneck count");
-  typedef StepTable<C3k2Plan<H_, NB, CIN, NW, TAIL>, NW> ST;
+  typedef C3k2Plan<H_, NB, CIN, NW, TAIL, E::KBLK> PL;
+  typedef StepTable<PL, NW> ST;
   static_assert(ST::valid(), "wave roles");
   static_assert((NW & (NW - 1)) == 0 && NW >= 2 && NW <= 16, "waves per workgroup");
+  static_assert(H_ % E::KBLK == 0 && CIN % E::KBLK == 0, "a weight block must not straddle a tap");
   constexpr int R0W = TW + 2 * NB, P0 = (TH + 2 * NB) * R0W;   // input / first-level region (tile + NB-pixel halo)
   constexpr int R1W = TW + 2, P1 = (TH + 2) * R1W;              // NB == 2: region of the first bottleneck's output
   constexpr int PT = TH * TW;
-  constexpr int HB = H_ / 32;                                   // k-blocks per tap of the hidden width
+  constexpr int HB = H_ / E::KBLK;                              // k-blocks per tap of the hidden width
   constexpr int NT = NW * 64;
+  constexpr int ESZ = E::ESZ;
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -44,29 +56,31 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
 
   // ---- weight prefetch queue: element g of this wave's flat sequence lives in slot g % D ----
   const unsigned char* wbase = p.wstream + (4 * l15 + (lq ^ swz_g(l15))) * 16;   // this lane's 16 bytes of any block
-  half8 q[D];
-  // biases of every step -> LDS
+  typename E::frag q[D];
+  // per-channel constants of every step -> LDS
   float* bias_lds = reinterpret_cast<float*>(smem + p.off_bias);
   for (int i = threadIdx.x; i < p.n_bias; i += NT) bias_lds[i] = p.bias[i];
+#define CST(S) (bias_lds + E::CM * PL::cfirst(S))
 
   // input patch (tile + NB-pixel halo, all CIN channels) -> LDS image
-  constexpr Img X = make_img(0, CIN / 8);
-  load_patch<TH + 2 * NB, R0W, CIN, NT>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0 - NB, tx0 - NB, p.zeros, wid, lane);
+  constexpr Img X = make_img(0, CIN / E::CH);
+  load_patch<TH + 2 * NB, R0W, CIN, NT, E>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0 - NB, tx0 - NB, p.zeros, wid, lane);
   static_for<0, D>([&](auto gc) { wq_fetch<ST, D, decltype(gc)::value>(q, wbase, wid); });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed (LDS-DMA is not tracked by the compiler)
   lds_barrier();
 
   const Img Xi = Img{p.off_x, X.nch, X.sh, X.mask};
-  const Img Y = make_img(p.off_y, 2 * H_ / 8);   // a | b on R0
-  const Img T = make_img(p.off_t, H_ / 8);       // t of the current bottleneck (R0, then R1)
-  const Img U1 = make_img(p.off_u1, H_ / 8);     // NB == 2: first bottleneck's output on R1
-  const Img U2 = make_img(p.off_u2, H_ / 8);     // last bottleneck's output on the tile
+  const Img Y = make_img(p.off_y, 2 * H_ / E::CH);   // a | b on R0
+  const Img T = make_img(p.off_t, H_ / E::CH);       // t of the current bottleneck (R0, then R1)
+  const Img U1 = make_img(p.off_u1, H_ / E::CH);     // NB == 2: first bottleneck's output on R1
+  const Img U2 = make_img(p.off_u2, H_ / E::CH);     // last bottleneck's output on the tile
   auto in_image = [&](int iy, int ix) { return (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W; };
 
   auto run_step = [&](auto sc, auto pc, auto baddr, auto epi) {
-    dev::run_step<ST, D, decltype(sc)::value, decltype(pc)::value>(q, wbase, smem, wid, lane, baddr, epi);
+    dev::run_step<ST, D, decltype(sc)::value, decltype(pc)::value, E>(q, wbase, smem, wid, lane, baddr, epi);
   };
 #define STEP(S, P) std::integral_constant<int, (S)>{}, std::integral_constant<int, (P)>{}
+  typedef typename E::acc_t acc_t;
 
   // ---- step 0: a | b = ReLU(W12 x + b12) on R0 --------------------------------------------------------------------
   run_step(STEP(0, P0),
@@ -74,11 +88,10 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
         const int r = sub * 16 + l15;
         return Xi.addr(r < P0 ? r : P0 - 1, decltype(kc)::value * 4 + lq);
       },
-      [&](int sub, int n, const floatx4& acc) {
+      [&](int sub, int n, const acc_t& acc) {
         const int r = sub * 16 + l15;
-        if (r < P0) store_h4(smem, Y, r, n, bias_relu(acc, bias_lds, n));
+        if (r < P0) store4<E, 2 * H_>(smem + img_at<E>(Y, r, n), act_relu<E, 2 * H_>(acc, CST(0), n), CST(0), n);
       });
-  const float* bias_b = bias_lds + 2 * H_;
 
   // ---- bottleneck 0 -----------------------------------------------------------------------------------------------
   // t = ReLU(Wb1 a + b) on R0, forced to 0 outside the image (zero padding of the 3x3 that follows)
@@ -87,13 +100,13 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
         const int r = sub * 16 + l15;
         return Y.addr(r < P0 ? r : P0 - 1, decltype(kc)::value * 4 + lq);
       },
-      [&](int sub, int n, const floatx4& acc) {
+      [&](int sub, int n, const acc_t& acc) {
         const int r = sub * 16 + l15;
         if (r >= P0) return;
         const int ry = r / R0W, rx = r - ry * R0W;
-        floatx4 v = bias_relu(acc, bias_b, n);
+        floatx4 v = act_relu<E, H_>(acc, CST(1), n);
         if (!in_image(ty0 - NB + ry, tx0 - NB + rx)) v = floatx4{0.f, 0.f, 0.f, 0.f};
-        store_h4(smem, T, r, n, v);
+        store4<E, H_>(smem + img_at<E>(T, r, n), v, CST(1), n);
       });
   if constexpr (NB == 1) {
     // u = ReLU(3x3(t) + b) + a on the tile
@@ -105,12 +118,12 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           const int py = pp / TW, px = pp - py * TW;
           return T.addr((py + th3) * R0W + px + (tap - th3 * 3), cb * 4 + lq);
         },
-        [&](int sub, int n, const floatx4& acc) {
+        [&](int sub, int n, const acc_t& acc) {
           const int pp = sub * 16 + l15;
           if (pp >= PT) return;
           const int py = pp / TW, px = pp - py * TW;
-          const floatx4 v = bias_relu(acc, bias_b + H_, n) + load_h4(smem, Y, (py + 1) * R0W + px + 1, n);
-          store_h4(smem, U2, pp, n, v);
+          const floatx4 v = add_res<E>(act_relu<E, H_>(acc, CST(2), n), smem, Y, (py + 1) * R0W + px + 1, n, p.res_scale[0]);
+          store4<E, H_>(smem + img_at<E>(U2, pp, n), v, CST(2), n);
         });
   } else {
     // u1 = ReLU(3x3(t1) + b) + a on R1
@@ -122,28 +135,27 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           const int py = pp / R1W, px = pp - py * R1W;
           return T.addr((py + th3) * R0W + px + (tap - th3 * 3), cb * 4 + lq);
         },
-        [&](int sub, int n, const floatx4& acc) {
+        [&](int sub, int n, const acc_t& acc) {
           const int pp = sub * 16 + l15;
           if (pp >= P1) return;
           const int py = pp / R1W, px = pp - py * R1W;
-          const floatx4 v = bias_relu(acc, bias_b + H_, n) + load_h4(smem, Y, (py + 1) * R0W + px + 1, n);
-          store_h4(smem, U1, pp, n, v);
+          const floatx4 v = add_res<E>(act_relu<E, H_>(acc, CST(2), n), smem, Y, (py + 1) * R0W + px + 1, n, p.res_scale[0]);
+          store4<E, H_>(smem + img_at<E>(U1, pp, n), v, CST(2), n);
         });
     // ---- bottleneck 1 ---------------------------------------------------------------------------------------------
-    const float* bias_c = bias_b + 2 * H_;
     // t2 = ReLU(Wb1' u1 + b) on R1, 0 outside the image
     run_step(STEP(3, P1),
         [&](int sub, auto kc) {
           const int r = sub * 16 + l15;
           return U1.addr(r < P1 ? r : P1 - 1, decltype(kc)::value * 4 + lq);
         },
-        [&](int sub, int n, const floatx4& acc) {
+        [&](int sub, int n, const acc_t& acc) {
           const int r = sub * 16 + l15;
           if (r >= P1) return;
           const int ry = r / R1W, rx = r - ry * R1W;
-          floatx4 v = bias_relu(acc, bias_c, n);
+          floatx4 v = act_relu<E, H_>(acc, CST(3), n);
           if (!in_image(ty0 - 1 + ry, tx0 - 1 + rx)) v = floatx4{0.f, 0.f, 0.f, 0.f};
-          store_h4(smem, T, r, n, v);
+          store4<E, H_>(smem + img_at<E>(T, r, n), v, CST(3), n);
         });
     // u2 = ReLU(3x3(t2) + b) + u1 on the tile
     run_step(STEP(4, PT),
@@ -154,47 +166,44 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           const int py = pp / TW, px = pp - py * TW;
           return T.addr((py + th3) * R1W + px + (tap - th3 * 3), cb * 4 + lq);
         },
-        [&](int sub, int n, const floatx4& acc) {
+        [&](int sub, int n, const acc_t& acc) {
           const int pp = sub * 16 + l15;
           if (pp >= PT) return;
           const int py = pp / TW, px = pp - py * TW;
-          const floatx4 v = bias_relu(acc, bias_c + H_, n) + load_h4(smem, U1, (py + 1) * R1W + px + 1, n);
-          store_h4(smem, U2, pp, n, v);
+          const floatx4 v = add_res<E>(act_relu<E, H_>(acc, CST(4), n), smem, U1, (py + 1) * R1W + px + 1, n, p.res_scale[1]);
+          store4<E, H_>(smem + img_at<E>(U2, pp, n), v, CST(4), n);
         });
   }
 
   // ---- last step: y = ReLU(W3 [u | b] + b3) on the tile -> staging image (linear rows) -> HBM ----------------------
-  constexpr int ROWB = 2 * H_ * 2 + 16;  // staged output row: 2h halfs + 16 bytes of padding (bank spread)
+  constexpr int ROWB = 2 * H_ * ESZ + 16;  // staged output row: 2h elements + 16 bytes of padding (bank spread)
   unsigned char* stage = smem + p.off_stage;
-  const float* bias_3 = bias_lds + 2 * H_ * (1 + NB);
-  run_step(STEP(1 + 2 * NB, PT),
+  constexpr int S3 = 1 + 2 * NB;
+  run_step(STEP(S3, PT),
       [&](int sub, auto kc) {
         constexpr int kb = decltype(kc)::value;
         int pp = sub * 16 + l15;
         pp = pp < PT ? pp : PT - 1;
-        if constexpr (kb < HB) {                                  // k-blocks [0, h/32): u
+        if constexpr (kb < HB) {                                  // k-blocks of channels [0, h): u
           return U2.addr(pp, kb * 4 + lq);
-        } else {                                                  // k-blocks [h/32, 2h/32): b = channels [h, 2h) of Y
+        } else {                                                  // k-blocks of channels [h, 2h): b = second half of Y
           const int py = pp / TW, px = pp - py * TW;
-          return Y.addr((py + NB) * R0W + px + NB, H_ / 8 + (kb - HB) * 4 + lq);
+          return Y.addr((py + NB) * R0W + px + NB, H_ / E::CH + (kb - HB) * 4 + lq);
         }
       },
-      [&](int sub, int n, const floatx4& acc) {
+      [&](int sub, int n, const acc_t& acc) {
         const int pp = sub * 16 + l15;
         if (pp >= PT) return;
-        const floatx4 v = bias_relu(acc, bias_3, n);
-        half4 hv;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hv[r] = (half_t)v[r];
-        *reinterpret_cast<half4*>(stage + pp * ROWB + n * 2) = hv;
+        store4<E, 2 * H_>(stage + pp * ROWB + n * ESZ, act_relu<E, 2 * H_>(acc, CST(S3), n), CST(S3), n);
       });
   typedef float vec16 __attribute__((ext_vector_type(4)));  // 16 opaque bytes
-  constexpr int CPR = 2 * H_ * 2 / 16;                      // 16-byte chunks per output pixel
+  constexpr int CPR = 2 * H_ * ESZ / 16;                    // 16-byte chunks per output pixel
+  unsigned char* dst = static_cast<unsigned char*>(p.dst);
   for (int c = threadIdx.x; c < PT * CPR; c += NT) {
     const int pp = c / CPR, ch = c - pp * CPR;
     const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
     if (oy < p.H && ox < p.W)
-      *reinterpret_cast<vec16*>(p.dst + (size_t)(oy * p.W + ox) * p.dst_ld + ch * 8) =
+      *reinterpret_cast<vec16*>(dst + ((size_t)(oy * p.W + ox) * p.dst_ld) * ESZ + ch * 16) =
           *reinterpret_cast<const vec16*>(stage + pp * ROWB + ch * 16);
   }
 
@@ -202,32 +211,29 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
     // ---- tail: lateral 1x1 (model.py:256,259: ConvBlock 2h -> h) on the block's output, still in the staging image,
     //      then nearest x2 upsample (model.py:145-147) in the store: each pixel's h channels go to its 2x2 block ----
     const Img YS = Img{p.off_stage, ROWB / 16, 0, 0};        // the staging image is linear: pitch ROWB, no swizzle
-    constexpr int ROWT = H_ * 2 + 16;
+    constexpr int ROWT = H_ * ESZ + 16;
+    constexpr int S4 = 2 + 2 * NB;
     unsigned char* tout = smem + p.off_tail;
-    const float* bias_t = bias_lds + 2 * H_ * (2 + NB);
-    run_step(STEP(2 + 2 * NB, PT),
+    run_step(STEP(S4, PT),
         [&](int sub, auto kc) {
           int pp = sub * 16 + l15;
           pp = pp < PT ? pp : PT - 1;
           return YS.addr(pp, decltype(kc)::value * 4 + lq);
         },
-        [&](int sub, int n, const floatx4& acc) {
+        [&](int sub, int n, const acc_t& acc) {
           const int pp = sub * 16 + l15;
           if (pp >= PT) return;
-          const floatx4 v = bias_relu(acc, bias_t, n);
-          half4 hv;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) hv[r] = (half_t)v[r];
-          *reinterpret_cast<half4*>(tout + pp * ROWT + n * 2) = hv;
+          store4<E, H_>(tout + pp * ROWT + n * ESZ, act_relu<E, H_>(acc, CST(S4), n), CST(S4), n);
         });
-    constexpr int CPT = H_ * 2 / 16;
-    const size_t px = (size_t)p.dst2_ld, row = (size_t)(2 * p.W) * px;
+    constexpr int CPT = H_ * ESZ / 16;
+    const size_t px = (size_t)p.dst2_ld * ESZ, row = (size_t)(2 * p.W) * px;
+    unsigned char* dst2 = static_cast<unsigned char*>(p.dst2);
     for (int c = threadIdx.x; c < PT * CPT; c += NT) {
       const int pp = c / CPT, ch = c - pp * CPT;
       const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
       if (oy < p.H && ox < p.W) {
         const vec16 v = *reinterpret_cast<const vec16*>(tout + pp * ROWT + ch * 16);
-        half_t* d = p.dst2 + ((size_t)(2 * oy) * (2 * p.W) + 2 * ox) * px + ch * 8;
+        unsigned char* d = dst2 + ((size_t)(2 * oy) * (2 * p.W) + 2 * ox) * px + ch * 16;
         *reinterpret_cast<vec16*>(d) = v;
         *reinterpret_cast<vec16*>(d + px) = v;
         *reinterpret_cast<vec16*>(d + row) = v;
@@ -236,6 +242,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
     }
   }
 #undef STEP
+#undef CST
 }
 
 template <int C>

@@ -14,7 +14,30 @@
 namespace unina {
 namespace dev {
 
-// LDS image: pixel row r owns nch 16-byte chunks (8 fp16 channels each); chunk c lives at slot c ^ ((r >> sh) & mask)
+// Element types of a block kernel. A 1-KiB weight fragment block is 16 rows x 4 chunks of 16 bytes for both:
+//   EltH : fp16, chunk = 8 channels,  block = 32 k, v_mfma_f32_16x16x32_f16, fp32 accumulators
+//   EltI8: int8, chunk = 16 channels, block = 64 k, v_mfma_i32_16x16x64_i8, exact int32 accumulators (INT8 engines)
+typedef int intx4 __attribute__((ext_vector_type(4)));
+struct EltH {
+  static constexpr bool I8 = false;
+  static constexpr int CH = 8, KBLK = 32, ESZ = 2, CM = 1;   // CM: fp32 constants per output channel (bias)
+  typedef half8 frag;
+  typedef floatx4 acc_t;
+  static __device__ __forceinline__ acc_t mma(const frag& a, const frag& b, const acc_t& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+struct EltI8 {
+  static constexpr bool I8 = true;
+  static constexpr int CH = 16, KBLK = 64, ESZ = 1, CM = 3;  // bias | multiplier | 1 / s_out
+  typedef intx4 frag;
+  typedef intx4 acc_t;
+  static __device__ __forceinline__ acc_t mma(const frag& a, const frag& b, const acc_t& c) {
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
+  }
+};
+
+// LDS image: pixel row r owns nch 16-byte chunks (8 fp16 / 16 int8 channels each); chunk c lives at slot c ^ ((r >> sh) & mask)
 // of its row, (sh, mask) chosen from the row pitch so that the 16 pixels of a fragment read hit 16 different bank slots.
 struct Img {
   int base, nch, sh, mask;
@@ -26,7 +49,7 @@ __host__ __device__ constexpr Img make_img(int base, int nch) {
   return (nch % 16 == 0) ? Img{base, nch, 0, 15} : ((nch % 8 == 0) ? Img{base, nch, 1, 7} : Img{base, nch, 2, 3});
 }
 
-// Step table. PLAN provides: N (steps), kb(s) = K/32 weight blocks per channel subtile, ns(s) = output channels / 16,
+// Step table. PLAN provides: N (steps), kb(s) = K/32 (int8: K/64) weight blocks per channel subtile, ns(s) = output channels / 16,
 // wnt(s) = subtiles per wave. Wave roles: waves_n = ns / wnt waves split the channels, waves_m = NW / waves_n split
 // the pixels (those load the same weight blocks: L1 serves the repeats). Every wave works in every step.
 template <typename PLAN, int NW>
@@ -69,12 +92,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // Element G of this wave's flat weight sequence -> queue slot G % D. wbase = stream + this lane's 16 bytes of a block.
-template <typename ST, int D, int G>
-__device__ __forceinline__ void wq_fetch(half8 (&q)[D], const unsigned char* wbase, int wid) {
+template <typename ST, int D, int G, typename FRAG>
+__device__ __forceinline__ void wq_fetch(FRAG (&q)[D], const unsigned char* wbase, int wid) {
   if constexpr (G < ST::total()) {
     constexpr int s = ST::step_of(G), e = G - ST::first(s), wnt = ST::wnt(s), kb = e / wnt, j = e - kb * wnt, ns = ST::ns(s);
     const int nsub = (wid % ST::waves_n(s)) * wnt + j;
-    q[G % D] = *reinterpret_cast<const half8*>(wbase + (size_t)(ST::blk(s) + kb * ns + nsub) * 1024);
+    q[G % D] = *reinterpret_cast<const FRAG*>(wbase + (size_t)(ST::blk(s) + kb * ns + nsub) * 1024);
   }
 }
 
@@ -89,24 +112,26 @@ __device__ __forceinline__ void lds_barrier() {  // publishes this wave's LDS wr
 //                    std::integral_constant) -- the same for all of the wave's channel subtiles
 //   epi(sub, n, acc): consumes channels n..n+3 of pixel sub*16 + (lane & 15)
 // Ends with the barrier that publishes the epilogue's LDS writes.
-template <typename ST, int D, int S, int P, typename BAddr, typename Epi>
-__device__ __forceinline__ void run_step(half8 (&q)[D], const unsigned char* wbase, const unsigned char* smem, int wid,
-                                         int lane, BAddr baddr, Epi epi) {
+template <typename ST, int D, int S, int P, typename E = EltH, typename BAddr, typename Epi>
+__device__ __forceinline__ void run_step(typename E::frag (&q)[D], const unsigned char* wbase, const unsigned char* smem,
+                                         int wid, int lane, BAddr baddr, Epi epi) {
+  typedef typename E::frag frag;
+  typedef typename E::acc_t acc_t;
   constexpr int KB = ST::kb(S), G0 = ST::first(S), WN_T = ST::wnt(S), WVN = ST::waves_n(S), WVM = ST::waves_m(S);
   constexpr int MS = (P + 15) / 16, WM_T = (MS + WVM - 1) / WVM;
   constexpr bool DB = WM_T <= 6;   // B fragments double-buffered in registers when they fit comfortably
   const int wm = wid / WVN, wn = wid % WVN, lq = lane >> 4;
-  floatx4 acc[WN_T][WM_T];
-  half8 b[2][WM_T];
+  acc_t acc[WN_T][WM_T];
+  frag b[2][WM_T];
 #pragma unroll
   for (int i = 0; i < WM_T; ++i) {
 #pragma unroll
-    for (int j = 0; j < WN_T; ++j) acc[j][i] = floatx4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (DB) b[0][i] = *reinterpret_cast<const half8*>(smem + baddr(wm * WM_T + i, std::integral_constant<int, 0>{}));
+    for (int j = 0; j < WN_T; ++j) acc[j][i] = acc_t{0, 0, 0, 0};
+    if constexpr (DB) b[0][i] = *reinterpret_cast<const frag*>(smem + baddr(wm * WM_T + i, std::integral_constant<int, 0>{}));
   }
   static_for<0, KB>([&](auto kc) {
     constexpr int kb = decltype(kc)::value;
-    half8 a[WN_T];
+    frag a[WN_T];
 #pragma unroll
     for (int j = 0; j < WN_T; ++j) a[j] = q[(G0 + kb * WN_T + j) % D];
     static_for<0, WN_T>([&](auto jc) { wq_fetch<ST, D, G0 + kb * WN_T + decltype(jc)::value + D>(q, wbase, wid); });
@@ -114,16 +139,16 @@ __device__ __forceinline__ void run_step(half8 (&q)[D], const unsigned char* wba
       if constexpr (kb + 1 < KB) {
 #pragma unroll
         for (int i = 0; i < WM_T; ++i)
-          b[(kb + 1) & 1][i] = *reinterpret_cast<const half8*>(smem + baddr(wm * WM_T + i, std::integral_constant<int, kb + 1>{}));
+          b[(kb + 1) & 1][i] = *reinterpret_cast<const frag*>(smem + baddr(wm * WM_T + i, std::integral_constant<int, kb + 1>{}));
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < WM_T; ++i) b[kb & 1][i] = *reinterpret_cast<const half8*>(smem + baddr(wm * WM_T + i, kc));
+      for (int i = 0; i < WM_T; ++i) b[kb & 1][i] = *reinterpret_cast<const frag*>(smem + baddr(wm * WM_T + i, kc));
     }
 #pragma unroll
     for (int j = 0; j < WN_T; ++j)
 #pragma unroll
-      for (int i = 0; i < WM_T; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[kb & 1][i], acc[j][i], 0, 0, 0);
+      for (int i = 0; i < WM_T; ++i) acc[j][i] = E::mma(a[j], b[kb & 1][i], acc[j][i]);
   });
 #pragma unroll
   for (int j = 0; j < WN_T; ++j)
@@ -150,23 +175,80 @@ __device__ __forceinline__ floatx4 load_h4(const unsigned char* smem, const Img&
   return floatx4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
 }
 
+// ---- element-generic epilogue pieces (the int8 forms repeat conv_igemm.hip's conv_epilogue operation for operation, so
+// a block kernel and the per-op table give the same codes) ----
+// y = ReLU(acc + bias)  |  ReLU(fma(acc, mult, bias)); `c` = the step's constants in LDS ([bias] | [bias | mult | inv]
+// of NCH channels each)
+template <typename E, int NCH>
+__device__ __forceinline__ floatx4 act_relu(const typename E::acc_t& acc, const float* c, int n) {
+  const floatx4 bias = *reinterpret_cast<const floatx4*>(c + n);
+  floatx4 v;
+  if constexpr (E::I8) {
+    const floatx4 mult = *reinterpret_cast<const floatx4*>(c + NCH + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf((float)acc[r], mult[r], bias[r]);
+  } else {
+    v = acc + bias;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+  return v;
+}
+// v + residual (channels n..n+3 of image row `row`); int8: fma(code, s_res, v)
+template <typename E>
+__device__ __forceinline__ floatx4 add_res(floatx4 v, const unsigned char* smem, const Img& im, int row, int n, float res_scale) {
+  if constexpr (E::I8) {
+    const int rv = *reinterpret_cast<const int*>(smem + im.addr(row, n >> 4) + (n & 15));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf((float)(signed char)(rv >> (8 * r)), res_scale, v[r]);
+    return v;
+  } else {
+    return v + load_h4(smem, im, row, n);
+  }
+}
+// 4 consecutive channels -> memory at `at` (fp16: 8 bytes; int8: q = clamp(rne(v * inv), -127, 127), 4 bytes)
+template <typename E, int NCH>
+__device__ __forceinline__ void store4(unsigned char* at, const floatx4& v, const float* c, int n) {
+  if constexpr (E::I8) {
+    const floatx4 inv = *reinterpret_cast<const floatx4*>(c + 2 * NCH + n);
+    unsigned int q = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t = __builtin_rintf(v[r] * inv[r]);  // round half to even
+      t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
+      q |= ((unsigned int)(int)t & 0xFFu) << (8 * r);
+    }
+    *reinterpret_cast<unsigned int*>(at) = q;
+  } else {
+    half4 hv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hv[r] = (_Float16)v[r];
+    *reinterpret_cast<half4*>(at) = hv;
+  }
+}
+template <typename E>
+__device__ __forceinline__ int img_at(const Img& im, int row, int n) {   // byte address of channel n (multiple of 4) of a row
+  return im.addr(row, n / E::CH) + (n % E::CH) * E::ESZ;
+}
+
 // Input patch -> LDS image by LDS-DMA: 16-byte slot s = (region pixel r of an RH x RW region whose origin is image
 // pixel (y0, x0), chunk cs); out-of-image pixels read the zero page. NT threads; every wave must afterwards wait
 // vmcnt(0) (its own DMAs) and pass a barrier before anyone reads the image.
-template <int RH, int RW, int CIN, int NT>
-__device__ __forceinline__ void load_patch(unsigned char* lds_img, const _Float16* src, int src_ld, int H, int W, int y0,
+template <int RH, int RW, int CIN, int NT, typename E = EltH>
+__device__ __forceinline__ void load_patch(unsigned char* lds_img, const void* src_, int src_ld, int H, int W, int y0,
                                            int x0, const void* zeros, int wid, int lane) {
-  constexpr Img X = make_img(0, CIN / 8);
-  constexpr int nchx = CIN / 8, nslots = RH * RW * nchx;
+  constexpr Img X = make_img(0, CIN / E::CH);
+  constexpr int nchx = CIN / E::CH, nslots = RH * RW * nchx;
+  const unsigned char* src = static_cast<const unsigned char*>(src_);
   for (int s0 = wid * 64; s0 < nslots; s0 += NT) {
     const int s = s0 + lane;
-    const _Float16* g = reinterpret_cast<const _Float16*>(zeros);
+    const unsigned char* g = static_cast<const unsigned char*>(zeros);
     if (s < nslots) {
       const int r = s / nchx, cs = s - r * nchx;
       const int ry = r / RW, rx = r - ry * RW;
       const int iy = y0 + ry, ix = x0 + rx;
       if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-        g = src + (size_t)(iy * W + ix) * src_ld + ((cs ^ X.key(r)) << 3);
+        g = src + ((size_t)(iy * W + ix) * src_ld) * E::ESZ + ((cs ^ X.key(r)) << 4);
     }
     glds16(g, lds_img + s0 * 16);
   }

@@ -36,23 +36,25 @@ using namespace dev;
 
 extern __shared__ __align__(16) unsigned char c3_smem[];
 
-template <int H_, int TH, int TW, int NB, int CIN, int NW, int D, int TAIL = 0>
+template <int H_, int TH, int TW, int NB, int CIN, int NW, int D, int TAIL = 0, typename E = EltH>
 __global__ __launch_bounds__(NW * 64) void c3k2_fused_kernel(const C3k2Params p) {
-  c3k2_fused_body<H_, TH, TW, NB, CIN, NW, D, TAIL>(p, (int)blockIdx.x, c3_smem);
+  c3k2_fused_body<H_, TH, TW, NB, CIN, NW, D, TAIL, E>(p, (int)blockIdx.x, c3_smem);
 }
 
 // ------------------------------------------------------------------------------------------------- host side
 namespace {
 
 struct Class {
-  int hid, nb, cin, tail, th, tw, nw;
+  int dtype, hid, nb, cin, tail, th, tw, nw;
   const char* name;
   void (*fn)(const C3k2Params);
 };
 #define C3K2(H_, TH, TW, NB, CIN, NW, D) \
-  {H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0>}
+  {kF16, H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0>}
 #define C3K2T(H_, TH, TW, NB, CIN, NW, D) \
-  {H_, NB, CIN, 1, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,lat>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 1>}
+  {kF16, H_, NB, CIN, 1, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,lat>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 1>}
+#define C3K2I(H_, TH, TW, NB, CIN, NW, D) \
+  {kI8, H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0, EltI8>}
 const Class kClasses[] = {
     // Tiles chosen by end-to-end A/B at 640^2: twice the workgroups of the first choice (8x16 / 8x8 / 4x8) cost more
     // halo recompute but cut the serial frame by ~10 us at equal throughput; one step smaller still (4x8 / 4x4 / 4x4)
@@ -67,12 +69,20 @@ const Class kClasses[] = {
     C3K2(128, 4, 4, 1, 384, 8, 16),    // neck.pan_c3k2_2
     C3K2(128, 4, 4, 1, 512, 8, 16),    // graph (B) fpn_c3k2_1 (qat.py:397)
     C3K2T(128, 4, 4, 1, 512, 8, 16),   // graph (B) fpn_c3k2_1 + lateral_p3
+    // INT8 engines: the blocks whose tensors are all int8 (h = 32 blocks touch the fp16 carve-outs: train.py:779)
+    C3K2I(64, 4, 8, 2, 128, 8, 8),     // backbone.stage2_c3k2
+    C3K2I(64, 4, 8, 1, 256, 8, 8),     // neck.fpn_c3k2_1
+    C3K2I(64, 4, 8, 1, 192, 8, 8),     // neck.pan_c3k2_1
+    C3K2I(128, 4, 4, 2, 256, 8, 8),    // backbone.stage3_c3k2
+    C3K2I(128, 4, 4, 1, 384, 8, 8),    // neck.pan_c3k2_2
+    C3K2I(128, 4, 4, 1, 512, 8, 8),    // graph (B) fpn_c3k2_1
 };
 #undef C3K2
 #undef C3K2T
-const Class* find_class(int hid, int nb, int cin, int tail) {
+#undef C3K2I
+const Class* find_class(int hid, int nb, int cin, int tail, int dtype) {
   for (const Class& c : kClasses)
-    if (c.hid == hid && c.nb == nb && c.cin == cin && c.tail == tail) return &c;
+    if (c.dtype == dtype && c.hid == hid && c.nb == nb && c.cin == cin && c.tail == tail) return &c;
   return nullptr;
 }
 constexpr int kMaxLds = 160 * 1024;
@@ -88,26 +98,28 @@ hipError_t c3k2_init() {
   return hipSuccess;
 }
 
-bool c3k2_supported(int hid, int nb, int cin, int tail) {
+bool c3k2_supported(int hid, int nb, int cin, int tail, int dtype) {
   C3k2Params p;
   memset(&p, 0, sizeof p);
+  p.dtype = dtype;
   p.hid = hid; p.nb = nb; p.Cin = cin; p.tail = tail; p.H = p.W = 64;
   return c3k2_layout(&p);
 }
 
 // Fills tile geometry and the LDS layout of `p` (needs hid, nb, Cin, H, W). False = no such class / no fit.
 bool c3k2_layout(C3k2Params* p) {
-  const Class* c = find_class(p->hid, p->nb, p->Cin, p->tail);
+  const Class* c = find_class(p->hid, p->nb, p->Cin, p->tail, p->dtype);
   if (!c) return false;
   const int h = p->hid, nb = p->nb;
+  const int esz = p->dtype == kI8 ? 1 : 2, cm = p->dtype == kI8 ? 3 : 1;
   const int p0 = (c->th + 2 * nb) * (c->tw + 2 * nb), p1 = (c->th + 2) * (c->tw + 2), pt = c->th * c->tw;
   p->tiles_x = (p->W + c->tw - 1) / c->tw;
   p->tiles_y = (p->H + c->th - 1) / c->th;
   p->tiles_x_magic = div_magic((unsigned)p->tiles_x);
-  p->n_bias = 2 * h * (2 + nb) + (p->tail ? h : 0);
-  const int x_bytes = align_up(p0 * p->Cin * 2, 1024) + 1024;  // the last patch DMA instruction may overrun by < 1 KiB
-  const int t_bytes = p0 * h * 2, u1_bytes = nb == 2 ? p1 * h * 2 : 0, u2_bytes = pt * h * 2;
-  const int stage_bytes = pt * (2 * h * 2 + 16);
+  p->n_bias = cm * (2 * h * (2 + nb) + (p->tail ? h : 0));
+  const int x_bytes = align_up(p0 * p->Cin * esz, 1024) + 1024;  // the last patch DMA instruction may overrun by < 1 KiB
+  const int t_bytes = p0 * h * esz, u1_bytes = nb == 2 ? p1 * h * esz : 0, u2_bytes = pt * h * esz;
+  const int stage_bytes = pt * (2 * h * esz + 16);
   // region A: the input patch; once step 0 has consumed it, t (and later the output staging tile), u1 and u2 live there
   const int head = t_bytes > stage_bytes ? t_bytes : stage_bytes;
   const int a_need = align_up(head, 16) + align_up(u1_bytes, 16) + align_up(u2_bytes, 16);
@@ -122,7 +134,7 @@ bool c3k2_layout(C3k2Params* p) {
   off += align_up(a_bytes, 1024);
   p->off_y = off;
   p->off_tail = off;                                          // the tail's output tile replaces a | b (dead after cv3)
-  const int y_bytes = p0 * 2 * h * 2, tail_bytes = p->tail ? pt * (h * 2 + 16) : 0;
+  const int y_bytes = p0 * 2 * h * esz, tail_bytes = p->tail ? pt * (h * esz + 16) : 0;
   off += align_up(y_bytes > tail_bytes ? y_bytes : tail_bytes, 1024);
   p->smem_bytes = off;
   return off <= kMaxLds;
@@ -131,12 +143,12 @@ bool c3k2_layout(C3k2Params* p) {
 // Packs the weights of a block's convs (each given as the exporter's [n/16][K/32] 1-KiB fragment blocks, up to two
 // output slices) into the stream the block kernels read: per conv, k-block-major [K/32][N/16] blocks (the wave that
 // owns subtile j of step s reads blocks blk(s) + kb*ns + j, kb = 0..), and concatenates the biases.
-void block_pack(const C3k2Conv* convs, int nconv, std::vector<unsigned char>* stream, std::vector<float>* bias) {
+void block_pack(const C3k2Conv* convs, int nconv, std::vector<unsigned char>* stream, std::vector<float>* bias, int dtype) {
   stream->clear();
   bias->clear();
   for (int ci = 0; ci < nconv; ++ci) {
     const C3k2Conv& cv = convs[ci];
-    const int ns = (cv.n[0] + cv.n[1]) / 16, kbn = cv.K / 32;
+    const int ns = (cv.n[0] + cv.n[1]) / 16, kbn = cv.K / (dtype == kI8 ? 64 : 32);
     const size_t base = stream->size();
     stream->resize(base + (size_t)kbn * ns * 1024, 0);
     for (int kb = 0; kb < kbn; ++kb)
@@ -147,42 +159,50 @@ void block_pack(const C3k2Conv* convs, int nconv, std::vector<unsigned char>* st
       }
     for (int seg = 0; seg < 2; ++seg)
       for (int i = 0; i < cv.n[seg]; ++i) bias->push_back(cv.bias[seg][i]);
+    if (dtype == kI8) {   // [bias | mult | 1/s_out] per conv (block_pipeline.h act_relu / store4)
+      for (int seg = 0; seg < 2; ++seg)
+        for (int i = 0; i < cv.n[seg]; ++i) bias->push_back(cv.mult[seg][i]);
+      for (int seg = 0; seg < 2; ++seg)
+        for (int i = 0; i < cv.n[seg]; ++i) bias->push_back(cv.out_inv[seg]);
+    }
   }
 }
 
 // C3k2 convs in execution order: cv1|cv2, {b.cv1, b.cv2} x nb, cv3.
-bool c3k2_pack(int hid, int nb, int cin, int tail, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias) {
-  if (!find_class(hid, nb, cin, tail)) return false;
+bool c3k2_pack(int hid, int nb, int cin, int tail, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias,
+               int dtype) {
+  if (!find_class(hid, nb, cin, tail, dtype)) return false;
   const int ncv3 = 1 + 2 * nb, nconv = 2 + 2 * nb + (tail ? 1 : 0);
   for (int ci = 0; ci < nconv; ++ci) {
     const C3k2Conv& cv = convs[ci];
     const int want_n = (ci == 0 || ci == ncv3) ? 2 * hid : hid;
     const int want_k = ci == 0 ? cin : (ci >= ncv3 ? 2 * hid : ((ci & 1) ? hid : 9 * hid));
     if (cv.n[0] + cv.n[1] != want_n || cv.K != want_k || cv.n[0] % 16 || cv.n[1] % 16) return false;
+    if (dtype == kI8 && (!cv.mult[0] || (cv.n[1] && !cv.mult[1]))) return false;
   }
-  block_pack(convs, nconv, stream, bias);
+  block_pack(convs, nconv, stream, bias, dtype);
   return true;
 }
 
 hipError_t c3k2_launch(const C3k2Params& p, hipStream_t stream) {
-  const Class* c = find_class(p.hid, p.nb, p.Cin, p.tail);
+  const Class* c = find_class(p.hid, p.nb, p.Cin, p.tail, p.dtype);
   if (!c) return hipErrorInvalidValue;
   hipLaunchKernelGGL(c->fn, dim3(p.tiles_x * p.tiles_y, 1, 1), dim3(c->nw * 64, 1, 1), p.smem_bytes, stream, p);
   return hipGetLastError();
 }
 
 bool c3k2_tile_is(const C3k2Params& p, int th, int tw) {
-  const Class* c = find_class(p.hid, p.nb, p.Cin, p.tail);
+  const Class* c = find_class(p.hid, p.nb, p.Cin, p.tail, p.dtype);
   return c && c->th == th && c->tw == tw;
 }
 
-const char* c3k2_kernel_name(int hid, int nb, int cin, int tail) {
-  const Class* c = find_class(hid, nb, cin, tail);
+const char* c3k2_kernel_name(int hid, int nb, int cin, int tail, int dtype) {
+  const Class* c = find_class(hid, nb, cin, tail, dtype);
   return c ? c->name : "c3k2_fused<?>";
 }
 
-int c3k2_block_threads(int hid, int nb, int cin, int tail) {
-  const Class* c = find_class(hid, nb, cin, tail);
+int c3k2_block_threads(int hid, int nb, int cin, int tail, int dtype) {
+  const Class* c = find_class(hid, nb, cin, tail, dtype);
   return c ? c->nw * 64 : 0;
 }
 

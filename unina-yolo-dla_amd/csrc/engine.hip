@@ -425,13 +425,19 @@ int plan(unina_engine* e) {
     const Buffer& dst = e->bufs[z.seg[0].dst_buf];
     C3k2Params& f = op.fp;
     memset(&f, 0, sizeof f);
-    f.src = static_cast<const half_t*>(src.ptr) + a.seg[0].src_coff;
+    f.dtype = act_dtype_of(src.d.dtype);
+    const size_t fesz = dtype_size(f.dtype);
+    f.src = static_cast<const char*>(src.ptr) + a.seg[0].src_coff * fesz;
     f.src_ld = (int)src.d.c;
     f.Cin = (int)a.cin;
     f.H = (int)a.in_h;
     f.W = (int)a.in_w;
-    f.dst = static_cast<half_t*>(dst.ptr) + z.seg[0].dst_coff;
+    f.dst = static_cast<char*>(dst.ptr) + z.seg[0].dst_coff * fesz;
     f.dst_ld = (int)dst.d.c;
+    for (int b = 0; b < op.nb; ++b) {   // int8: scale of each bottleneck's shortcut tensor (the 3x3's residual buffer)
+      const OpDesc& c2 = e->ops[i + 2 + 2 * b].d;
+      f.res_scale[b] = c2.res_buf >= 0 ? e->bufs[c2.res_buf].d.scale : 1.0f;
+    }
     f.wstream = reinterpret_cast<const unsigned char*>(blob + op.stream_off);
     f.bias = reinterpret_cast<const float*>(blob + op.fbias_off);
     f.zeros = e->d_zeros;
@@ -441,7 +447,7 @@ int plan(unina_engine* e) {
       const SegDesc& ts = e->ops[op.tail_op].d.seg[0];
       const Buffer& tb = e->bufs[ts.dst_buf];
       f.tail = 1;
-      f.dst2 = static_cast<half_t*>(tb.ptr) + ts.dst_coff;
+      f.dst2 = static_cast<char*>(tb.ptr) + ts.dst_coff * fesz;
       f.dst2_ld = (int)tb.d.c;
     }
     if (!c3k2_layout(&f)) return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: fused C3k2 block does not fit", i);
@@ -451,7 +457,7 @@ int plan(unina_engine* e) {
     const int last_op = op.tail_op >= 0 ? op.tail_op : op.group_last;
     for (int k = (int)i; k <= last_op; ++k) {
       flops += e->ops[k].info.flops;
-      wbytes += 2.0 * e->ops[k].info.n * e->ops[k].info.k + 4.0 * e->ops[k].info.n;
+      wbytes += (double)fesz * e->ops[k].info.n * e->ops[k].info.k + 4.0 * e->ops[k].info.n;
       if (k > (int)i) {
         unina_op_info& ai = e->ops[k].info;
         ai.flops = 0;
@@ -461,13 +467,13 @@ int plan(unina_engine* e) {
       }
     }
     info.flops = flops;
-    info.bytes = 2.0 * f.H * f.W * f.Cin + wbytes + 2.0 * f.H * f.W * 2 * f.hid +   // input once, weights once, output once
-                 (f.tail ? 2.0 * 4 * f.H * f.W * f.hid : 0.0);                        // (+ the up-sampled lateral output)
+    info.bytes = (double)fesz * f.H * f.W * f.Cin + wbytes + (double)fesz * f.H * f.W * 2 * f.hid +   // input once, weights once, output once
+                 (f.tail ? (double)fesz * 4 * f.H * f.W * f.hid : 0.0);                                // (+ the up-sampled lateral output)
     info.n = 2 * f.hid;
     info.k = 0;
     info.grid = f.tiles_x * f.tiles_y;
-    info.block = c3k2_block_threads(f.hid, f.nb, f.Cin, f.tail);
-    snprintf(info.kernel, sizeof info.kernel, "%s", c3k2_kernel_name(f.hid, f.nb, f.Cin, f.tail));
+    info.block = c3k2_block_threads(f.hid, f.nb, f.Cin, f.tail, f.dtype);
+    snprintf(info.kernel, sizeof info.kernel, "%s", c3k2_kernel_name(f.hid, f.nb, f.Cin, f.tail, f.dtype));
     snprintf(info.name, sizeof info.name, "%.*s[c3k2 x%d]", (int)(strchr(a.name, '+') ? strchr(a.name, '+') - a.name - 4 : 60), a.name, f.nb);
   }
   // dual launches: pair independent convs of one kernel family (the P3 / P4 head layers) into one grid each. The later
@@ -503,7 +509,7 @@ int plan(unina_engine* e) {
         a.info.flops += b.info.flops;
         a.info.bytes += b.info.bytes;
         a.info.grid += b.info.grid;
-        snprintf(a.info.kernel, sizeof a.info.kernel, "%s", block_dual_name());
+        snprintf(a.info.kernel, sizeof a.info.kernel, "%s", block_dual_name(a.fp.dtype));
         b.info.flops = 0;
         b.info.bytes = 0;
         b.info.grid = 0;
@@ -674,10 +680,10 @@ int capture(unina_engine* e) {
 // [cv3 (1x1 over the concat buffer)]. This recognises that shape in the op table (structurally: buffers, slices and
 // residual wiring must match exactly, and no op outside the group may read the group's intermediates), packs the
 // group's weights into the stage stream of c3k2_fused.hip and appends it to the (host copy of the) blob.
-bool is_plain_conv(const OpDesc& d, uint32_t k, uint32_t nseg) {
+bool is_plain_conv(const OpDesc& d, uint32_t k, uint32_t nseg, bool int8 = false) {
   if (d.kind != kOpConv || d.ksize != k || d.stride != 1 || !d.relu || d.nseg != nseg) return false;
   for (uint32_t s = 0; s < nseg; ++s)
-    if (d.seg[s].flags || d.seg[s].m_off || d.seg[s].n_pad != d.seg[s].n_count) return false;
+    if (d.seg[s].flags || (d.seg[s].m_off != 0) != int8 || d.seg[s].n_pad != d.seg[s].n_count) return false;
   return true;
 }
 
@@ -685,10 +691,16 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
   const size_t n = e->ops.size();
   for (size_t i = 0; i + 3 < n; ++i) {
     const OpDesc& a = e->ops[i].d;
-    if (!is_plain_conv(a, 1, 2) || a.res_buf >= 0) continue;
+    // fp16 block, or (INT8 engines) a block whose input, output and intermediates are all int8 code tensors
+    const uint32_t bdt = e->bufs[a.src_buf].d.dtype;
+    if (bdt != kBufF16Nhwc && bdt != kBufI8Nhwc) continue;
+    const bool i8 = bdt == kBufI8Nhwc;
+    const int dt = i8 ? kI8 : kF16;
+    const uint32_t al = i8 ? 16 : 8;   // channels per 16-byte chunk
+    if (!is_plain_conv(a, 1, 2, i8) || a.res_buf >= 0) continue;
     const uint32_t h = a.seg[0].n_count;
     if (a.seg[1].n_count != h || a.seg[0].src_coff != a.seg[1].src_coff) continue;
-    if (e->bufs[a.src_buf].d.dtype != kBufF16Nhwc) continue;
+    if (a.seg[0].src_coff % al || e->bufs[a.src_buf].d.c % al) continue;
     // bottlenecks
     uint32_t cur_buf = a.seg[0].dst_buf, cur_coff = a.seg[0].dst_coff;
     size_t j = i + 1;
@@ -697,7 +709,7 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     while (j + 1 < n && nb < 2) {
       const OpDesc& c1 = e->ops[j].d;
       const OpDesc& c2 = e->ops[j + 1].d;
-      if (!is_plain_conv(c1, 1, 1) || !is_plain_conv(c2, 3, 1)) break;
+      if (!is_plain_conv(c1, 1, 1, i8) || !is_plain_conv(c2, 3, 1, i8)) break;
       if (c1.res_buf >= 0 || c1.cin != h || c1.seg[0].n_count != h || c1.src_buf != cur_buf || c1.seg[0].src_coff != cur_coff) break;
       if (c2.cin != h || c2.seg[0].n_count != h || c2.src_buf != c1.seg[0].dst_buf || c2.seg[0].src_coff != c1.seg[0].dst_coff) break;
       if (c2.res_buf != (int)cur_buf || c2.res_coff != (int)cur_coff) break;
@@ -710,15 +722,15 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     }
     if (nb < 1 || j >= n) continue;
     const OpDesc& z = e->ops[j].d;  // cv3 over [last bottleneck | cv2]
-    if (!is_plain_conv(z, 1, 1) || z.res_buf >= 0 || z.cin != 2 * h || z.seg[0].n_count != 2 * h) continue;
+    if (!is_plain_conv(z, 1, 1, i8) || z.res_buf >= 0 || z.cin != 2 * h || z.seg[0].n_count != 2 * h) continue;
     if (z.src_buf != cur_buf || z.src_buf != a.seg[1].dst_buf || cur_coff != z.seg[0].src_coff || a.seg[1].dst_coff != cur_coff + h) continue;
-    if (e->bufs[z.seg[0].dst_buf].d.dtype != kBufF16Nhwc || z.seg[0].dst_coff % 8 || e->bufs[z.seg[0].dst_buf].d.c % 8) continue;
+    if (e->bufs[z.seg[0].dst_buf].d.dtype != bdt || z.seg[0].dst_coff % al || e->bufs[z.seg[0].dst_buf].d.c % al) continue;
     if (a.in_h != z.out_h || a.in_w != z.out_w) continue;
-    if (!c3k2_supported((int)h, nb, (int)a.cin)) continue;
+    if (!c3k2_supported((int)h, nb, (int)a.cin, 0, dt)) continue;
     // an FPN block is followed by its lateral conv (model.py:256,259: ConvBlock 1x1, 2h -> h) whose store does the
     // nearest x2 upsample: it becomes the block kernel's last step when that class exists
     size_t jt = j;   // last op of the group incl. the tail
-    if (j + 1 < n) {
+    if (j + 1 < n && !i8) {
       const OpDesc& t = e->ops[j + 1].d;
       if (t.kind == kOpConv && t.ksize == 1 && t.stride == 1 && t.relu && t.nseg == 1 && t.res_buf < 0 && t.seg[0].flags == kSegUp2 &&
           !t.seg[0].m_off && t.seg[0].n_pad == t.seg[0].n_count && t.cin == 2 * h && t.seg[0].n_count == h &&
@@ -730,7 +742,7 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     // the group's intermediates must be private to it, and must not be its own input or output
     bool priv = true;
     for (uint32_t b : inter) {
-      if (e->bufs[b].d.dtype != kBufF16Nhwc) priv = false;   // (an INT8 engine's fp16 conv may still write an int8 buffer)
+      if (e->bufs[b].d.dtype != bdt) priv = false;   // (an INT8 engine's fp16 conv may still write an int8 buffer)
       if (b == a.src_buf || b == z.seg[0].dst_buf || (e->bufs[b].d.flags & (kBufInput | kBufOutput))) priv = false;
       for (size_t k = 0; k < n && priv; ++k) {
         if (k >= i && k <= j) continue;
@@ -751,13 +763,17 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
         cv.w[s] = reinterpret_cast<const unsigned char*>(blob->data() + o.seg[s].w_off);
         cv.bias[s] = reinterpret_cast<const float*>(blob->data() + o.seg[s].b_off);
         cv.n[s] = (int)o.seg[s].n_count;
+        if (i8) {
+          cv.mult[s] = reinterpret_cast<const float*>(blob->data() + o.seg[s].m_off);
+          cv.out_inv[s] = 1.0f / e->bufs[o.seg[s].dst_buf].d.scale;   // as plan() computes ConvSeg::out_inv_scale
+        }
       }
       cv.K = (int)(o.ksize * o.ksize * o.cin);
       convs.push_back(cv);
     }
     std::vector<unsigned char> stream;
     std::vector<float> bias;
-    if (!c3k2_pack((int)h, nb, (int)a.cin, jt > j ? 1 : 0, convs.data(), &stream, &bias)) continue;
+    if (!c3k2_pack((int)h, nb, (int)a.cin, jt > j ? 1 : 0, convs.data(), &stream, &bias, dt)) continue;
     blob->resize((blob->size() + 255) & ~(size_t)255);
     const uint64_t so = blob->size();
     blob->insert(blob->end(), stream.begin(), stream.end());
@@ -1146,8 +1162,8 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   }
   if (e->images_buf < 0) return bail(UNINA_ERR_FORMAT, "engine file lacks the images input buffer");
 
-  // fusable C3k2 groups (fp16 engines): their packed weight streams are appended to the blob before upload
-  // (the matchers only accept all-fp16 groups: in an INT8 engine that is the carved-out P2 head, train.py:779)
+  // fusable groups: their packed weight streams are appended to the blob before upload. The matchers accept all-fp16
+  // groups (in an INT8 engine: the carved-out P2 head, train.py:779) and, for C3k2 blocks, all-int8 groups
   if (e->h.precision == kFp16 || e->h.precision == kInt8) {
     find_c3k2_groups(e, &blob);
     find_head_groups(e, &blob);

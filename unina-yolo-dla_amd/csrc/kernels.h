@@ -90,20 +90,23 @@ hipError_t conv_dual_launch(int kind, const ConvParams& a, const ConvParams& b, 
 
 // ------------------------------------------------------------------------------------------------
 // Fused C3k2 block (model.py:76-110): cv1|cv2 -> n x Bottleneck(1x1, 3x3 + shortcut) -> cv3 in ONE launch, all
-// intermediates in LDS (c3k2_fused.hip). fp16 engines only.
+// intermediates in LDS (c3k2_fused.hip). dtype kF16: fp16 blocks; kI8 (INT8 engines): blocks whose input, output and
+// every intermediate tensor are int8 codes -- same per-tensor scales and epilogue arithmetic as the per-op table.
 // ------------------------------------------------------------------------------------------------
 struct C3k2Params {
-  const half_t* src;             // block input, channel offset applied
+  int dtype;                     // kF16 or kI8: element type of src, dst and every tensor in between
+  const void* src;               // block input, channel offset applied
   int src_ld, Cin;
   int H, W;                      // spatial size (input == output)
-  half_t* dst;                   // block output (cv3), channel offset applied
+  void* dst;                     // block output (cv3), channel offset applied
   int dst_ld;
   const unsigned char* wstream;  // every conv's weight blocks in consumption order (c3k2_pack)
-  const float* bias;             // concatenated folded biases, same order
+  const float* bias;             // per-step constants, same order: fp16 [bias(n)]; int8 [bias(n) | mult(n) | 1/s_out(n)]
   const void* zeros;             // >= 16 bytes of zeros in HBM
   int hid, nb;                   // hidden width h = Cout/2, number of bottlenecks
+  float res_scale[2];            // int8: scale of each bottleneck's shortcut tensor
   int tail;                      // 1: the lateral 1x1 conv (2h -> h) + nearest x2 upsample that follows runs as a last step
-  half_t* dst2;                  // tail output (2H x 2W pixels), channel offset applied
+  void* dst2;                    // tail output (2H x 2W pixels), channel offset applied
   int dst2_ld;
   // filled by c3k2_layout():
   int n_bias;
@@ -112,22 +115,25 @@ struct C3k2Params {
   int off_bias, off_x, off_y, off_t, off_u1, off_u2, off_stage, off_tail, smem_bytes;   // LDS layout (bytes)
 };
 struct C3k2Conv {                // one conv of the block as the exporter stored it (host pointers)
-  const unsigned char* w[2];     // packed 1-KiB fragment blocks [n/16][K/32] per output slice (slice 1 only for cv1|cv2)
+  const unsigned char* w[2];     // packed 1-KiB fragment blocks [n/16][K/32 | K/64] per output slice (slice 1 only for cv1|cv2)
   const float* bias[2];
+  const float* mult[2];          // int8: per-channel multipliers (SegDesc::m_off)
+  float out_inv[2];              // int8: 1 / scale of the slice's destination tensor
   int n[2];                      // output channels per slice (multiples of 16)
   int K;                         // ksize*ksize*cin
 };
 hipError_t c3k2_init();
 bool c3k2_layout(C3k2Params* p);
-bool c3k2_supported(int hid, int nb, int cin, int tail = 0);
-bool c3k2_pack(int hid, int nb, int cin, int tail, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias);
+bool c3k2_supported(int hid, int nb, int cin, int tail = 0, int dtype = kF16);
+bool c3k2_pack(int hid, int nb, int cin, int tail, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias,
+               int dtype = kF16);
 hipError_t c3k2_launch(const C3k2Params& p, hipStream_t stream);
-const char* c3k2_kernel_name(int hid, int nb, int cin, int tail = 0);
-int c3k2_block_threads(int hid, int nb, int cin, int tail = 0);
+const char* c3k2_kernel_name(int hid, int nb, int cin, int tail = 0, int dtype = kF16);
+int c3k2_block_threads(int hid, int nb, int cin, int tail = 0, int dtype = kF16);
 
 // Generic packer of the block kernels' weight stream: per conv, k-block-major [K/32][N/16] 1-KiB blocks (slice 0's
 // channel subtiles first), then the concatenated biases (n entries per slice).
-void block_pack(const C3k2Conv* convs, int nconv, std::vector<unsigned char>* stream, std::vector<float>* bias);
+void block_pack(const C3k2Conv* convs, int nconv, std::vector<unsigned char>* stream, std::vector<float>* bias, int dtype = kF16);
 
 // ------------------------------------------------------------------------------------------------
 // Fused DetectionHead (model.py:274-303): cls.0|reg.0 (3x3) -> cls.1|reg.1 (grouped 3x3) -> cls.2|reg.2 (grouped 1x1,
@@ -159,7 +165,7 @@ int head_block_threads(int c);
 // A fused C3k2 block and a fused head that do not depend on each other, side by side in one grid (block_dual.hip).
 hipError_t block_dual_init();
 bool block_dual_match(const C3k2Params& pc, const HeadParams& ph);
-const char* block_dual_name();
+const char* block_dual_name(int dtype = kF16);
 hipError_t block_dual_launch(const C3k2Params& pc, const HeadParams& ph, hipStream_t stream, int* grid_out = nullptr);
 bool c3k2_tile_is(const C3k2Params& p, int th, int tw);    // the tile the layout of `p` was computed for
 bool head_tile_is(const HeadParams& p, int th, int tw);
