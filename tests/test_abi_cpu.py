@@ -126,9 +126,9 @@ def test_c3k2_groups_are_recognised_at_load(lib, pkg, sd7, tmp_path):
     assert lib.unina_debug_fusable_groups(path.encode()) == 7
     assert lib.unina_debug_fusable_groups(b"/nonexistent.une") == -1
     # INT8 engine file: the five blocks whose tensors are all int8 (stage2/3, fpn_c3k2_1, pan_c3k2_1/2) as int8 block
-    # kernels + the carved-out fp16 P2 head; the h = 32 blocks touch the fp16 carve-outs (train.py:779) and stay per-op
+    # kernels, the two h = 32 blocks (fp16 by builder choice) and the carved-out P2 head (train.py:779) as fp16 ones
     from emulate import run_op_table
     b16 = export.EngineBuilder(sd7, g)
     amax = export.calibrate(run_op_table(b16, pkg.rng.frame(5000 + i, 64, 64))[1] for i in range(2))
     export.export_engine(sd7, path, g, precision=export.INT8, amax=amax)
-    assert lib.unina_debug_fusable_groups(path.encode()) == 6
+    assert lib.unina_debug_fusable_groups(path.encode()) == 8

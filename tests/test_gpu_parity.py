@@ -420,7 +420,7 @@ def test_int8_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
     amax = calibrate_amax(sd7, g, [pkg.rng.frame(5000 + i, size, size) for i in range(2)])
     e = Engine.from_state_dict(sd7, g, precision=export.INT8, amax=amax)
     try:
-        assert e.L.unina_fusion_groups(e.h) == 6              # 5 int8 blocks + the carved-out fp16 P2 head
+        assert e.L.unina_fusion_groups(e.h) == 8              # 5 int8 blocks + the 2 narrow fp16 blocks + the fp16 P2 head
         x = _frame(pkg, torch_cuda, 1234, size)
         fused = {k: v.copy() for k, v in e.forward(x).items()}
         bufs = ("neck.cat_fpn1", "neck.cat_pan1", "neck.cat_pan2", "p3_out", "p4_out")
@@ -436,7 +436,7 @@ def test_int8_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
             assert np.array_equal(fused_bufs[b], e.read_buffer(b)), b
         for k in plain:
             assert np.array_equal(fused[k], plain[k]), k
-        assert e.set_fusion(True) == 6
+        assert e.set_fusion(True) == 8
         d1 = e.infer(x, 0.5, 0.45, 0.1)
         e.set_fusion(False)
         d0 = e.infer(x, 0.5, 0.45, 0.1)

@@ -148,7 +148,8 @@ def test_int8_engine_table_from_a_qat_checkpoint(pkg, sd7b, oracle_mod, osd7b, t
         if op.kind == export.OP_CONV:
             carve = any(sg.module.startswith(c) for sg in op.segs for c in ("stem", "stage1_conv", "head_p2"))
             final = any(sg.module.endswith(".2") for sg in op.segs)
-            assert q == (not carve and not final and op.cin % 64 == 0), op.name
+            narrow = any(sg.module.startswith(c) for sg in op.segs for c in ("stage1_c3k2.", "fpn_c3k2_3.", "stage2_conv"))   # fp16 by builder choice (export.py _quantize_pass)
+            assert q == (not carve and not final and not narrow and op.cin % 64 == 0), op.name
     x = pkg.rng.frame(1234, 64, 64)
     o8, _ = run_op_table(b8, x)
     ref = oracle_mod.forward(osd7b, x, variant="B")

@@ -42,8 +42,9 @@ def test_lite_p2_op_table(pkg, oracle_mod):
 
 
 def test_int8_pass_structure_and_drift(pkg, sd7, oracle_mod, oracle_sd7):
-    """INT8 engine table on CPU: the reference's FP16 carve-outs are honoured (train.py:779), the buffer typing is
-    consistent, and the emulated integer arithmetic stays within PTQ-typical drift of the fp32 oracle."""
+    """INT8 engine table on CPU: the reference's FP16 carve-outs are honoured (train.py:779), the narrow (h = 32) C3k2
+    blocks and the conv sharing their concat buffer stay fp16 as a builder choice (export.py _quantize_pass), the buffer
+    typing is consistent, and the emulated integer arithmetic stays within PTQ-typical drift of the fp32 oracle."""
     from unina_yolo_dla_amd import export
     from emulate import run_op_table
     g = pkg.graph.Graph(in_h=64, in_w=64)
@@ -55,10 +56,11 @@ def test_int8_pass_structure_and_drift(pkg, sd7, oracle_mod, oracle_sd7):
             continue
         carve = any(sg.module.startswith(c) for sg in op.segs for c in export.INT8_CARVE_OUT)
         final = any(sg.module.endswith(".2") for sg in op.segs)
-        assert q == (not carve and not final and op.cin % 64 == 0), op.name
+        narrow = any(sg.module.startswith(c) for sg in op.segs for c in ("backbone.stage1_block.", "neck.fpn_c3k2_2.", "backbone.stage2_conv"))
+        assert q == (not carve and not final and not narrow and op.cin % 64 == 0), op.name
         src_dt = b8.buffers[op.src_buf][4]
         assert src_dt == (export.BUF_I8 if q else export.BUF_F16), op.name        # int8 ops read int8, fp16 ops fp16
-    assert sum(b8.op_int8) == 40 and sum(o.kind == export.OP_QUANT for o in b8.ops) == 1
+    assert sum(b8.op_int8) == 35 and sum(o.kind == export.OP_QUANT for o in b8.ops) == 1
     x = pkg.rng.frame(1234, 64, 64)
     o8, _ = run_op_table(b8, x)
     ref = oracle_mod.forward(oracle_sd7, x)

@@ -404,6 +404,12 @@ class EngineBuilder:
         * an op runs in int8 iff it is a BN conv of a module outside the reference's FP16 carve-outs
           (train.py:779) whose Cin is a multiple of the int8 MFMA block (64). The head's output convs are plain
           nn.Conv2d in the reference's QAT graph (qat.py:416,421: unquantised) -> fp16.
+        * precision is a per-layer builder choice, as in the reference's TensorRT build (export_trt.py:432-441 sets
+          the INT8 flag without precision constraints, so the builder keeps a layer in float where that is faster):
+          a C3k2 block whose bottlenecks cannot be int8 (hidden width 32 < one int8 MFMA block) runs in fp16 as a
+          whole -- alternating types inside it costs more than int8 saves and loses the one-launch block kernel --
+          and so does a conv that shares a multi-writer concat buffer with fp16 readers (an int8 twin of a buffer
+          that is written in several places would need several QUANT passes).
         * a buffer is int8 iff every op that reads it as an INPUT is int8 (the SPPF pool is type-agnostic); a
           buffer with mixed readers stays fp16 and gets an int8 twin filled by one QUANT op.
         * scales: activations s = amax/127 per BUFFER (a concat buffer has one scale: its consumer conv has one
@@ -414,9 +420,26 @@ class EngineBuilder:
         self.op_int8 = [op.kind == OP_CONV and op.cin % 64 == 0 and all(seg_q(sg) for sg in op.segs) for op in self.ops]
         nbuf = len(self.buffers)
         readers = {b: [] for b in range(nbuf)}
+        writers = {b: set() for b in range(nbuf)}
         for i, op in enumerate(self.ops):
             if op.kind == OP_CONV:
                 readers[op.src_buf].append(i)
+            for sg in op.segs:
+                writers[sg.dst.buf].add(i)
+        narrow = {sg.module.split(".bottlenecks.")[0] + "." for op in self.ops if op.kind == OP_CONV and op.cin % 64
+                  for sg in op.segs if ".bottlenecks." in sg.module and seg_q(sg)}
+        for i, op in enumerate(self.ops):
+            if self.op_int8[i] and any(sg.module.startswith(n) for sg in op.segs for n in narrow):
+                self.op_int8[i] = False
+        changed = True
+        while changed:
+            changed = False
+            for b in range(nbuf):
+                qs = [self.op_int8[i] for i in readers[b]]
+                if len(writers[b]) > 1 and any(qs) and not all(qs):
+                    for i in readers[b]:
+                        self.op_int8[i] = False
+                    changed = True
         new_ops: List[Op] = []
         twin_of: Dict[int, int] = {}
         for b in range(nbuf):
