@@ -11,9 +11,14 @@ import torch.nn.functional as F
 from unina_yolo_dla_amd import export
 
 
-def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = True):
+def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = True, teacher: dict = None):
     """x: [1,3,H,W] fp32. Returns ({output name: [C,H,W] fp32}, {buffer name: [C,H,W] fp32}).
-    int8 buffers are returned as their integer codes (multiply by the buffer scale to dequantise)."""
+    int8 buffers are returned as their integer codes (multiply by the buffer scale to dequantise).
+
+    teacher = {buffer name: stored values (codes for int8 buffers) read back from the ENGINE after a per-op forward}:
+    every op then reads the engine's own buffers and writes into a separate set, so the returned buffers hold each
+    op's emulated output GIVEN THE ENGINE'S INPUTS -- a per-op comparison that rounding flips cannot snowball through
+    (deep in an int8 network a handful of +-1 input codes moves a third of the outputs by one code)."""
     prec = builder.precision
     wdt = {export.FP16: "<f2", export.FP32: "<f4", export.INT8: "<f2"}[prec]
     blob = bytes(builder.blob)
@@ -23,6 +28,12 @@ def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = Tr
             for i, (name, h, w, c, *_rest) in enumerate(builder.buffers)}
     img = next(i for i, b in enumerate(builder.buffers) if b[5] & export.BUF_INPUT)
     bufs[img] = torch.from_numpy(np.ascontiguousarray(x[0])).to(bufs[img].dtype)
+    wr = bufs
+    if teacher is not None:
+        for i, b in enumerate(builder.buffers):
+            if i != img and b[0] in teacher:
+                bufs[i] = torch.from_numpy(np.ascontiguousarray(teacher[b[0]])).to(bufs[i].dtype)
+        wr = {i: t.clone() for i, t in bufs.items()}
 
     def store(dst_buf, y):
         """round y (real values) the way a kernel writing into buffer `dst_buf` does"""
@@ -44,17 +55,17 @@ def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = Tr
             w = torch.from_numpy(np.frombuffer(blob, dtype="<f4", count=s.n_count * 27, offset=s.w_off).reshape(s.n_count, 3, 3, 3).copy())
             b = torch.from_numpy(np.frombuffer(blob, dtype="<f4", count=s.n_count, offset=s.b_off).copy())
             y = F.relu(F.conv2d(src[None].float(), w, b, stride=2, padding=1))[0].to(src.dtype)
-            bufs[s.dst.buf][s.dst.coff:s.dst.coff + s.n_count] = store(s.dst.buf, y)
+            wr[s.dst.buf][s.dst.coff:s.dst.coff + s.n_count] = store(s.dst.buf, y)
         elif op.kind == export.OP_SPPF_POOL:
             s = op.segs[0]
             c = op.cin
             t = src[s.src_coff:s.src_coff + c][None]
             for i in range(1, 4):
                 t = F.max_pool2d(t, 5, 1, 2)
-                src[s.src_coff + i * c:s.src_coff + (i + 1) * c] = t[0]
+                wr[op.src_buf][s.src_coff + i * c:s.src_coff + (i + 1) * c] = t[0]
         elif op.kind == export.OP_QUANT:
             s = op.segs[0]
-            bufs[s.dst.buf][s.dst.coff:s.dst.coff + s.n_count] = store(s.dst.buf, src[:s.n_count])
+            wr[s.dst.buf][s.dst.coff:s.dst.coff + s.n_count] = store(s.dst.buf, src[:s.n_count])
         elif op.kind == export.OP_CONV:
             k = op.k
             int8 = prec == export.INT8 and builder.op_int8[oi]
@@ -84,15 +95,15 @@ def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = Tr
                     else:
                         y = (y.float() + r.float()).to(y.dtype)
                 if s.flags & export.SEG_PLANAR_F32:
-                    bufs[s.dst.buf][s.dst.coff:s.dst.coff + s.n_count] = y.float().to(y.dtype)
+                    wr[s.dst.buf][s.dst.coff:s.dst.coff + s.n_count] = y.float().to(y.dtype)
                     continue
                 y = store(s.dst.buf, y)
                 if s.flags & export.SEG_UP2:
                     y = y.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
-                bufs[s.dst.buf][s.dst.coff:s.dst.coff + s.n_count] = y
+                wr[s.dst.buf][s.dst.coff:s.dst.coff + s.n_count] = y
         else:
             raise NotImplementedError(op.kind)
-    named = {builder.buffers[i][0]: t.float().numpy() for i, t in bufs.items()}
+    named = {builder.buffers[i][0]: t.float().numpy() for i, t in wr.items()}
     outs = {n: named[n] for n in ("p2_cls", "p2_reg", "p3_cls", "p3_reg", "p4_cls", "p4_reg")}
     return outs, named
 
@@ -102,4 +113,33 @@ def dequantised(builder: "export.EngineBuilder", named: dict) -> dict:
     out = {}
     for name, h, w, c, dtype, flags, scale in builder.buffers:
         out[name] = named[name] * scale if dtype == export.BUF_I8 else named[name]
+    return out
+
+
+def engine_buffers(builder: "export.EngineBuilder", read_buffer) -> dict:
+    """{buffer name: stored values} of an engine after a per-op (unfused) forward, int8 buffers as codes: the `teacher`
+    of run_op_table. read_buffer(name) returns real values (code * scale), as Engine.read_buffer does."""
+    out = {}
+    for name, h, w, c, dtype, flags, scale in builder.buffers:
+        if dtype in (export.BUF_F16, export.BUF_I8) and not (flags & export.BUF_INPUT):
+            v = read_buffer(name)
+            out[name] = np.rint(v / np.float32(scale)) if dtype == export.BUF_I8 else v
+    return out
+
+
+def per_op_mismatch(builder: "export.EngineBuilder", teacher: dict, named: dict) -> dict:
+    """Per activation buffer: (fraction of int8 codes that differ | fraction of fp16 values off by more than 2 fp16
+    ulp, worst difference in codes | in units of the 2-ulp tolerance) between the engine and the teacher-forced emulation."""
+    out = {}
+    for name, h, w, c, dtype, flags, scale in builder.buffers:
+        if name not in teacher:
+            continue
+        a, b = np.asarray(teacher[name], np.float64), np.asarray(named[name], np.float64)
+        if dtype == export.BUF_I8:
+            d = np.abs(a - b)
+            out[name] = (float((d > 0.5).mean()), float(d.max()))
+        else:
+            tol = 2.0 ** -9 * np.maximum(np.abs(a), np.abs(b)) + 1e-4
+            d = np.abs(a - b) / tol
+            out[name] = (float((d > 1.0).mean()), float(d.max()))
     return out

@@ -106,7 +106,7 @@ def test_graph_b_int8_engine_from_a_qat_checkpoint(pkg, sd7b, oracle_mod, torch_
     """The QAT-checkpoint path end to end on the GPU: checkpoint (weights + quantizer ranges, qat.py key names) ->
     INT8 engine file of graph (B) -> HIP int8 kernels, against the torch-CPU integer emulation of the same table (codes
     agree up to rare +-1 flips) and, as calibrated drift, against the fp32 oracle."""
-    from emulate import run_op_table, dequantised
+    from emulate import run_op_table, engine_buffers, per_op_mismatch
     from test_graph_b_cpu import _synthetic_qat_checkpoint
     from unina_yolo_dla_amd import export
     from unina_yolo_dla_amd.engine import Engine
@@ -121,17 +121,26 @@ def test_graph_b_int8_engine_from_a_qat_checkpoint(pkg, sd7b, oracle_mod, torch_
         x = pkg.rng.frame(1234, 128, 128)
         heads = e.forward(torch_cuda.from_numpy(x).cuda())
         emu, named = run_op_table(b8, x)
-        real = dequantised(b8, named)
-        for bname in ("stage2_conv", "stage4_conv", "cat_fpn1", "cat_pan2", "p3_out"):
-            i = [bb[0] for bb in b8.buffers].index(bname)
-            scale = b8.buffers[i][6] if b8.buffers[i][4] == export.BUF_I8 else 1e-3
-            diff = np.abs(e.read_buffer(bname) - real[bname]) / scale
-            assert float((diff > 0.5).mean()) < 0.05 and diff.max() <= 4.5, (bname, float((diff > 0.5).mean()), float(diff.max()))
+        # per-op exactness, teacher-forced: every op of the emulation reads the ENGINE's own (per-op forward) buffers, so
+        # a rounding flip cannot snowball (free-running, a handful of +-1 input codes moves a third of a deep layer's
+        # outputs by one code). int8 codes must agree but for the rare round-to-nearest tie; fp16 values within 2 ulp.
+        e.set_fusion(False)
+        e.forward(torch_cuda.from_numpy(x).cuda())
+        teacher = engine_buffers(b8, e.read_buffer)
+        e.set_fusion(True)
+        forced = run_op_table(b8, x, teacher=teacher)[1]
+        mm = per_op_mismatch(b8, teacher, forced)
+        assert len(mm) > 40
+        for bname, (frac, worst) in mm.items():
+            i8 = b8.buffers[[bb[0] for bb in b8.buffers].index(bname)][4] == export.BUF_I8
+            assert frac < 2e-3 and worst <= (1.0 if i8 else 4.0), (bname, i8, frac, worst)
         ref = oracle_mod.forward(osd, x, variant="B")
         for n in pkg.graph.OUTPUT_NAMES:
-            e_kernel = float(np.sqrt(((heads[n] - emu[n]) ** 2).mean()))
+            # free-running, the engine and the emulation are two equally valid roundings of the same arithmetic: each
+            # must sit at the same distance (the quantisation drift) from the fp32 oracle
+            e_engine = float(np.sqrt(((heads[n] - ref[n]) ** 2).mean()))
             e_quant = float(np.sqrt(((emu[n] - ref[n]) ** 2).mean()))
-            assert e_kernel < 0.75 * e_quant, (n, e_kernel, e_quant)
+            assert e_engine < 1.25 * e_quant + 1e-3, (n, e_engine, e_quant)
             assert e_quant < 0.15 * max(float(ref[n].std()), 0.3), (n, e_quant)
         dets = e.infer(torch_cuda.from_numpy(x).cuda(), 0.75, 0.45, 0.1)
         assert dets.dtype.itemsize == 32 and np.all(np.diff(dets["confidence"]) <= 0)
