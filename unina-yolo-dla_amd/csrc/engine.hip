@@ -536,7 +536,37 @@ int plan(unina_engine* e) {
           for (const Region& r : ri)
             for (const Region& w2 : wj) legal = legal && !overlaps(r, w2);
         }
-        if (!legal) continue;
+        if (!legal) {
+          // the other direction: the EARLIER op sinks to the later one's position (an INT8 engine's P3 output conv
+          // waits for the P4 head's): nothing in between may read what it writes or write what it reads / writes
+          const int kind2 = conv_dual_match(b.cp, a.cp);
+          if (kind2 < 0) continue;
+          std::vector<Region> ra, wa;
+          op_regions(e, i, &ra, &wa);
+          bool sink = true;
+          for (size_t k = i + 1; k <= j && sink; ++k) {
+            op_regions(e, k, &ri, &wi);
+            for (const Region& w : wi) {
+              for (const Region& r : ra) sink = sink && !overlaps(w, r);
+              for (const Region& w2 : wa) sink = sink && !overlaps(w, w2);
+            }
+            for (const Region& r : ri)
+              for (const Region& w2 : wa) sink = sink && !overlaps(r, w2);
+          }
+          if (!sink) continue;
+          b.dual_with = (int)i;
+          b.dual_kind = kind2;
+          a.dual_absorbed = true;
+          b.info.flops += a.info.flops;
+          b.info.bytes += a.info.bytes;
+          b.info.grid += a.info.grid;
+          snprintf(b.info.kernel, sizeof b.info.kernel, "%s", conv_dual_name(kind2));
+          a.info.flops = 0;
+          a.info.bytes = 0;
+          a.info.grid = 0;
+          snprintf(a.info.kernel, sizeof a.info.kernel, "(dual launch with op %zu)", j);
+          break;
+        }
         a.dual_with = (int)j;
         a.dual_kind = kind;
         b.dual_absorbed = true;
