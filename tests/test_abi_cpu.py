@@ -103,11 +103,14 @@ def test_bn_folding_matches_unfolded_math(pkg, sd7):
     np.testing.assert_allclose(x * scale + b, unfolded, rtol=1e-12, atol=1e-12)
 
 
-def test_export_rejects_unsupported_width(pkg):
+def test_export_embeds_narrow_widths(pkg):
+    """base_channels=16 (model.py:331-333) is below the kernels' 32-channel K block: the exporter embeds it at width
+    32 (numerics: test_op_table_cpu.py::test_narrow_base_channels_are_embedded_exactly)."""
     from unina_yolo_dla_amd import export
-    g = pkg.graph.Graph(base_channels=16)
-    with pytest.raises(NotImplementedError):
-        export.EngineBuilder(pkg.synth.make_state_dict(7, g), g)
+    g = pkg.graph.Graph(base_channels=16, in_h=64, in_w=64)
+    b = export.EngineBuilder(pkg.synth.make_state_dict(7, g), g)
+    assert b.narrow_base_channels == 16 and b.g.base_channels == 32
+    assert all(op.cin % 32 == 0 for op in b.ops if op.kind == export.OP_CONV)
 
 
 def test_c3k2_groups_are_recognised_at_load(lib, pkg, sd7, tmp_path):

@@ -179,6 +179,32 @@ def test_infer_end_to_end_vs_oracle(pkg, eng640, oracle_mod, oracle_sd7, torch_c
         check_fp16_detections(got, want, 0.5)
 
 
+def test_narrow_model_base_channels_16(pkg, oracle_mod, torch_cuda):
+    """model.py:331-333 base_channels=16: embedded at width 32 by the exporter (zero channels, exact); heads and
+    detections against the fp32 oracle of the NARROW model, same tolerance as the default width."""
+    from unina_yolo_dla_amd.engine import Engine
+    g = pkg.graph.Graph(base_channels=16, in_h=320, in_w=320)
+    sd = pkg.synth.make_state_dict(7, g, head_scales={n: (8.0 if n.endswith("cls") else 2.0) for n in pkg.graph.OUTPUT_NAMES})
+    osd = oracle_mod.StateDict(sd)
+    e = Engine.from_state_dict(sd, g)
+    try:
+        assert e.L.unina_fusion_groups(e.h) == 8               # the widened model is graph (A) at width 32
+        x = pkg.rng.frame(1234, 320, 320)
+        heads = e.forward(torch_cuda.from_numpy(x).cuda())
+        o = oracle_mod.forward(osd, x, base_channels=16)
+        for n in pkg.graph.OUTPUT_NAMES:
+            err = float(np.sqrt(((heads[n] - o[n]) ** 2).mean()))
+            assert err < 4e-3 * max(1.0, float(np.abs(o[n]).max())), (n, err)
+        thr = 0.2
+        got = e.infer(torch_cuda.from_numpy(x).cuda(), thr, 0.45, 0.1)
+        want, ncand = oracle_mod.postprocess([o[n] for n in pkg.graph.OUTPUT_NAMES], thr, 0.45, 0.1)
+        assert 0 < ncand < 1024
+        check_fp16_detections(got, want, thr)
+    finally:
+        e.close()
+        osd.close()
+
+
 def test_infer_matches_reference_fixture_detections(pkg, eng640, torch_cuda):
     """Against detections produced by the reference's own model.py + postprocess.hpp (committed fixture)."""
     gold = load_golden("frame640_seed1234.npz")

@@ -26,6 +26,35 @@ def test_op_table_fp32_equals_oracle_mini64(pkg, sd7, oracle_mod, oracle_sd7):
         np.testing.assert_allclose(named[bname], ref[oname], atol=1e-2 * max(1.0, np.abs(ref[oname]).max()), rtol=0, err_msg=bname)
 
 
+def test_narrow_base_channels_are_embedded_exactly(pkg, oracle_mod):
+    """model.py:331-333 base_channels=16 (and variant B, qat.py): narrower than the kernels' 32-channel K block, so the
+    exporter embeds the model in the same topology at width 32 with zero channels (statedict.widen_state_dict). The
+    wide state_dict must compute the narrow model's heads EXACTLY in the fp32 oracle (only zeros join the sums), and
+    the op table built from it must match as any other."""
+    from unina_yolo_dla_amd import export, statedict
+    torch.set_num_threads(4)
+    x = pkg.rng.frame(1234, 64, 64)
+    for variant in ("A", "B"):
+        g = pkg.graph.Graph(base_channels=16, in_h=64, in_w=64, variant=variant)
+        sd = pkg.synth.make_state_dict(7, g)
+        osd = oracle_mod.StateDict(sd)
+        ref = oracle_mod.forward(osd, x, base_channels=16, variant=variant)
+        wide, gw = statedict.widen_state_dict(sd, g, 32)
+        assert gw.base_channels == 32 and set(wide) == set(pkg.synth.make_state_dict(7, gw))
+        owide = oracle_mod.StateDict(wide)
+        via_wide = oracle_mod.forward(owide, x, base_channels=32, variant=variant)
+        for n in pkg.graph.OUTPUT_NAMES:
+            np.testing.assert_allclose(via_wide[n], ref[n], atol=2e-5, rtol=1e-5, err_msg=n)   # summation order only
+        b = export.EngineBuilder(sd, g)
+        assert b.narrow_base_channels == 16 and b.g.base_channels == 32
+        outs, _ = run_op_table(b, x, fp16=False)
+        for n in pkg.graph.OUTPUT_NAMES:
+            np.testing.assert_allclose(outs[n], ref[n], atol=2e-2, rtol=0, err_msg=n)
+            assert np.sqrt(((outs[n] - ref[n]) ** 2).mean()) < 5e-3
+        osd.close()
+        owide.close()
+
+
 def test_lite_p2_op_table(pkg, oracle_mod):
     from unina_yolo_dla_amd import export
     g = pkg.graph.Graph(lite_p2=True, in_h=64, in_w=64)

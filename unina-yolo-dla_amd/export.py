@@ -20,6 +20,7 @@ the output is an explicit table of FUSED ops over NHWC fp16 activation buffers:
 """
 from __future__ import annotations
 
+import math
 import struct
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
@@ -163,8 +164,16 @@ class EngineBuilder:
         self.wdtype = np.float32 if precision == FP32 else np.float16
         self.act_dtype = BUF_F32_NHWC if precision == FP32 else BUF_F16
         self.g = graph or Graph()
+        self.narrow_base_channels = 0
         if self.g.base_channels % 32:
-            raise NotImplementedError("engine kernels need Cin % 32 == 0 beyond the stem (base_channels multiple of 32)")
+            # the kernels' K block is 32 channels: a narrower model (model.py:331-333 base_channels=16) is embedded, exactly,
+            # in the same topology at the next supported width (statedict.widen_state_dict: zero channels)
+            from .statedict import widen_state_dict
+            if self.g.base_channels <= 0:
+                raise NotImplementedError("base_channels must be positive")
+            self.narrow_base_channels = self.g.base_channels
+            wide = self.g.base_channels * 32 // math.gcd(self.g.base_channels, 32)
+            self.sd, self.g = widen_state_dict(sd, self.g, wide)
         self.buffers: List[list] = []   # [name, h, w, c, dtype, flags, scale]
         self.ops: List[Op] = []
         self.blob = bytearray()

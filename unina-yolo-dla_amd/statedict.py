@@ -87,3 +87,58 @@ def detect_variant(sd: Dict[str, np.ndarray]) -> str:
     if "stem.conv.weight" in sd and "stage4_conv.conv.weight" in sd:
         return "B"
     raise ValueError("state_dict matches neither graph (A) (model.py) nor graph (B) (qat.py)")
+
+
+def widen_state_dict(sd: Dict[str, np.ndarray], g, base_channels: int):
+    """Embeds a narrow model (``g.base_channels`` not a multiple of the kernels' 32-channel K block, e.g. the reference's
+    ``base_channels=16`` option, model.py:331-333) in the SAME topology at ``base_channels``: every ConvBlock keeps its
+    real output channels first and gains zero ones (zero weights, BN = identity with zero shift -> ReLU(0) = 0), and
+    every conv's input weights are scattered to where its producers' real channels sit (a concat of widened tensors
+    has gaps). The widened network computes the narrow one's outputs exactly (only zeros are added to the sums).
+    Returns (state_dict, graph) of the wide model."""
+    from .graph import Graph
+    big = Graph(num_classes=g.num_classes, base_channels=base_channels, lite_p2=g.lite_p2, in_h=g.in_h, in_w=g.in_w,
+                variant=g.variant)
+    if len(big.nodes) != len(g.nodes):
+        raise ValueError("widening changes the topology")
+    pos: Dict[int, np.ndarray] = {}
+
+    def positions(i: int) -> np.ndarray:
+        """positions of node i's (narrow) channels inside the wide graph's node i"""
+        if i < 0:
+            return np.arange(3)
+        if i not in pos:
+            n = g.nodes[i]
+            if n.kind in ("conv", "convout"):
+                pos[i] = np.arange(n.c)
+            elif n.kind == "cat":
+                parts, off = [], 0
+                for s, sb in zip(n.srcs, big.nodes[i].srcs):
+                    parts.append(positions(s) + off)
+                    off += big.nodes[sb].c
+                pos[i] = np.concatenate(parts)
+            else:                                   # add / pool5 / up2: channel-wise
+                pos[i] = positions(n.srcs[0])
+        return pos[i]
+
+    out: Dict[str, np.ndarray] = {}
+    for n, nb in zip(g.nodes, big.nodes):
+        if n.kind not in ("conv", "convout"):
+            continue
+        if nb.name != n.name or nb.kind != n.kind:
+            raise ValueError("widening changes the topology")
+        ip = positions(n.srcs[0])
+        if n.kind == "conv":
+            w = np.zeros((nb.c, nb.cin, n.k, n.k), np.float32)
+            w[:n.c, ip] = sd[f"{n.name}.conv.weight"]
+            out[f"{n.name}.conv.weight"] = w
+            for key, fill in (("weight", 1.0), ("bias", 0.0), ("running_mean", 0.0), ("running_var", 1.0)):
+                v = np.full((nb.c,), fill, np.float32)
+                v[:n.c] = sd[f"{n.name}.bn.{key}"]
+                out[f"{n.name}.bn.{key}"] = v
+        else:
+            w = np.zeros((n.c, nb.cin, 1, 1), np.float32)
+            w[:, ip] = sd[f"{n.name}.weight"]
+            out[f"{n.name}.weight"] = w
+            out[f"{n.name}.bias"] = np.asarray(sd[f"{n.name}.bias"], np.float32).copy()
+    return out, big
