@@ -374,12 +374,19 @@ def test_determinism_and_rebinding(pkg, eng640, torch_cuda):
     assert first[0] != first[1]
 
 
-def test_tile_configs_and_autotune_are_bit_identical(pkg, sd7, torch_cuda):
-    """Every conv tile configuration accumulates each output's K terms in the same order, so forcing any fitting
-    configuration -- or letting the autotuner choose -- must not change a single bit of the outputs."""
-    from unina_yolo_dla_amd.engine import Engine
+@pytest.mark.parametrize("precision", ["fp16", "int8"])
+def test_tile_configs_and_autotune_are_bit_identical(pkg, sd7, torch_cuda, precision):
+    """Every conv tile configuration accumulates each output's K terms in the same order (fp16) or exactly (int8), so
+    forcing any fitting configuration -- im2col, halo and register-queue kernels, stride 1 and 2 -- or letting the
+    autotuner choose must not change a single bit of the outputs."""
+    from unina_yolo_dla_amd import export
+    from unina_yolo_dla_amd.engine import Engine, calibrate_amax
     g = pkg.graph.Graph(in_h=128, in_w=128)
-    e = Engine.from_state_dict(sd7, g)
+    if precision == "int8":
+        amax = calibrate_amax(sd7, g, [pkg.rng.frame(5000 + i, 128, 128) for i in range(2)])
+        e = Engine.from_state_dict(sd7, g, precision=export.INT8, amax=amax)
+    else:
+        e = Engine.from_state_dict(sd7, g)
     try:
         x = _frame(pkg, torch_cuda, 1234, 128)
         fused = {k: v.copy() for k, v in e.forward(x).items()}

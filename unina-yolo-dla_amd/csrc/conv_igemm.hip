@@ -699,11 +699,16 @@ __device__ __forceinline__ void stem_patch(unsigned char* smem, unsigned char* w
 }
 
 // WN = 16-channel subtiles per wave (each activation fragment then feeds WN MFMAs: halves the LDS reads per MFMA at 2).
-template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, bool STEM = false, int WN = 1>
+// T = half_t, or signed char (INT8 engines: int8 patch image, 64-k weight blocks, v_mfma_i32_16x16x64_i8).
+template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, bool STEM = false, int WN = 1, typename T = half_t>
 __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, int nwg, const StemParams* sp = nullptr) {
-  typedef Elem<half_t> E;
+  typedef Elem<T> E;
+  typedef typename E::frag frag;
+  typedef typename std::conditional<sizeof(T) == 1, EltI8, EltH>::type PE;   // block_pipeline.h element traits of T
+  static_assert(!STEM || sizeof(T) == 2, "the stem patch is fp16");
   // S = stride (1 or 2): the patch is the (S*TH + 2 or S*TH + 1) x (...) input footprint of the tile
-  constexpr int BM = TH * TW, R0W = S * (TW - 1) + 3, R0H = S * (TH - 1) + 3, NT = NW * 64, CB = CIN / 32, KB = 9 * CB;
+  constexpr int BM = TH * TW, R0W = S * (TW - 1) + 3, R0H = S * (TH - 1) + 3, NT = NW * 64, CB = CIN / E::kBlockK, KB = 9 * CB;
+  static_assert(CIN % E::kBlockK == 0, "a weight block must not straddle a tap");
   constexpr int NS = BN / 16 / WN, WVM = NW / NS, MS = (BM + 15) / 16, WM_T = (MS + WVM - 1) / WVM;   // NS = waves along the channels
   static_assert((BN / 16) % WN == 0 && NW % NS == 0 && WM_T >= 1 && KB * WN >= D, "tile");
 
@@ -729,20 +734,20 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
     nsub = nsub * 16 < n_pad ? nsub : (n_pad >> 4) - 1;
     wptr[j] = static_cast<const unsigned char*>(sg.w) + (size_t)nsub * KB * 1024 + (4 * l15 + (lq ^ swz_g(l15))) * 16;
   }
-  half8 q[D];
+  frag q[D];
   auto fetch = [&](auto gc) {
     constexpr int g = decltype(gc)::value;
-    if constexpr (g < KB * WN) q[g % D] = *reinterpret_cast<const half8*>(wptr[g % WN] + (g / WN) * 1024);
+    if constexpr (g < KB * WN) q[g % D] = *reinterpret_cast<const frag*>(wptr[g % WN] + (g / WN) * 1024);
   };
 
-  constexpr Img X = make_img(0, CIN / 8);
+  constexpr Img X = make_img(0, CIN / E::kChunk);
   if constexpr (STEM) {
     static_for<0, D>(fetch);   // weights first: they are in flight while the stem patch is computed
     constexpr int PATCH = ((R0H * R0W * CIN * 2 + 1023) / 1024) * 1024;
     stem_patch<R0H, R0W, CIN, NT>(conv_smem, conv_smem + PATCH, *sp, S * ty0 - 1, S * tx0 - 1);
   } else {
-    load_patch<R0H, R0W, CIN, NT>(conv_smem, static_cast<const half_t*>(p.src) + sg.src_coff, p.src_ld, p.H, p.W, S * ty0 - 1,
-                                  S * tx0 - 1, p.zeros, wid, lane);
+    load_patch<R0H, R0W, CIN, NT, PE>(conv_smem, static_cast<const T*>(p.src) + sg.src_coff, p.src_ld, p.H, p.W, S * ty0 - 1,
+                                      S * tx0 - 1, p.zeros, wid, lane);
     static_for<0, D>(fetch);
   }
   EpiConsts<WN> ec;
@@ -762,22 +767,22 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
     return X.addr(row0[i] + th3 * R0W + (tap - th3 * 3), cb * 4 + lq);
   };
   typename E::acc_t acc[WN][WM_T];
-  half8 b[2][WM_T];
+  frag b[2][WM_T];
 #pragma unroll
   for (int i = 0; i < WM_T; ++i) {
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[j][i] = typename E::acc_t{0, 0, 0, 0};
-    b[0][i] = *reinterpret_cast<const half8*>(conv_smem + baddr(i, std::integral_constant<int, 0>{}));
+    b[0][i] = *reinterpret_cast<const frag*>(conv_smem + baddr(i, std::integral_constant<int, 0>{}));
   }
   static_for<0, KB>([&](auto kc) {
     constexpr int kb = decltype(kc)::value;
-    half8 a[WN];
+    frag a[WN];
 #pragma unroll
     for (int j = 0; j < WN; ++j) a[j] = q[(kb * WN + j) % D];
     static_for<0, WN>([&](auto jc) { fetch(std::integral_constant<int, kb * WN + decltype(jc)::value + D>{}); });
     if constexpr (kb + 1 < KB) {
 #pragma unroll
-      for (int i = 0; i < WM_T; ++i) b[(kb + 1) & 1][i] = *reinterpret_cast<const half8*>(conv_smem + baddr(i, std::integral_constant<int, kb + 1>{}));
+      for (int i = 0; i < WM_T; ++i) b[(kb + 1) & 1][i] = *reinterpret_cast<const frag*>(conv_smem + baddr(i, std::integral_constant<int, kb + 1>{}));
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j)
@@ -785,7 +790,7 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
       for (int i = 0; i < WM_T; ++i) acc[j][i] = E::mma(a[j], b[kb & 1][i], acc[j][i]);
   });
 
-  conv_epilogue<half_t, BM, BN, WM_T, WN>(p, sg, acc, ec, wm, wn, nb0, l15, lq,
+  conv_epilogue<T, BM, BN, WM_T, WN>(p, sg, acc, ec, wm, wn, nb0, l15, lq,
                                          [&](int pl) {
                                            const int oy = ty0 + pl / TW, ox = tx0 + pl % TW;
                                            return (pl < BM && oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
@@ -793,9 +798,9 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
                                          conv_smem, NT);
 }
 
-template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, int WN = 1>
+template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, int WN = 1, typename T = half_t>
 __global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
-  conv3x3_regq_body<TH, TW, BN, CIN, NW, D, S, false, WN>(p, (int)blockIdx.x, (int)gridDim.x);
+  conv3x3_regq_body<TH, TW, BN, CIN, NW, D, S, false, WN, T>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // backbone.stem -> backbone.stage1_conv as ONE launch: the 3x3/s2 conv's input patch is the stem's output, computed in
@@ -819,6 +824,11 @@ __global__ __launch_bounds__(512, 2) void stem_conv3x3s2_kernel(const StemConvPa
 __global__ __launch_bounds__(512, 4) void conv_dual_head3x3(const ConvParams pa, const ConvParams pb, int na) {
   if ((int)blockIdx.x < na) conv3x3_regq_body<8, 16, 64, 128, 8, 8, 1>(pa, (int)blockIdx.x, na);
   else conv3x3_regq_body<8, 8, 64, 256, 8, 8, 1>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
+}
+// INT8 engines: the same pair on int8 inputs (P3 | P4 head layers .0 and .1 are int8 convs there)
+__global__ __launch_bounds__(512, 4) void conv_dual_head3x3_i8(const ConvParams pa, const ConvParams pb, int na) {
+  if ((int)blockIdx.x < na) conv3x3_regq_body<8, 16, 64, 128, 8, 8, 1, false, 1, signed char>(pa, (int)blockIdx.x, na);
+  else conv3x3_regq_body<8, 8, 64, 256, 8, 8, 1, false, 1, signed char>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
 }
 // Variant with 128-channel workgroup tiles and two subtiles per wave (half the LDS fragment reads per MFMA): 100 + 100
 // workgroups, one per CU.
@@ -869,6 +879,12 @@ constexpr size_t smem_of() {
 #define REGQ2(TH, TW, BN, CIN, NW, D)                                                                \
   {(TH) * (TW), BN, 32, 3, "conv3x3_regq<f16," #TH "x" #TW "," #BN "," #CIN "," #NW "w,s2>",             \
    conv3x3_regq<TH, TW, BN, CIN, NW, D, 2>, 0, TH, TW, CIN, (NW) * 64, 2}
+#define REGQI(TH, TW, BN, CIN, NW, D)                                                                \
+  {(TH) * (TW), BN, 32, 3, "conv3x3_regq<i8," #TH "x" #TW "," #BN "," #CIN "," #NW "w>",                 \
+   conv3x3_regq<TH, TW, BN, CIN, NW, D, 1, 1, signed char>, 0, TH, TW, CIN, (NW) * 64, 1}
+#define REGQI2(TH, TW, BN, CIN, NW, D)                                                               \
+  {(TH) * (TW), BN, 32, 3, "conv3x3_regq<i8," #TH "x" #TW "," #BN "," #CIN "," #NW "w,s2>",              \
+   conv3x3_regq<TH, TW, BN, CIN, NW, D, 2, 1, signed char>, 0, TH, TW, CIN, (NW) * 64, 2}
 #define NOCFG {0, 0, 0, 0, "n/a", nullptr, 0, 0, 0, -1, 0, 0}
 
 // [dtype][config]; BK is in fp16-equivalent k (KSUB = BK/32 fragment blocks): a K-step covers BK channels in fp16
@@ -990,8 +1006,20 @@ const CfgInfo kCfg[3][kCfgCount] = {
         HALO(signed char, "i8", 8, 16, 64, 128, 2, 2, 4), // kCfgHalo8x16n64k128
         CFG(signed char, "i8", 32, 64, 128, 1, 4, 4),     // kCfg32x64k128
         CFG(signed char, "i8", 64, 64, 128, 2, 2, 4),     // kCfg64x64k128
-        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
-        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
+        REGQI(8, 16, 64, 128, 8, 16),                 // kCfgRegq8x16n64c128   (P3 head layers)
+        REGQI(8, 8, 64, 128, 8, 16),                  // kCfgRegq8x8n64c128
+        REGQI(8, 8, 64, 256, 8, 16),                  // kCfgRegq8x8n64c256    (P4 head layers)
+        REGQI(8, 8, 32, 256, 8, 16),                  // kCfgRegq8x8n32c256
+        NOCFG,                                        // kCfgRegq8x16n64c64    (the P2 head is an fp16 carve-out)
+        REGQI(8, 16, 32, 128, 8, 16),                 // kCfgRegq8x16n32c128
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
+        REGQI2(8, 8, 64, 64, 8, 8),                   // kCfgRegqS2_8x8n64c64     (down1)
+        REGQI2(8, 16, 64, 64, 8, 8),                  // kCfgRegqS2_8x16n64c64
+        REGQI2(8, 8, 64, 128, 8, 16),                 // kCfgRegqS2_8x8n64c128    (stage3_conv, down2)
+        REGQI2(4, 8, 64, 128, 8, 16),                 // kCfgRegqS2_4x8n64c128
+        NOCFG,                                        // kCfgRegqS2_8x16n64c32    (Cin 32 < one int8 block)
+        REGQI2(8, 8, 32, 128, 8, 16),                 // kCfgRegqS2_8x8n32c128
+        NOCFG, NOCFG,
     },
 };
 #undef CFG
@@ -999,6 +1027,8 @@ const CfgInfo kCfg[3][kCfgCount] = {
 #undef REGQ
 #undef REGQ2
 #undef REGQW
+#undef REGQI
+#undef REGQI2
 #undef NOCFG
 
 inline int block_k(int dtype) { return dtype == kF32 ? 16 : (dtype == kI8 ? 64 : 32); }
@@ -1008,7 +1038,7 @@ inline size_t smem_for(const ConvParams& p, const CfgInfo& c) {
   if (!c.th) return c.smem;
   if (c.cin) {  // register-queue kernel: patch (+ < 1 KiB overrun of its last DMA instruction) or the epilogue staging tile
     const size_t ph = c.stride * (c.th - 1) + 3, pw = c.stride * (c.tw - 1) + 3;
-    const size_t patch = ((ph * pw * c.cin * 2 + 1023) & ~(size_t)1023) + 1024;
+    const size_t patch = ((ph * pw * c.cin * esize(p) + 1023) & ~(size_t)1023) + 1024;
     return max_sz(patch, stage_bytes((c.bm + 15) & ~15, c.bn));
   }
   const size_t patch = (size_t)(c.th + 2) * (c.tw + 2) * p.Cin * esize(p);
@@ -1026,7 +1056,7 @@ int n_tiles(const ConvParams& p, int bn) {
 
 hipError_t conv_init() {
   for (const void* f : {reinterpret_cast<const void*>(conv_dual_head3x3), reinterpret_cast<const void*>(conv_dual_head1x1),
-                        reinterpret_cast<const void*>(conv_dual_head3x3_w2),
+                        reinterpret_cast<const void*>(conv_dual_head3x3_w2), reinterpret_cast<const void*>(conv_dual_head3x3_i8),
                         reinterpret_cast<const void*>(stem_conv3x3s2_kernel)}) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (e != hipSuccess) return e;
@@ -1045,8 +1075,8 @@ bool conv_config_valid(const ConvParams& p, int cfg) {
   if (cfg < 0 || cfg >= kCfgCount) return false;
   const CfgInfo& c = kCfg[p.dtype][cfg];
   if (!c.fn) return false;
-  if (c.cin) {  // register-queue kernel: 3x3 / stride 1 on exactly its Cin, fp16 in; every slice at least one tile wide
-    if (p.dtype != kF16 || p.Cin != c.cin || p.ksize != 3 || p.stride != c.stride || p.pad != 1 || smem_for(p, c) > kMaxLds) return false;
+  if (c.cin) {  // register-queue kernel: 3x3 on exactly its Cin and stride (fp16 / int8 rows of the table); every slice at least one tile wide
+    if (p.Cin != c.cin || p.ksize != 3 || p.stride != c.stride || p.pad != 1 || smem_for(p, c) > kMaxLds) return false;
     for (int s = 0; s < p.nseg; ++s)
       if (((p.seg[s].n_count + 15) & ~15) < c.bn) return false;
     return true;
@@ -1177,11 +1207,16 @@ const DualKind kDual[] = {
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3<regq 8x16,64,128 | regq 8x8,64,256>", conv_dual_head3x3},
     {kCfg128x16k64, kCfg128x16k64, 256, "conv_dual_head1x1<glds 128,16,64 x2>", conv_dual_head1x1},
     {kCfgRegqW8x16n128c128, kCfgRegqW8x8n128c256, 512, "conv_dual_head3x3_w2<regq 8x16,128,128,wn2 | regq 8x8,128,256,wn2>", conv_dual_head3x3_w2},
+    {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3_i8<regq i8,8x16,64,128 | regq i8,8x8,64,256>", conv_dual_head3x3_i8},
 };
+constexpr int kDualKinds = 4;
 }  // namespace
 
 int conv_dual_match(const ConvParams& a, const ConvParams& b) {
-  if (a.dtype != kF16 || b.dtype != kF16 || a.stamps || b.stamps) return -1;
+  if (a.stamps || b.stamps) return -1;
+  if (a.dtype == kI8 && b.dtype == kI8)
+    return (a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[3].cfg_a) && conv_config_valid(b, kDual[3].cfg_b)) ? 3 : -1;
+  if (a.dtype != kF16 || b.dtype != kF16) return -1;
   static const bool w2 = getenv("UNINA_DUAL_W2") && getenv("UNINA_DUAL_W2")[0] == '1';
   if (w2 && a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[2].cfg_a) && conv_config_valid(b, kDual[2].cfg_b)) return 2;
   if (a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[0].cfg_a) && conv_config_valid(b, kDual[0].cfg_b)) return 0;
@@ -1194,15 +1229,15 @@ int conv_dual_match(const ConvParams& a, const ConvParams& b) {
   return -1;
 }
 
-const char* conv_dual_name(int kind) { return kind >= 0 && kind < 3 ? kDual[kind].name : "?"; }
+const char* conv_dual_name(int kind) { return kind >= 0 && kind < kDualKinds ? kDual[kind].name : "?"; }
 
 hipError_t conv_dual_launch(int kind, const ConvParams& pa_in, const ConvParams& pb_in, hipStream_t stream, int* grid_out) {
-  if (kind < 0 || kind >= 3) return hipErrorInvalidValue;
+  if (kind < 0 || kind >= kDualKinds) return hipErrorInvalidValue;
   const DualKind& k = kDual[kind];
   ConvParams pa = pa_in, pb = pb_in;
   const dim3 ga = conv_prepare(pa, k.cfg_a), gb = conv_prepare(pb, k.cfg_b);
   const int na = (int)(ga.x * ga.y), nb = (int)(gb.x * gb.y);
-  const size_t sa = smem_for(pa, kCfg[kF16][k.cfg_a]), sb = smem_for(pb, kCfg[kF16][k.cfg_b]);
+  const size_t sa = smem_for(pa, kCfg[pa.dtype][k.cfg_a]), sb = smem_for(pb, kCfg[pb.dtype][k.cfg_b]);
   if (grid_out) *grid_out = na + nb;
   hipLaunchKernelGGL(k.fn, dim3(na + nb, 1, 1), dim3(k.threads, 1, 1), max_sz(sa, sb), stream, pa, pb, na);
   return hipGetLastError();
