@@ -416,7 +416,8 @@ def test_tile_configs_and_autotune_are_bit_identical(pkg, sd7, torch_cuda, preci
         e.close()
 
 
-BLOCK_OUTPUTS = ("neck.cat_fpn2", "neck.cat_fpn1", "neck.cat_pan2", "neck.cat_pan1", "p2_fused", "p3_out", "p4_out")
+BLOCK_OUTPUTS = ("neck.cat_fpn2", "neck.cat_fpn1", "neck.cat_pan2", "neck.cat_pan1", "p2_fused", "p3_out", "p4_out",
+                 "backbone.sppf.cat")    # (sppf.cv1 runs as the last step of stage3's block kernel)
 
 
 @pytest.mark.parametrize("size", [64, 640, 96])
@@ -463,10 +464,10 @@ def test_int8_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
         assert e.L.unina_fusion_groups(e.h) == 8              # 5 int8 blocks + the 2 narrow fp16 blocks + the fp16 P2 head
         x = _frame(pkg, torch_cuda, 1234, size)
         fused = {k: v.copy() for k, v in e.forward(x).items()}
-        bufs = ("neck.cat_fpn1", "neck.cat_pan1", "neck.cat_pan2", "p3_out", "p4_out")
+        bufs = ("neck.cat_fpn1", "neck.cat_pan1", "neck.cat_pan2", "p3_out", "p4_out", "backbone.sppf.cat")
         names = [b[0] for b in export.EngineBuilder(sd7, g, export.INT8, amax).buffers]
         bufs = tuple(b for b in bufs if b in names)
-        assert len(bufs) == 5
+        assert len(bufs) == 6
         fused_bufs = {b: e.read_buffer(b) for b in bufs}
         kernels = [o["kernel"] for o in e.op_infos()]
         assert sum("c3k2_fused<i8" in k or "block_dual_c3k2i8" in k for k in kernels) == 5, kernels

@@ -10,12 +10,13 @@ namespace dev {
 
 // step 0: cv1|cv2 (K = CIN, N = 2h); odd steps: bottleneck 1x1 (K = h, N = h); even steps: bottleneck 3x3 (K = 9h,
 // N = h); last step: cv3 (K = 2h, N = 2h). A wave owns one channel subtile, or ns / NW of them when ns > NW.
-// TAIL = 1 appends the lateral 1x1 conv (2h -> h, + nearest x2 upsample in its store) that follows an FPN block.
+// TAIL = 1 appends the lateral 1x1 conv (2h -> h, + nearest x2 upsample in its store) that follows an FPN block;
+// TAIL = 2 appends a plain 1x1 ConvBlock 2h -> h on the block's output (stage3_c3k2 -> sppf.cv1, model.py:215-216).
 // KBLK = k per weight block (32 fp16 / 64 int8).
 template <int H_, int NB, int CIN, int NW, int TAIL, int KBLK = 32>
 struct C3k2Plan {
   static constexpr int CV3 = 1 + 2 * NB;        // index of the cv3 step
-  static constexpr int N = 2 + 2 * NB + TAIL;
+  static constexpr int N = 2 + 2 * NB + (TAIL ? 1 : 0);
   static constexpr int kb(int s) { return s == 0 ? CIN / KBLK : (s >= CV3 ? 2 * H_ / KBLK : ((s & 1) ? H_ / KBLK : 9 * H_ / KBLK)); }
   static constexpr int ns(int s) { return (s == 0 || s == CV3) ? 2 * H_ / 16 : H_ / 16; }
   static constexpr int wnt(int s) { return ns(s) <= NW ? 1 : ns(s) / NW; }
@@ -226,18 +227,28 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           store4<E, H_>(tout + pp * ROWT + n * ESZ, act_relu<E, H_>(acc, CST(S4), n), CST(S4), n);
         });
     constexpr int CPT = H_ * ESZ / 16;
-    const size_t px = (size_t)p.dst2_ld * ESZ, row = (size_t)(2 * p.W) * px;
     unsigned char* dst2 = static_cast<unsigned char*>(p.dst2);
-    for (int c = threadIdx.x; c < PT * CPT; c += NT) {
-      const int pp = c / CPT, ch = c - pp * CPT;
-      const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
-      if (oy < p.H && ox < p.W) {
-        const vec16 v = *reinterpret_cast<const vec16*>(tout + pp * ROWT + ch * 16);
-        unsigned char* d = dst2 + ((size_t)(2 * oy) * (2 * p.W) + 2 * ox) * px + ch * 16;
-        *reinterpret_cast<vec16*>(d) = v;
-        *reinterpret_cast<vec16*>(d + px) = v;
-        *reinterpret_cast<vec16*>(d + row) = v;
-        *reinterpret_cast<vec16*>(d + row + px) = v;
+    if constexpr (TAIL == 1) {
+      const size_t px = (size_t)p.dst2_ld * ESZ, row = (size_t)(2 * p.W) * px;
+      for (int c = threadIdx.x; c < PT * CPT; c += NT) {
+        const int pp = c / CPT, ch = c - pp * CPT;
+        const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
+        if (oy < p.H && ox < p.W) {
+          const vec16 v = *reinterpret_cast<const vec16*>(tout + pp * ROWT + ch * 16);
+          unsigned char* d = dst2 + ((size_t)(2 * oy) * (2 * p.W) + 2 * ox) * px + ch * 16;
+          *reinterpret_cast<vec16*>(d) = v;
+          *reinterpret_cast<vec16*>(d + px) = v;
+          *reinterpret_cast<vec16*>(d + row) = v;
+          *reinterpret_cast<vec16*>(d + row + px) = v;
+        }
+      }
+    } else {
+      for (int c = threadIdx.x; c < PT * CPT; c += NT) {
+        const int pp = c / CPT, ch = c - pp * CPT;
+        const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
+        if (oy < p.H && ox < p.W)
+          *reinterpret_cast<vec16*>(dst2 + ((size_t)(oy * p.W + ox) * p.dst2_ld) * ESZ + ch * 16) =
+              *reinterpret_cast<const vec16*>(tout + pp * ROWT + ch * 16);
       }
     }
   }

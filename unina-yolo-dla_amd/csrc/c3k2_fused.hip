@@ -53,6 +53,10 @@ struct Class {
   {kF16, H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0>}
 #define C3K2T(H_, TH, TW, NB, CIN, NW, D) \
   {kF16, H_, NB, CIN, 1, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,lat>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 1>}
+#define C3K2P(H_, TH, TW, NB, CIN, NW, D) \
+  {kF16, H_, NB, CIN, 2, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,+1x1>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 2>}
+#define C3K2IP(H_, TH, TW, NB, CIN, NW, D) \
+  {kI8, H_, NB, CIN, 2, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,+1x1>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 2, EltI8>}
 #define C3K2I(H_, TH, TW, NB, CIN, NW, D) \
   {kI8, H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0, EltI8>}
 const Class kClasses[] = {
@@ -66,6 +70,7 @@ const Class kClasses[] = {
     C3K2T(64, 4, 8, 1, 256, 8, 8),     // neck.fpn_c3k2_1 + neck.lateral_p2 (+ x2 upsample)
     C3K2(64, 4, 8, 1, 192, 8, 8),      // neck.pan_c3k2_1
     C3K2(128, 4, 4, 2, 256, 8, 16),    // backbone.stage3_c3k2          40^2: 100  (16 waves: 27 vs 20 us)
+    C3K2P(128, 4, 4, 2, 256, 8, 16),   // backbone.stage3_c3k2 + backbone.sppf.cv1 (model.py:215-216)
     C3K2(128, 4, 4, 1, 384, 8, 16),    // neck.pan_c3k2_2
     C3K2(128, 4, 4, 1, 512, 8, 16),    // graph (B) fpn_c3k2_1 (qat.py:397)
     C3K2T(128, 4, 4, 1, 512, 8, 16),   // graph (B) fpn_c3k2_1 + lateral_p3
@@ -74,12 +79,15 @@ const Class kClasses[] = {
     C3K2I(64, 4, 8, 1, 256, 8, 8),     // neck.fpn_c3k2_1
     C3K2I(64, 4, 8, 1, 192, 8, 8),     // neck.pan_c3k2_1
     C3K2I(128, 4, 4, 2, 256, 8, 8),    // backbone.stage3_c3k2
+    C3K2IP(128, 4, 4, 2, 256, 8, 8),   // backbone.stage3_c3k2 + backbone.sppf.cv1
     C3K2I(128, 4, 4, 1, 384, 8, 8),    // neck.pan_c3k2_2
     C3K2I(128, 4, 4, 1, 512, 8, 8),    // graph (B) fpn_c3k2_1
 };
 #undef C3K2
 #undef C3K2T
 #undef C3K2I
+#undef C3K2P
+#undef C3K2IP
 const Class* find_class(int hid, int nb, int cin, int tail, int dtype) {
   for (const Class& c : kClasses)
     if (c.dtype == dtype && c.hid == hid && c.nb == nb && c.cin == cin && c.tail == tail) return &c;

@@ -48,7 +48,8 @@ struct PlannedOp {
   int dual_with = -1;       // >= 0: this conv and conv `dual_with` (independent, same kernel family) run as ONE grid
   int dual_kind = -1;
   bool dual_absorbed = false;   // runs inside an earlier op's dual launch
-  int tail_op = -1;         // role 1, C3k2: index of the lateral 1x1 (+ x2 upsample) that runs as the block kernel's last step
+  int tail_op = -1;         // role 1, C3k2: index of the 1x1 conv that runs as the block kernel's last step
+  int tail_kind = 0;        // 1: lateral 1x1 + x2 upsample store; 2: plain 1x1 ConvBlock (same resolution)
   int hid = 0, nb = 0;      // role 1: hidden width, bottleneck count
   uint64_t stream_off = 0, fbias_off = 0;   // role 1: blob offsets of the packed stage stream / concatenated biases
   C3k2Params fp;
@@ -446,7 +447,7 @@ int plan(unina_engine* e) {
     if (op.tail_op >= 0) {
       const SegDesc& ts = e->ops[op.tail_op].d.seg[0];
       const Buffer& tb = e->bufs[ts.dst_buf];
-      f.tail = 1;
+      f.tail = op.tail_kind;
       f.dst2 = static_cast<char*>(tb.ptr) + ts.dst_coff * fesz;
       f.dst2_ld = (int)tb.d.c;
     }
@@ -468,7 +469,7 @@ int plan(unina_engine* e) {
     }
     info.flops = flops;
     info.bytes = (double)fesz * f.H * f.W * f.Cin + wbytes + (double)fesz * f.H * f.W * 2 * f.hid +   // input once, weights once, output once
-                 (f.tail ? (double)fesz * 4 * f.H * f.W * f.hid : 0.0);                                // (+ the up-sampled lateral output)
+                 (f.tail ? (double)fesz * (f.tail == 1 ? 4 : 1) * f.H * f.W * f.hid : 0.0);            // (+ the tail conv's output)
     info.n = 2 * f.hid;
     info.k = 0;
     info.grid = f.tiles_x * f.tiles_y;
@@ -769,6 +770,18 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
           t.seg[0].dst_buf != z.seg[0].dst_buf && c3k2_supported((int)h, nb, (int)a.cin, 1))
         jt = j + 1;
     }
+    // ... or by a plain 1x1 ConvBlock 2h -> h on its output (stage3_c3k2 -> sppf.cv1, model.py:215-216), fp16 or int8
+    int tail_kind = jt > j ? 1 : 0;
+    if (jt == j && j + 1 < n) {
+      const OpDesc& t = e->ops[j + 1].d;
+      if (is_plain_conv(t, 1, 1, i8) && t.res_buf < 0 && t.cin == 2 * h && t.seg[0].n_count == h && t.src_buf == z.seg[0].dst_buf &&
+          t.seg[0].src_coff == z.seg[0].dst_coff && e->bufs[t.seg[0].dst_buf].d.dtype == bdt && t.seg[0].dst_coff % al == 0 &&
+          e->bufs[t.seg[0].dst_buf].d.c % al == 0 && t.seg[0].dst_buf != z.seg[0].dst_buf && t.in_h == z.out_h && t.in_w == z.out_w &&
+          c3k2_supported((int)h, nb, (int)a.cin, 2, dt)) {
+        jt = j + 1;
+        tail_kind = 2;
+      }
+    }
     // the group's intermediates must be private to it, and must not be its own input or output
     bool priv = true;
     for (uint32_t b : inter) {
@@ -803,7 +816,7 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     }
     std::vector<unsigned char> stream;
     std::vector<float> bias;
-    if (!c3k2_pack((int)h, nb, (int)a.cin, jt > j ? 1 : 0, convs.data(), &stream, &bias, dt)) continue;
+    if (!c3k2_pack((int)h, nb, (int)a.cin, tail_kind, convs.data(), &stream, &bias, dt)) continue;
     blob->resize((blob->size() + 255) & ~(size_t)255);
     const uint64_t so = blob->size();
     blob->insert(blob->end(), stream.begin(), stream.end());
@@ -819,6 +832,7 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     head.stream_off = so;
     head.fbias_off = bo;
     head.tail_op = jt > j ? (int)jt : -1;
+    head.tail_kind = tail_kind;
     for (size_t k = i + 1; k <= jt; ++k) e->ops[k].fuse_role = 2;
     ++e->n_groups;
     i = jt;
