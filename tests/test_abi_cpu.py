@@ -121,12 +121,12 @@ def test_c3k2_groups_are_recognised_at_load(lib, pkg, sd7, tmp_path):
     g = pkg.graph.Graph(in_h=64, in_w=64)
     path = str(tmp_path / "a.une")
     export.export_engine(sd7, path, g)
-    assert lib.unina_debug_fusable_groups(path.encode()) == 8
+    assert lib.unina_debug_fusable_groups(path.encode()) == 9      # 7 C3k2 blocks + P2 head + the sppf.cv2 -> lateral_p3 pair
     export.export_engine(sd7, path, g, precision=export.FP32)
     assert lib.unina_debug_fusable_groups(path.encode()) == 0
     gl = pkg.graph.Graph(in_h=64, in_w=64, lite_p2=True)
     export.export_engine(pkg.synth.make_state_dict(7, gl), path, gl)
-    assert lib.unina_debug_fusable_groups(path.encode()) == 7
+    assert lib.unina_debug_fusable_groups(path.encode()) == 8
     assert lib.unina_debug_fusable_groups(b"/nonexistent.une") == -1
     # INT8 engine file: the five blocks whose tensors are all int8 (stage2/3, fpn_c3k2_1, pan_c3k2_1/2) as int8 block
     # kernels, the two h = 32 blocks (fp16 by builder choice) and the carved-out P2 head (train.py:779) as fp16 ones
@@ -134,4 +134,4 @@ def test_c3k2_groups_are_recognised_at_load(lib, pkg, sd7, tmp_path):
     b16 = export.EngineBuilder(sd7, g)
     amax = export.calibrate(run_op_table(b16, pkg.rng.frame(5000 + i, 64, 64))[1] for i in range(2))
     export.export_engine(sd7, path, g, precision=export.INT8, amax=amax)
-    assert lib.unina_debug_fusable_groups(path.encode()) == 8
+    assert lib.unina_debug_fusable_groups(path.encode()) == 9

@@ -68,7 +68,7 @@ def unfused64(eng64):
     """Per-layer checks read the C3k2 blocks' internal buffers, which only the unfused op table writes."""
     eng64.set_fusion(False)
     yield eng64
-    assert eng64.set_fusion(True) == 8
+    assert eng64.set_fusion(True) == 9
 
 
 def test_mini64_every_buffer_vs_oracle(pkg, unfused64, oracle_mod, oracle_sd7, torch_cuda):
@@ -188,7 +188,7 @@ def test_narrow_model_base_channels_16(pkg, oracle_mod, torch_cuda):
     osd = oracle_mod.StateDict(sd)
     e = Engine.from_state_dict(sd, g)
     try:
-        assert e.L.unina_fusion_groups(e.h) == 8               # the widened model is graph (A) at width 32
+        assert e.L.unina_fusion_groups(e.h) == 9               # the widened model is graph (A) at width 32
         x = pkg.rng.frame(1234, 320, 320)
         heads = e.forward(torch_cuda.from_numpy(x).cuda())
         o = oracle_mod.forward(osd, x, base_channels=16)
@@ -428,7 +428,7 @@ def test_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
     from unina_yolo_dla_amd.engine import Engine
     e = Engine.from_state_dict(sd7, pkg.graph.Graph(in_h=size, in_w=size))
     try:
-        assert e.L.unina_fusion_groups(e.h) == 8              # 7 C3k2 blocks + the P2 head, on by default
+        assert e.L.unina_fusion_groups(e.h) == 9              # 7 C3k2 blocks + the P2 head + the sppf.cv2 -> lateral_p3 pair, on by default
         x = _frame(pkg, torch_cuda, 1234, size)
         fused = {k: v.copy() for k, v in e.forward(x).items()}
         fused_bufs = {b: e.read_buffer(b) for b in BLOCK_OUTPUTS}
@@ -436,13 +436,14 @@ def test_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
         assert sum("c3k2_fused" in k or "block_dual" in k for k in kernels) == 7    # (one block may share its grid with the head)
         assert sum("head_fused" in k or "block_dual" in k for k in kernels) == 1
         assert sum(k.startswith("conv_dual") for k in kernels) == 3                           # P3 | P4 head layers pairwise
+        assert sum(k.startswith("conv_pair") for k in kernels) == 1                           # sppf.cv2 -> lateral_p3
         assert e.set_fusion(False) == 0
         plain = e.forward(x)
         for b in BLOCK_OUTPUTS:
             assert np.array_equal(fused_bufs[b], e.read_buffer(b)), b
         for k in plain:
             assert np.array_equal(fused[k], plain[k]), k
-        assert e.set_fusion(True) == 8
+        assert e.set_fusion(True) == 9
         again = e.forward(x)
         for k in plain:
             assert np.array_equal(again[k], plain[k]), k
@@ -461,7 +462,7 @@ def test_int8_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
     amax = calibrate_amax(sd7, g, [pkg.rng.frame(5000 + i, size, size) for i in range(2)])
     e = Engine.from_state_dict(sd7, g, precision=export.INT8, amax=amax)
     try:
-        assert e.L.unina_fusion_groups(e.h) == 8              # 5 int8 blocks + the 2 narrow fp16 blocks + the fp16 P2 head
+        assert e.L.unina_fusion_groups(e.h) == 9              # 5 int8 blocks + the 2 narrow fp16 blocks + the fp16 P2 head + the int8 conv pair
         x = _frame(pkg, torch_cuda, 1234, size)
         fused = {k: v.copy() for k, v in e.forward(x).items()}
         bufs = ("neck.cat_fpn1", "neck.cat_pan1", "neck.cat_pan2", "p3_out", "p4_out", "backbone.sppf.cat")
@@ -477,7 +478,7 @@ def test_int8_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
             assert np.array_equal(fused_bufs[b], e.read_buffer(b)), b
         for k in plain:
             assert np.array_equal(fused[k], plain[k]), k
-        assert e.set_fusion(True) == 8
+        assert e.set_fusion(True) == 9
         d1 = e.infer(x, 0.5, 0.45, 0.1)
         e.set_fusion(False)
         d0 = e.infer(x, 0.5, 0.45, 0.1)
@@ -504,7 +505,7 @@ def test_frame_graph_and_tiled_nms_match_the_plain_forms(pkg, sd7, torch_cuda, m
             e.close()
 
     fast, groups = run()
-    assert groups == 8
+    assert groups == 9
     monkeypatch.setenv("UNINA_FULL_GRAPH", "0")
     monkeypatch.setenv("UNINA_POST_SPLIT", "0")
     monkeypatch.setenv("UNINA_FUSE", "0")
@@ -529,7 +530,7 @@ def test_opt_in_stem_fusion_is_bit_identical(pkg, sd7, torch_cuda, monkeypatch):
     d0, h0, g0 = run()
     monkeypatch.setenv("UNINA_STEM_FUSE", "1")
     d1, h1, g1 = run()
-    assert (g0, g1) == (8, 9) and d0 == d1
+    assert (g0, g1) == (9, 10) and d0 == d1
     for k in h0:
         assert np.array_equal(h0[k], h1[k]), k
 

@@ -23,6 +23,7 @@ UNITS = {
     "c3k2_fused.hip": [],
     "head_fused.hip": [],
     "block_dual.hip": [],
+    "conv_pair.hip": [],
     "stem_pool.hip": [],
     "postprocess.hip": ["-ffp-contract=off"],   # box arithmetic must round like the reference's scalar code
     "preprocess.hip": ["-ffp-contract=off"],    # normalisation arithmetic rounds as written (oracle/preprocess_oracle.c)

@@ -1,0 +1,182 @@
+// conv_pair.hip -- two consecutive 1x1 ConvBlocks as ONE launch (block-pipeline form, block_pipeline.h).
+//
+// The SPPF's output conv and the FPN lateral that follows it (model.py:130-132 SPPF_DLA.cv2, 512 -> 256, then
+// model.py:256 Neck.lateral_p3, 256 -> 128, whose store does the nearest x2 upsample of model.py:145-147) are two
+// launches of a few microseconds of work each on a 40 x 40 map: both sit on the launch + latency floor. A 1x1 conv
+// needs no halo, so a workgroup that owns TH x TW pixels can run both: the input pixels are DMA'd into an LDS image,
+// step 0 writes the first conv's output rows to a staging image (and to HBM: other ops may read it), step 1 reads
+// them back as its B operand; weights stream L2 -> registers through the per-wave prefetch queue that keeps running
+// across the step boundary. Same MFMA, K order, epilogue and rounding points as the per-op kernels -> bit-identical
+// (tests/test_gpu_parity.py block-fusion tests). fp16 and int8 (EltI8) forms.
+#include "block_kernels.h"
+
+#include <cstring>
+
+namespace unina {
+
+using namespace dev;
+
+extern __shared__ __align__(16) unsigned char pair_smem[];
+
+template <int C0, int C1, int C2, int NW, int KBLK>
+struct PairPlan {
+  static constexpr int N = 2;
+  static constexpr int kb(int s) { return (s == 0 ? C0 : C1) / KBLK; }
+  static constexpr int ns(int s) { return (s == 0 ? C1 : C2) / 16; }
+  static constexpr int wnt(int s) { return ns(s) <= NW ? 1 : ns(s) / NW; }
+  static constexpr int nch(int s) { return 16 * ns(s); }
+  static constexpr int cfirst(int s) { return s == 0 ? 0 : nch(0); }
+};
+
+template <int C0, int C1, int C2, int TH, int TW, int NW, int D, int UP2, typename E>
+__global__ __launch_bounds__(NW * 64) void conv_pair_kernel(const PairParams p) {
+  typedef PairPlan<C0, C1, C2, NW, E::KBLK> PL;
+  typedef StepTable<PL, NW> ST;
+  static_assert(ST::valid(), "wave roles");
+  static_assert(C0 % E::KBLK == 0 && C1 % E::KBLK == 0, "K blocks");
+  constexpr int PT = TH * TW, NT = NW * 64, ESZ = E::ESZ;
+  unsigned char* smem = pair_smem;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int bid = (int)blockIdx.x;
+  const int tyi = fast_div(bid, p.tiles_x_magic), txi = bid - tyi * p.tiles_x;
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+
+  const unsigned char* wbase = p.wstream + (4 * l15 + (lq ^ swz_g(l15))) * 16;
+  typename E::frag q[D];
+  float* cst = reinterpret_cast<float*>(smem + p.off_bias);
+  for (int i = threadIdx.x; i < p.n_bias; i += NT) cst[i] = p.bias[i];
+  constexpr Img X = make_img(0, C0 / E::CH);
+  load_patch<TH, TW, C0, NT, E>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0, tx0, p.zeros, wid, lane);
+  static_for<0, D>([&](auto gc) { wq_fetch<ST, D, decltype(gc)::value>(q, wbase, wid); });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
+  lds_barrier();
+
+  const Img Xi = Img{p.off_x, X.nch, X.sh, X.mask};
+  typedef typename E::acc_t acc_t;
+  typedef float vec16 __attribute__((ext_vector_type(4)));  // 16 opaque bytes
+  auto pixel = [&](int sub) {
+    const int pp = sub * 16 + l15;
+    return pp < PT ? pp : PT - 1;
+  };
+
+  // ---- step 0: y = ReLU(W0 x + b0) -> staging image (linear rows) -> HBM ----
+  constexpr int ROWB = C1 * ESZ + 16;
+  unsigned char* stage = smem + p.off_stage;
+  const float* c0 = cst;
+  run_step<ST, D, 0, PT, E>(q, wbase, smem, wid, lane,
+      [&](int sub, auto kc) { return Xi.addr(pixel(sub), decltype(kc)::value * 4 + lq); },
+      [&](int sub, int n, const acc_t& acc) {
+        const int pp = sub * 16 + l15;
+        if (pp < PT) store4<E, C1>(stage + pp * ROWB + n * ESZ, act_relu<E, C1>(acc, c0, n), c0, n);
+      });
+  constexpr int CPR = C1 * ESZ / 16;
+  unsigned char* dst = static_cast<unsigned char*>(p.dst);
+  for (int c = threadIdx.x; c < PT * CPR; c += NT) {
+    const int pp = c / CPR, ch = c - pp * CPR;
+    const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
+    if (oy < p.H && ox < p.W)
+      *reinterpret_cast<vec16*>(dst + ((size_t)(oy * p.W + ox) * p.dst_ld) * ESZ + ch * 16) =
+          *reinterpret_cast<const vec16*>(stage + pp * ROWB + ch * 16);
+  }
+
+  // ---- step 1: z = ReLU(W1 y + b1) -> output tile -> HBM (x2 nearest upsample in the store when UP2) ----
+  const Img YS = Img{p.off_stage, ROWB / 16, 0, 0};
+  constexpr int ROWT = C2 * ESZ + 16;
+  unsigned char* tout = smem + p.off_out;
+  const float* c1 = cst + E::CM * PL::cfirst(1);
+  run_step<ST, D, 1, PT, E>(q, wbase, smem, wid, lane,
+      [&](int sub, auto kc) { return YS.addr(pixel(sub), decltype(kc)::value * 4 + lq); },
+      [&](int sub, int n, const acc_t& acc) {
+        const int pp = sub * 16 + l15;
+        if (pp < PT) store4<E, C2>(tout + pp * ROWT + n * ESZ, act_relu<E, C2>(acc, c1, n), c1, n);
+      });
+  constexpr int CPT = C2 * ESZ / 16;
+  unsigned char* dst2 = static_cast<unsigned char*>(p.dst2);
+  const size_t px = (size_t)p.dst2_ld * ESZ, row = (size_t)(2 * p.W) * px;
+  for (int c = threadIdx.x; c < PT * CPT; c += NT) {
+    const int pp = c / CPT, ch = c - pp * CPT;
+    const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
+    if (oy >= p.H || ox >= p.W) continue;
+    const vec16 v = *reinterpret_cast<const vec16*>(tout + pp * ROWT + ch * 16);
+    if constexpr (UP2) {
+      unsigned char* d = dst2 + ((size_t)(2 * oy) * (2 * p.W) + 2 * ox) * px + ch * 16;
+      *reinterpret_cast<vec16*>(d) = v;
+      *reinterpret_cast<vec16*>(d + px) = v;
+      *reinterpret_cast<vec16*>(d + row) = v;
+      *reinterpret_cast<vec16*>(d + row + px) = v;
+    } else {
+      *reinterpret_cast<vec16*>(dst2 + (size_t)(oy * p.W + ox) * px + ch * 16) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- host side
+namespace {
+
+struct PClass {
+  int dtype, c0, c1, c2, up2, th, tw, nw;
+  const char* name;
+  void (*fn)(const PairParams);
+};
+const PClass kPairClasses[] = {
+    // backbone.sppf.cv2 -> neck.lateral_p3 (+ x2 upsample): 100 workgroups at 40^2
+    {kF16, 512, 256, 128, 1, 4, 4, 8, "conv_pair<512,256,128,4x4,8w,up2>", conv_pair_kernel<512, 256, 128, 4, 4, 8, 16, 1, EltH>},
+    {kI8, 512, 256, 128, 1, 4, 4, 8, "conv_pair<i8,512,256,128,4x4,8w,up2>", conv_pair_kernel<512, 256, 128, 4, 4, 8, 8, 1, EltI8>},
+};
+const PClass* find_pclass(int dtype, int c0, int c1, int c2, int up2) {
+  for (const PClass& c : kPairClasses)
+    if (c.dtype == dtype && c.c0 == c0 && c.c1 == c1 && c.c2 == c2 && c.up2 == up2) return &c;
+  return nullptr;
+}
+int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+hipError_t pair_init() {
+  for (const PClass& c : kPairClasses) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c.fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+bool pair_supported(int dtype, int c0, int c1, int c2, int up2) { return find_pclass(dtype, c0, c1, c2, up2) != nullptr; }
+
+bool pair_layout(PairParams* p) {
+  const PClass* c = find_pclass(p->dtype, p->c0, p->c1, p->c2, p->up2);
+  if (!c) return false;
+  const int esz = p->dtype == kI8 ? 1 : 2, cm = p->dtype == kI8 ? 3 : 1, pt = c->th * c->tw;
+  p->tiles_x = (p->W + c->tw - 1) / c->tw;
+  p->tiles_y = (p->H + c->th - 1) / c->th;
+  p->tiles_x_magic = div_magic((unsigned)p->tiles_x);
+  p->n_bias = cm * (p->c1 + p->c2);
+  int off = 0;
+  p->off_bias = off; off += align_up(p->n_bias * 4, 1024);
+  p->off_x = off;
+  p->off_out = off;                                           // the output tile replaces the input patch (dead after step 0)
+  const int x_bytes = align_up(pt * p->c0 * esz, 1024) + 1024, out_bytes = pt * (p->c2 * esz + 16);
+  off += align_up(x_bytes > out_bytes ? x_bytes : out_bytes, 1024);
+  p->off_stage = off; off += align_up(pt * (p->c1 * esz + 16), 1024);
+  p->smem_bytes = off;
+  return off <= 160 * 1024;
+}
+
+hipError_t pair_launch(const PairParams& p, hipStream_t stream) {
+  const PClass* c = find_pclass(p.dtype, p.c0, p.c1, p.c2, p.up2);
+  if (!c) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(c->fn, dim3(p.tiles_x * p.tiles_y, 1, 1), dim3(c->nw * 64, 1, 1), p.smem_bytes, stream, p);
+  return hipGetLastError();
+}
+
+const char* pair_kernel_name(const PairParams& p) {
+  const PClass* c = find_pclass(p.dtype, p.c0, p.c1, p.c2, p.up2);
+  return c ? c->name : "conv_pair<?>";
+}
+int pair_block_threads(const PairParams& p) {
+  const PClass* c = find_pclass(p.dtype, p.c0, p.c1, p.c2, p.up2);
+  return c ? c->nw * 64 : 0;
+}
+
+}  // namespace unina

@@ -44,6 +44,7 @@ struct PlannedOp {
   int fuse_role = 0;
   int fuse_kind = 0;        // role 1: 1 = C3k2 block (c3k2_fused.hip), 2 = DetectionHead (head_fused.hip)
   HeadParams hp;
+  PairParams pr;            // fuse_kind 4: two consecutive 1x1 convs (conv_pair.hip)
   int group_last = -1;      // role 1: index of the group's last op (cv3 / the head's output convs)
   int dual_with = -1;       // >= 0: this conv and conv `dual_with` (independent, same kernel family) run as ONE grid
   int dual_kind = -1;
@@ -188,6 +189,8 @@ void op_regions(const unina_engine* e, size_t i, std::vector<Region>* reads, std
   if (e->fuse && e->ops[i].fuse_role == 1) {
     const OpDesc& last = e->ops[e->ops[i].group_last].d;
     reads->push_back({(int)d.src_buf, (int)d.seg[0].src_coff, (int)(d.seg[0].src_coff + d.cin)});
+    if (e->ops[i].fuse_kind == 4)   // the first conv's output goes to HBM too
+      writes->push_back({(int)d.seg[0].dst_buf, (int)d.seg[0].dst_coff, (int)(d.seg[0].dst_coff + d.seg[0].n_count)});
     for (uint32_t s = 0; s < last.nseg; ++s)
       writes->push_back({(int)last.seg[s].dst_buf, (int)last.seg[s].dst_coff, (int)(last.seg[s].dst_coff + last.seg[s].n_count)});
     if (e->ops[i].tail_op >= 0) {
@@ -375,6 +378,44 @@ int plan(unina_engine* e) {
       cv.info.bytes = 0;
       cv.info.grid = 0;
       snprintf(cv.info.kernel, sizeof cv.info.kernel, "(fused into op %zu)", i);
+      continue;
+    }
+    if (op.fuse_kind == 4) {
+      const OpDesc& a = op.d;
+      PlannedOp& zb = e->ops[op.group_last];
+      const OpDesc& z = zb.d;
+      const Buffer& src = e->bufs[a.src_buf];
+      const Buffer& mid = e->bufs[a.seg[0].dst_buf];
+      const Buffer& out = e->bufs[z.seg[0].dst_buf];
+      PairParams& f = op.pr;
+      memset(&f, 0, sizeof f);
+      f.dtype = act_dtype_of(src.d.dtype);
+      const size_t esz = dtype_size(f.dtype);
+      f.src = static_cast<const char*>(src.ptr) + a.seg[0].src_coff * esz;
+      f.src_ld = (int)src.d.c;
+      f.c0 = (int)a.cin; f.c1 = (int)a.seg[0].n_count; f.c2 = (int)z.seg[0].n_count;
+      f.H = (int)a.in_h; f.W = (int)a.in_w;
+      f.dst = static_cast<char*>(mid.ptr) + a.seg[0].dst_coff * esz;
+      f.dst_ld = (int)mid.d.c;
+      f.dst2 = static_cast<char*>(out.ptr) + z.seg[0].dst_coff * esz;
+      f.dst2_ld = (int)out.d.c;
+      f.up2 = (z.seg[0].flags & kSegUp2) ? 1 : 0;
+      f.wstream = reinterpret_cast<const unsigned char*>(blob + op.stream_off);
+      f.bias = reinterpret_cast<const float*>(blob + op.fbias_off);
+      f.zeros = e->d_zeros;
+      if (!pair_layout(&f)) return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: fused conv pair does not fit", i);
+      if (!e->fuse) continue;
+      op.info.flops += zb.info.flops;
+      op.info.bytes += zb.info.bytes - (double)esz * f.H * f.W * f.c1;     // the second conv reads the first's output from LDS
+      op.info.grid = f.tiles_x * f.tiles_y;
+      op.info.block = pair_block_threads(f);
+      op.info.k = 0;
+      snprintf(op.info.kernel, sizeof op.info.kernel, "%s", pair_kernel_name(f));
+      snprintf(op.info.name, sizeof op.info.name, "%.40s+%.40s", a.name, z.name);
+      zb.info.flops = 0;
+      zb.info.bytes = 0;
+      zb.info.grid = 0;
+      snprintf(zb.info.kernel, sizeof zb.info.kernel, "(fused into op %zu)", i);
       continue;
     }
     if (op.fuse_kind == 2) {
@@ -595,6 +636,7 @@ hipError_t launch_op(unina_engine* e, size_t i, hipStream_t s) {
   if (op.dual_absorbed) return hipSuccess;
   if (e->fuse && op.fuse_role == 1 && op.dual_with >= 0) return block_dual_launch(op.fp, e->ops[op.dual_with].hp, s);
   if (e->fuse && op.fuse_role == 1 && op.fuse_kind == 3) return stemconv_launch(op.sp, e->ops[op.group_last].cp, s);
+  if (e->fuse && op.fuse_role == 1 && op.fuse_kind == 4) return pair_launch(op.pr, s);
   if (e->fuse && op.fuse_role == 1) return op.fuse_kind == 2 ? head_launch(op.hp, s) : c3k2_launch(op.fp, s);
   if (op.dual_with >= 0) return conv_dual_launch(op.dual_kind, op.cp, e->ops[op.dual_with].cp, s);
   if (e->fuse && op.fuse_role == 2) return hipSuccess;   // runs inside its group's launch
@@ -836,6 +878,64 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     for (size_t k = i + 1; k <= jt; ++k) e->ops[k].fuse_role = 2;
     ++e->n_groups;
     i = jt;
+  }
+}
+
+// Two consecutive 1x1 ConvBlocks outside any block group (sppf.cv2 -> lateral_p3, whose store does the x2 upsample):
+// one launch when conv_pair.hip has a class for the channel counts. fp16 or all-int8.
+void find_pair_groups(unina_engine* e, std::vector<char>* blob) {
+  const size_t n = e->ops.size();
+  for (size_t i = 0; i + 1 < n; ++i) {
+    if (e->ops[i].fuse_role || e->ops[i + 1].fuse_role) continue;
+    const OpDesc& a = e->ops[i].d;
+    const OpDesc& z = e->ops[i + 1].d;
+    if (a.kind != kOpConv || z.kind != kOpConv) continue;
+    const uint32_t bdt = e->bufs[a.src_buf].d.dtype;
+    if (bdt != kBufF16Nhwc && bdt != kBufI8Nhwc) continue;
+    const bool i8 = bdt == kBufI8Nhwc;
+    const uint32_t al = i8 ? 16 : 8;
+    if (!is_plain_conv(a, 1, 1, i8) || a.res_buf >= 0) continue;
+    if (z.ksize != 1 || z.stride != 1 || !z.relu || z.nseg != 1 || z.res_buf >= 0 || (z.seg[0].flags & ~(uint32_t)kSegUp2) ||
+        (z.seg[0].m_off != 0) != i8 || z.seg[0].n_pad != z.seg[0].n_count) continue;
+    if (z.src_buf != a.seg[0].dst_buf || z.seg[0].src_coff != a.seg[0].dst_coff || z.cin != a.seg[0].n_count) continue;
+    if (e->bufs[a.seg[0].dst_buf].d.dtype != bdt || e->bufs[z.seg[0].dst_buf].d.dtype != bdt) continue;
+    if (a.seg[0].src_coff % al || e->bufs[a.src_buf].d.c % al || a.seg[0].dst_coff % al || e->bufs[a.seg[0].dst_buf].d.c % al ||
+        z.seg[0].dst_coff % al || e->bufs[z.seg[0].dst_buf].d.c % al) continue;
+    if (z.seg[0].dst_buf == a.seg[0].dst_buf || z.seg[0].dst_buf == a.src_buf || a.seg[0].dst_buf == a.src_buf) continue;
+    const int dt = i8 ? kI8 : kF16, up2 = (z.seg[0].flags & kSegUp2) ? 1 : 0;
+    if (!pair_supported(dt, (int)a.cin, (int)a.seg[0].n_count, (int)z.seg[0].n_count, up2)) continue;
+    C3k2Conv cv[2];
+    memset(cv, 0, sizeof cv);
+    const OpDesc* od[2] = {&a, &z};
+    for (int k = 0; k < 2; ++k) {
+      const SegDesc& sg = od[k]->seg[0];
+      cv[k].w[0] = reinterpret_cast<const unsigned char*>(blob->data() + sg.w_off);
+      cv[k].bias[0] = reinterpret_cast<const float*>(blob->data() + sg.b_off);
+      cv[k].n[0] = (int)sg.n_count;
+      cv[k].K = (int)od[k]->cin;
+      if (i8) {
+        cv[k].mult[0] = reinterpret_cast<const float*>(blob->data() + sg.m_off);
+        cv[k].out_inv[0] = 1.0f / e->bufs[sg.dst_buf].d.scale;
+      }
+    }
+    std::vector<unsigned char> stream;
+    std::vector<float> bias;
+    block_pack(cv, 2, &stream, &bias, dt);
+    blob->resize((blob->size() + 255) & ~(size_t)255);
+    const uint64_t so = blob->size();
+    blob->insert(blob->end(), stream.begin(), stream.end());
+    blob->resize((blob->size() + 255) & ~(size_t)255);
+    const uint64_t bo = blob->size();
+    blob->insert(blob->end(), reinterpret_cast<const char*>(bias.data()), reinterpret_cast<const char*>(bias.data() + bias.size()));
+    PlannedOp& head = e->ops[i];
+    head.fuse_role = 1;
+    head.fuse_kind = 4;
+    head.group_last = (int)(i + 1);
+    head.stream_off = so;
+    head.fbias_off = bo;
+    e->ops[i + 1].fuse_role = 2;
+    ++e->n_groups;
+    ++i;
   }
 }
 
@@ -1211,6 +1311,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   if (e->h.precision == kFp16 || e->h.precision == kInt8) {
     find_c3k2_groups(e, &blob);
     find_head_groups(e, &blob);
+    find_pair_groups(e, &blob);
     find_stem_group(e);
     const char* fz = getenv("UNINA_FUSE");
     e->fuse = e->n_groups > 0 && !(fz && fz[0] == '0');
@@ -1233,6 +1334,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   LOADCHK(conv_init());
   LOADCHK(c3k2_init());
   LOADCHK(head_init());
+  LOADCHK(pair_init());
   LOADCHK(block_dual_init());
   LOADCHK(hipMalloc(&e->d_zeros, 256));
   LOADCHK(hipMemset(e->d_zeros, 0, 256));
@@ -1460,6 +1562,7 @@ int unina_debug_fusable_groups(const char* path) {
   if (e.h.precision == kFp16 || e.h.precision == kInt8) {
     find_c3k2_groups(&e, &blob);
     find_head_groups(&e, &blob);
+    find_pair_groups(&e, &blob);
     find_stem_group(&e);
   }
   return e.n_groups;

@@ -162,6 +162,33 @@ hipError_t head_launch(const HeadParams& p, hipStream_t stream);
 const char* head_kernel_name(int c);
 int head_block_threads(int c);
 
+// Two consecutive 1x1 ConvBlocks (SPPF cv2 -> FPN lateral, + x2 upsample store) in ONE launch (conv_pair.hip).
+struct PairParams {
+  int dtype;                     // kF16 or kI8: element type of src, dst and dst2
+  const void* src;               // input, channel offset applied
+  int src_ld;
+  int c0, c1, c2;                // channels: input, first conv's output, second conv's output
+  int H, W;
+  void* dst;                     // first conv's output (other ops may read it), channel offset applied
+  int dst_ld;
+  void* dst2;                    // second conv's output; up2: a (2H x 2W) destination, every pixel written to its 2x2 block
+  int dst2_ld;
+  int up2;
+  const unsigned char* wstream;  // block_pack of the two convs
+  const float* bias;             // per-step constants (fp16 [bias]; int8 [bias | mult | 1/s_out])
+  const void* zeros;
+  // filled by pair_layout():
+  int n_bias, tiles_x, tiles_y;
+  unsigned tiles_x_magic;
+  int off_bias, off_x, off_stage, off_out, smem_bytes;
+};
+hipError_t pair_init();
+bool pair_supported(int dtype, int c0, int c1, int c2, int up2);
+bool pair_layout(PairParams* p);
+hipError_t pair_launch(const PairParams& p, hipStream_t stream);
+const char* pair_kernel_name(const PairParams& p);
+int pair_block_threads(const PairParams& p);
+
 // A fused C3k2 block and a fused head that do not depend on each other, side by side in one grid (block_dual.hip).
 hipError_t block_dual_init();
 bool block_dual_match(const C3k2Params& pc, const HeadParams& ph);
