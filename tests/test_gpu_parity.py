@@ -465,13 +465,15 @@ def test_int8_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
         assert e.L.unina_fusion_groups(e.h) == 9              # 5 int8 blocks + the 2 narrow fp16 blocks + the fp16 P2 head + the int8 conv pair
         x = _frame(pkg, torch_cuda, 1234, size)
         fused = {k: v.copy() for k, v in e.forward(x).items()}
-        bufs = ("neck.cat_fpn1", "neck.cat_pan1", "neck.cat_pan2", "p3_out", "p4_out", "backbone.sppf.cat")
+        bufs = ("neck.cat_fpn1", "neck.cat_pan1", "neck.cat_pan2", "p3_out", "p4_out", "backbone.sppf.cat",
+                "neck.cat_fpn2", "p2_fused", "p2_fused.q8")   # (int8 block -> fp16 lateral tail; fp16 block -> int8 twin store)
         names = [b[0] for b in export.EngineBuilder(sd7, g, export.INT8, amax).buffers]
         bufs = tuple(b for b in bufs if b in names)
-        assert len(bufs) == 6
+        assert len(bufs) == 9
         fused_bufs = {b: e.read_buffer(b) for b in bufs}
         kernels = [o["kernel"] for o in e.op_infos()]
         assert sum("c3k2_fused<i8" in k or "block_dual_c3k2i8" in k for k in kernels) == 5, kernels
+        assert not any("quant_f16_i8" in k for k in kernels) and sum("lat f16" in k for k in kernels) == 1, kernels
         assert e.set_fusion(False) == 0
         plain = e.forward(x)
         for b in bufs:

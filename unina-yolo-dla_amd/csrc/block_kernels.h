@@ -11,7 +11,9 @@ namespace dev {
 // step 0: cv1|cv2 (K = CIN, N = 2h); odd steps: bottleneck 1x1 (K = h, N = h); even steps: bottleneck 3x3 (K = 9h,
 // N = h); last step: cv3 (K = 2h, N = 2h). A wave owns one channel subtile, or ns / NW of them when ns > NW.
 // TAIL = 1 appends the lateral 1x1 conv (2h -> h, + nearest x2 upsample in its store) that follows an FPN block;
-// TAIL = 2 appends a plain 1x1 ConvBlock 2h -> h on the block's output (stage3_c3k2 -> sppf.cv1, model.py:215-216).
+// TAIL = 2 appends a plain 1x1 ConvBlock 2h -> h on the block's output (stage3_c3k2 -> sppf.cv1, model.py:215-216);
+// TAIL = 3 is TAIL = 1 for an int8 block whose lateral writes an fp16 tensor (INT8 engines: fpn_c3k2_1 -> lateral_p2
+// into the fp16 concat buffer of the narrow fpn_c3k2_2 block).
 // KBLK = k per weight block (32 fp16 / 64 int8).
 template <int H_, int NB, int CIN, int NW, int TAIL, int KBLK = 32>
 struct C3k2Plan {
@@ -203,16 +205,32 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
   for (int c = threadIdx.x; c < PT * CPR; c += NT) {
     const int pp = c / CPR, ch = c - pp * CPR;
     const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
-    if (oy < p.H && ox < p.W)
-      *reinterpret_cast<vec16*>(dst + ((size_t)(oy * p.W + ox) * p.dst_ld) * ESZ + ch * 16) =
-          *reinterpret_cast<const vec16*>(stage + pp * ROWB + ch * 16);
+    if (oy < p.H && ox < p.W) {
+      const vec16 v = *reinterpret_cast<const vec16*>(stage + pp * ROWB + ch * 16);
+      *reinterpret_cast<vec16*>(dst + ((size_t)(oy * p.W + ox) * p.dst_ld) * ESZ + ch * 16) = v;
+      if constexpr (!E::I8) {
+        if (p.dst_q) {   // int8 twin of the output for the block's int8 consumers: stem_pool.hip quant_f16_i8_kernel's arithmetic
+          const half8 hv = *reinterpret_cast<const half8*>(&v);
+          unsigned int q[2] = {0u, 0u};
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            float t = __builtin_rintf((float)hv[r] * p.q_inv);
+            t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
+            q[r >> 2] |= ((unsigned int)(int)t & 0xFFu) << (8 * (r & 3));
+          }
+          *reinterpret_cast<uint2*>(p.dst_q + (size_t)(oy * p.W + ox) * p.dst_q_ld + ch * 8) = make_uint2(q[0], q[1]);
+        }
+      }
+    }
   }
 
   if constexpr (TAIL) {
     // ---- tail: lateral 1x1 (model.py:256,259: ConvBlock 2h -> h) on the block's output, still in the staging image,
     //      then nearest x2 upsample (model.py:145-147) in the store: each pixel's h channels go to its 2x2 block ----
     const Img YS = Img{p.off_stage, ROWB / 16, 0, 0};        // the staging image is linear: pitch ROWB, no swizzle
-    constexpr int ROWT = H_ * ESZ + 16;
+    typedef typename std::conditional<TAIL == 3, EltH, E>::type TE;   // element type of the tail's output
+    constexpr int TSZ = TE::ESZ;
+    constexpr int ROWT = H_ * TSZ + 16;
     constexpr int S4 = 2 + 2 * NB;
     unsigned char* tout = smem + p.off_tail;
     run_step(STEP(S4, PT),
@@ -224,12 +242,12 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
         [&](int sub, int n, const acc_t& acc) {
           const int pp = sub * 16 + l15;
           if (pp >= PT) return;
-          store4<E, H_>(tout + pp * ROWT + n * ESZ, act_relu<E, H_>(acc, CST(S4), n), CST(S4), n);
+          store4<TE, H_>(tout + pp * ROWT + n * TSZ, act_relu<E, H_>(acc, CST(S4), n), CST(S4), n);
         });
-    constexpr int CPT = H_ * ESZ / 16;
+    constexpr int CPT = H_ * TSZ / 16;
     unsigned char* dst2 = static_cast<unsigned char*>(p.dst2);
-    if constexpr (TAIL == 1) {
-      const size_t px = (size_t)p.dst2_ld * ESZ, row = (size_t)(2 * p.W) * px;
+    if constexpr (TAIL == 1 || TAIL == 3) {
+      const size_t px = (size_t)p.dst2_ld * TSZ, row = (size_t)(2 * p.W) * px;
       for (int c = threadIdx.x; c < PT * CPT; c += NT) {
         const int pp = c / CPT, ch = c - pp * CPT;
         const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
@@ -247,7 +265,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
         const int pp = c / CPT, ch = c - pp * CPT;
         const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
         if (oy < p.H && ox < p.W)
-          *reinterpret_cast<vec16*>(dst2 + ((size_t)(oy * p.W + ox) * p.dst2_ld) * ESZ + ch * 16) =
+          *reinterpret_cast<vec16*>(dst2 + ((size_t)(oy * p.W + ox) * p.dst2_ld) * TSZ + ch * 16) =
               *reinterpret_cast<const vec16*>(tout + pp * ROWT + ch * 16);
       }
     }

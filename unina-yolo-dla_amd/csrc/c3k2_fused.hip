@@ -57,6 +57,8 @@ struct Class {
   {kF16, H_, NB, CIN, 2, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,+1x1>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 2>}
 #define C3K2IP(H_, TH, TW, NB, CIN, NW, D) \
   {kI8, H_, NB, CIN, 2, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,+1x1>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 2, EltI8>}
+#define C3K2IL(H_, TH, TW, NB, CIN, NW, D) \
+  {kI8, H_, NB, CIN, 3, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,lat f16>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 3, EltI8>}
 #define C3K2I(H_, TH, TW, NB, CIN, NW, D) \
   {kI8, H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0, EltI8>}
 const Class kClasses[] = {
@@ -77,6 +79,7 @@ const Class kClasses[] = {
     // INT8 engines: the blocks whose tensors are all int8 (h = 32 blocks touch the fp16 carve-outs: train.py:779)
     C3K2I(64, 4, 8, 2, 128, 8, 8),     // backbone.stage2_c3k2
     C3K2I(64, 4, 8, 1, 256, 8, 8),     // neck.fpn_c3k2_1
+    C3K2IL(64, 4, 8, 1, 256, 8, 8),    // neck.fpn_c3k2_1 + neck.lateral_p2 (+ x2 upsample) into the fp16 concat of fpn_c3k2_2
     C3K2I(64, 4, 8, 1, 192, 8, 8),     // neck.pan_c3k2_1
     C3K2I(128, 4, 4, 2, 256, 8, 8),    // backbone.stage3_c3k2
     C3K2IP(128, 4, 4, 2, 256, 8, 8),   // backbone.stage3_c3k2 + backbone.sppf.cv1
@@ -87,6 +90,7 @@ const Class kClasses[] = {
 #undef C3K2T
 #undef C3K2I
 #undef C3K2P
+#undef C3K2IL
 #undef C3K2IP
 const Class* find_class(int hid, int nb, int cin, int tail, int dtype) {
   for (const Class& c : kClasses)
@@ -142,7 +146,7 @@ bool c3k2_layout(C3k2Params* p) {
   off += align_up(a_bytes, 1024);
   p->off_y = off;
   p->off_tail = off;                                          // the tail's output tile replaces a | b (dead after cv3)
-  const int y_bytes = p0 * 2 * h * esz, tail_bytes = p->tail ? pt * (h * esz + 16) : 0;
+  const int y_bytes = p0 * 2 * h * esz, tail_bytes = p->tail ? pt * (h * (p->tail == 3 ? 2 : esz) + 16) : 0;
   off += align_up(y_bytes > tail_bytes ? y_bytes : tail_bytes, 1024);
   p->smem_bytes = off;
   return off <= kMaxLds;

@@ -50,7 +50,8 @@ struct PlannedOp {
   int dual_kind = -1;
   bool dual_absorbed = false;   // runs inside an earlier op's dual launch
   int tail_op = -1;         // role 1, C3k2: index of the 1x1 conv that runs as the block kernel's last step
-  int tail_kind = 0;        // 1: lateral 1x1 + x2 upsample store; 2: plain 1x1 ConvBlock (same resolution)
+  int tail_kind = 0;        // 1: lateral 1x1 + x2 upsample store; 2: plain 1x1 ConvBlock (same resolution); 3: 1 with int8 in, fp16 out
+  int quant_op = -1;        // role 1, fp16 C3k2 in an INT8 engine: the QUANT op of the block's output that the kernel's store absorbs
   int hid = 0, nb = 0;      // role 1: hidden width, bottleneck count
   uint64_t stream_off = 0, fbias_off = 0;   // role 1: blob offsets of the packed stage stream / concatenated biases
   C3k2Params fp;
@@ -196,6 +197,10 @@ void op_regions(const unina_engine* e, size_t i, std::vector<Region>* reads, std
     if (e->ops[i].tail_op >= 0) {
       const SegDesc& ts = e->ops[e->ops[i].tail_op].d.seg[0];
       writes->push_back({(int)ts.dst_buf, (int)ts.dst_coff, (int)(ts.dst_coff + ts.n_count)});
+    }
+    if (e->ops[i].quant_op >= 0) {
+      const SegDesc& qs = e->ops[e->ops[i].quant_op].d.seg[0];
+      writes->push_back({(int)qs.dst_buf, (int)qs.dst_coff, (int)(qs.dst_coff + qs.n_count)});
     }
     if (e->ops[i].dual_with >= 0) {   // block dual: the partner group's reads / writes happen here too
       const PlannedOp& hb = e->ops[e->ops[i].dual_with];
@@ -489,11 +494,24 @@ int plan(unina_engine* e) {
       const SegDesc& ts = e->ops[op.tail_op].d.seg[0];
       const Buffer& tb = e->bufs[ts.dst_buf];
       f.tail = op.tail_kind;
-      f.dst2 = static_cast<char*>(tb.ptr) + ts.dst_coff * fesz;
+      f.dst2 = static_cast<char*>(tb.ptr) + ts.dst_coff * (op.tail_kind == 3 ? 2 : fesz);
       f.dst2_ld = (int)tb.d.c;
+    }
+    if (op.quant_op >= 0) {
+      const Buffer& qb = e->bufs[e->ops[op.quant_op].d.seg[0].dst_buf];
+      f.dst_q = static_cast<signed char*>(qb.ptr);
+      f.dst_q_ld = (int)qb.d.c;
+      f.q_inv = 1.0f / qb.d.scale;   // as the QUANT op's own parameter
     }
     if (!c3k2_layout(&f)) return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: fused C3k2 block does not fit", i);
     if (!e->fuse) continue;
+    if (op.quant_op >= 0) {
+      unina_op_info& qi = e->ops[op.quant_op].info;
+      qi.flops = 0;
+      qi.bytes = 0;
+      qi.grid = 0;
+      snprintf(qi.kernel, sizeof qi.kernel, "(fused into op %zu)", i);
+    }
     unina_op_info& info = op.info;
     double flops = 0, wbytes = 0;
     const int last_op = op.tail_op >= 0 ? op.tail_op : op.group_last;
@@ -824,6 +842,27 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
         tail_kind = 2;
       }
     }
+    // INT8 engines: an int8 FPN block whose lateral (int8 conv) writes the fp16 concat buffer of a narrow fp16 block
+    if (jt == j && i8 && j + 1 < n) {
+      const OpDesc& t = e->ops[j + 1].d;
+      if (t.kind == kOpConv && t.ksize == 1 && t.stride == 1 && t.relu && t.nseg == 1 && t.res_buf < 0 && t.seg[0].flags == kSegUp2 &&
+          t.seg[0].m_off && t.seg[0].n_pad == t.seg[0].n_count && t.cin == 2 * h && t.seg[0].n_count == h &&
+          t.src_buf == z.seg[0].dst_buf && t.seg[0].src_coff == z.seg[0].dst_coff &&
+          e->bufs[t.seg[0].dst_buf].d.dtype == kBufF16Nhwc && t.seg[0].dst_coff % 8 == 0 && e->bufs[t.seg[0].dst_buf].d.c % 8 == 0 &&
+          c3k2_supported((int)h, nb, (int)a.cin, 3, dt)) {
+        jt = j + 1;
+        tail_kind = 3;
+      }
+    }
+    // INT8 engines: an fp16 block whose output gets an int8 twin from the QUANT op that follows (mixed readers)
+    int quant_op = -1;
+    if (!i8 && jt + 1 < n) {
+      const OpDesc& qd = e->ops[jt + 1].d;
+      if (qd.kind == kOpQuant && qd.src_buf == z.seg[0].dst_buf && z.seg[0].dst_coff == 0 && e->bufs[z.seg[0].dst_buf].d.c == 2 * h &&
+          qd.nseg == 1 && qd.seg[0].dst_coff == 0 && e->bufs[qd.seg[0].dst_buf].d.dtype == kBufI8Nhwc &&
+          e->bufs[qd.seg[0].dst_buf].d.c == 2 * h && !e->ops[jt + 1].fuse_role)
+        quant_op = (int)(jt + 1);
+    }
     // the group's intermediates must be private to it, and must not be its own input or output
     bool priv = true;
     for (uint32_t b : inter) {
@@ -875,6 +914,8 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     head.fbias_off = bo;
     head.tail_op = jt > j ? (int)jt : -1;
     head.tail_kind = tail_kind;
+    head.quant_op = quant_op;
+    if (quant_op >= 0) e->ops[quant_op].fuse_role = 2;
     for (size_t k = i + 1; k <= jt; ++k) e->ops[k].fuse_role = 2;
     ++e->n_groups;
     i = jt;

@@ -105,7 +105,11 @@ struct C3k2Params {
   const void* zeros;             // >= 16 bytes of zeros in HBM
   int hid, nb;                   // hidden width h = Cout/2, number of bottlenecks
   float res_scale[2];            // int8: scale of each bottleneck's shortcut tensor
-  int tail;                      // 1: the lateral 1x1 conv (2h -> h) + nearest x2 upsample that follows runs as a last step
+  signed char* dst_q;            // fp16 blocks in INT8 engines: int8 twin of the block output (the QUANT op that follows), or nullptr
+  int dst_q_ld;
+  float q_inv;                   // 1 / scale of the twin
+  int tail;                      // 1: the lateral 1x1 conv (2h -> h) + nearest x2 upsample that follows runs as a last step;
+                                 // 2: a plain 1x1 ConvBlock 2h -> h; 3: as 1, int8 block whose lateral writes an fp16 tensor
   void* dst2;                    // tail output (2H x 2W pixels), channel offset applied
   int dst2_ld;
   // filled by c3k2_layout():
