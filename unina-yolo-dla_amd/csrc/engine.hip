@@ -87,6 +87,7 @@ struct unina_engine {
   void* d_post_ws = nullptr;         // two-launch post-process workspace (sorted candidates, mask tiles, second ticket)
   DeviceResult* d_result = nullptr;
   DeviceResult* h_result = nullptr;  // pinned
+  DeviceResult* h_result_dev = nullptr;  // the same block as the device addresses it (hipHostGetDevicePointer)
   int post_blocks = 0;
   // graph
   bool use_graph = true;
@@ -1403,7 +1404,12 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   LOADCHK(hipMemset(e->d_post_ws, 0, post_workspace_bytes()));
   LOADCHK(hipMalloc(&e->d_result, sizeof(DeviceResult)));
   LOADCHK(hipMemset(e->d_result, 0, sizeof(DeviceResult)));
-  LOADCHK(hipHostMalloc(&e->h_result, sizeof(DeviceResult), hipHostMallocDefault));
+  LOADCHK(hipHostMalloc(&e->h_result, sizeof(DeviceResult), hipHostMallocMapped));
+  memset(e->h_result, 0, sizeof(DeviceResult));
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_result_dev), e->h_result, 0) != hipSuccess) {
+    e->h_result_dev = nullptr;
+    (void)hipGetLastError();
+  }
   LOADCHK(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
   LOADCHK(hipDeviceSynchronize());
 #undef LOADCHK
@@ -1523,9 +1529,18 @@ int unina_infer_async(unina_engine_t* e, const float* d_images, float conf, floa
 int unina_infer(unina_engine_t* e, const float* d_images, float conf, float iou, float q, GpuDetection* out,
                 int* out_count, hipStream_t stream) {
   if (!e || !out || !out_count) return UNINA_ERR_ARG;
-  int rc = unina_infer_async(e, d_images, conf, iou, q, e->d_result->det, &e->d_result->count, stream);
-  if (rc != UNINA_OK) return rc;
-  HIPCHK(e, hipMemcpyAsync(e->h_result, e->d_result, sizeof(DeviceResult), hipMemcpyDeviceToHost, stream));
+  // The post-process writes its compacted output (write-only: count + n records) straight into the pinned, device-mapped
+  // host block: no D2H copy command (a blit-kernel launch of its own, and all 1024 slots) on the latency path.
+  // UNINA_HOST_RESULT=0 restores the device buffer + copy.
+  static const bool host_result = !(getenv("UNINA_HOST_RESULT") && getenv("UNINA_HOST_RESULT")[0] == '0');
+  if (host_result && e->h_result_dev) {
+    int rc = unina_infer_async(e, d_images, conf, iou, q, e->h_result_dev->det, &e->h_result_dev->count, stream);
+    if (rc != UNINA_OK) return rc;
+  } else {
+    int rc = unina_infer_async(e, d_images, conf, iou, q, e->d_result->det, &e->d_result->count, stream);
+    if (rc != UNINA_OK) return rc;
+    HIPCHK(e, hipMemcpyAsync(e->h_result, e->d_result, sizeof(DeviceResult), hipMemcpyDeviceToHost, stream));
+  }
   HIPCHK(e, hipStreamSynchronize(stream));
   int n = e->h_result->count;
   if (n < 0 || n > MAX_DETECTIONS) return fail(e, UNINA_ERR_STATE, "post-process returned count %d", n);
