@@ -10,6 +10,8 @@
 // distinct slots keep two handles = two frames in flight trivially independent).
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -60,7 +62,8 @@ struct PlannedOp {
 struct DeviceResult {  // what the fused post-process writes; one D2H brings count + records
   int count;
   int candidates;
-  int pad[6];
+  unsigned int seq;    // host block only: the sequence number the post-process stores last (unina_infer's completion word)
+  int pad[5];
   GpuDetection det[MAX_DETECTIONS];
   long long pad_stamps[8];  // debug phase stamps of the post-process kernel (UNINA_POST_STAMPS=1)
 };
@@ -88,6 +91,9 @@ struct unina_engine {
   DeviceResult* d_result = nullptr;
   DeviceResult* h_result = nullptr;  // pinned
   DeviceResult* h_result_dev = nullptr;  // the same block as the device addresses it (hipHostGetDevicePointer)
+  unsigned int result_seq = 0;           // unina_infer calls so far
+  unsigned int* done_flag = nullptr;     // set around unina_infer's launch: the post-process signals completion there
+  unsigned int done_value = 0;
   int post_blocks = 0;
   // graph
   bool use_graph = true;
@@ -1272,6 +1278,8 @@ int fill_post_params(unina_engine* e, PostParams* pp, float conf, float iou, flo
   pp->out_count = d_count;
   pp->out_candidates = d_cand_count;
   pp->stamps = getenv("UNINA_POST_STAMPS") ? reinterpret_cast<long long*>(e->d_result->pad_stamps) : nullptr;
+  pp->done_flag = e->done_flag;
+  pp->done_value = e->done_value;
   return UNINA_OK;
 }
 
@@ -1533,15 +1541,40 @@ int unina_infer(unina_engine_t* e, const float* d_images, float conf, float iou,
   // host block: no D2H copy command (a blit-kernel launch of its own, and all 1024 slots) on the latency path.
   // UNINA_HOST_RESULT=0 restores the device buffer + copy.
   static const bool host_result = !(getenv("UNINA_HOST_RESULT") && getenv("UNINA_HOST_RESULT")[0] == '0');
+  // ... and the host does not wait for the stream either: the last block stores this call's sequence number behind the
+  // records (system-scope release) and the host spins on that word -- the runtime's completion signal of the frame graph
+  // arrives microseconds later. UNINA_HOST_POLL=0 waits with hipStreamSynchronize instead.
+  static const bool host_poll = !(getenv("UNINA_HOST_POLL") && getenv("UNINA_HOST_POLL")[0] == '0');
   if (host_result && e->h_result_dev) {
+    unsigned int seq = 0;
+    if (host_poll) {
+      seq = ++e->result_seq ? e->result_seq : ++e->result_seq;   // never 0
+      e->done_flag = &e->h_result_dev->seq;
+      e->done_value = seq;
+    }
     int rc = unina_infer_async(e, d_images, conf, iou, q, e->h_result_dev->det, &e->h_result_dev->count, stream);
+    e->done_flag = nullptr;
     if (rc != UNINA_OK) return rc;
+    if (host_poll) {
+      volatile unsigned int* flag = &e->h_result->seq;
+      const auto t0 = std::chrono::steady_clock::now();
+      bool seen = false;
+      for (unsigned long it = 1;; ++it) {
+        if (*flag == seq) { seen = true; break; }
+        __builtin_ia32_pause();
+        if ((it & 0xFFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (!seen) HIPCHK(e, hipStreamSynchronize(stream));   // (a faulted launch reports here)
+    } else {
+      HIPCHK(e, hipStreamSynchronize(stream));
+    }
   } else {
     int rc = unina_infer_async(e, d_images, conf, iou, q, e->d_result->det, &e->d_result->count, stream);
     if (rc != UNINA_OK) return rc;
     HIPCHK(e, hipMemcpyAsync(e->h_result, e->d_result, sizeof(DeviceResult), hipMemcpyDeviceToHost, stream));
+    HIPCHK(e, hipStreamSynchronize(stream));
   }
-  HIPCHK(e, hipStreamSynchronize(stream));
   int n = e->h_result->count;
   if (n < 0 || n > MAX_DETECTIONS) return fail(e, UNINA_ERR_STATE, "post-process returned count %d", n);
   memcpy(out, e->h_result->det, sizeof(GpuDetection) * (size_t)n);

@@ -275,6 +275,8 @@ struct PostParams {
   int* out_count;            // kept
   int* out_candidates;       // optional (may be nullptr): number of cells that passed the threshold
   long long* stamps;         // optional debug: 8 wall_clock64 stamps of the last block's phases (nullptr = off)
+  unsigned int* done_flag;   // optional (pinned host memory): receives done_value, system-scope release, after every output store
+  unsigned int done_value;
   // two-launch form (engine): launch 1 ends with the sorted candidates in this workspace, launch 2 builds the
   // suppression-mask tiles on many CUs and its last block scans + compacts. All nullptr = everything in launch 1.
   float4* ws_box;            // [MAX_DETECTIONS] sorted boxes

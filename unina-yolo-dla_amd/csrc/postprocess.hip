@@ -337,6 +337,15 @@ __device__ void sort_and_nms(Smem& s, int n, float iou_thr, long long* stamps = 
 
 }  // namespace
 
+// Host hand-off without a stream synchronisation: when the outputs live in pinned host memory, the last block publishes
+// them at system scope and then stores the caller's sequence number; the host spins on that word (engine.hip unina_infer).
+__device__ __forceinline__ void signal_done(const PostParams& p, int tid) {
+  if (!p.done_flag) return;
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(p.done_flag, p.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ================================================================================================ fused kernel
 extern __shared__ __align__(16) unsigned char post_smem[];
 
@@ -450,6 +459,7 @@ __global__ __launch_bounds__(kPostBlock) void postprocess_kernel(const PostParam
     __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     if (p.stamps) p.stamps[6] = wall_clock64();
   }
+  signal_done(p, tid);
 }
 
 // ---- launch 2 of the two-launch form: suppression-mask tiles on many CUs, then scan + compaction by the last block ----
@@ -561,6 +571,7 @@ __global__ __launch_bounds__(kTileThreads) void nms_tiles_kernel(const PostParam
     __hip_atomic_store(p.ticket2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     if (p.stamps) p.stamps[6] = wall_clock64();
   }
+  signal_done(p, tid);
 }
 
 namespace { hipError_t post_init(); }
