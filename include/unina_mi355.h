@@ -97,7 +97,11 @@ int unina_enqueue(unina_engine_t *e, hipStream_t stream);
  *   d_images_nchw : device, fp32 [1,3,H,W] (same as binding "images"); NULL = keep the current binding
  *   out           : HOST buffer for up to MAX_DETECTIONS records (sorted by confidence, valid=1)
  *   out_count     : HOST int
- * Synchronous: returns after the records are in `out` (one stream sync, one D2H of <= 32 KiB). */
+ * Synchronous: returns after the records are in `out`. The post-process writes the count and the kept records straight
+ * into a pinned host block and then a completion word (system-scope release); the call spins on that word, so the
+ * latency path has neither a D2H copy command nor a stream synchronisation. `stream` may still hold the tail of the
+ * frame's launch for a few microseconds after the call returns (work submitted to it later is ordered as usual).
+ * UNINA_HOST_RESULT=0 / UNINA_HOST_POLL=0 restore the device buffer + copy / hipStreamSynchronize. */
 int unina_infer(unina_engine_t *e, const float *d_images_nchw, float conf_threshold, float iou_threshold,
                 float conformal_q, GpuDetection *out, int *out_count, hipStream_t stream);
 
