@@ -105,6 +105,21 @@ int unina_enqueue(unina_engine_t *e, hipStream_t stream);
 int unina_infer(unina_engine_t *e, const float *d_images_nchw, float conf_threshold, float iou_threshold,
                 float conformal_q, GpuDetection *out, int *out_count, hipStream_t stream);
 
+/* Normalisation constants of the pre-process (pre-process C API below; also taken by unina_infer_bgra). */
+typedef struct {
+  float mean_r, mean_g, mean_b;
+  float std_r, std_g, std_b;
+} NormParams; /* cuda_preprocess.h:38-45 */
+
+/* Camera frame -> detections in one call: unina_infer with the pre-process of cuda_preprocess.h:50-112
+ * (preprocess_bgra when the frame has the network's size, preprocess_bgra_resize otherwise) computed inside the
+ * stem kernel, i.e. perception_node.cpp:601-656 (preprocess_bgra_resize ... copy_valid_detections_to_host) as ONE
+ * graph launch without the fp32 tensor in between. Identical results to the two-step form.
+ *   d_bgra : device, pitched BGRA8 (src_pitch bytes per row, multiple of 4, >= 4 * src_width) */
+int unina_infer_bgra(unina_engine_t *e, const uint8_t *d_bgra, int src_width, int src_height, int src_pitch,
+                     const NormParams *norm, float conf_threshold, float iou_threshold, float conformal_q,
+                     GpuDetection *out, int *out_count, hipStream_t stream);
+
 /* Asynchronous variant: results stay on the device (d_out: MAX_DETECTIONS records, d_out_count: one int);
  * nothing is synchronised. Used to pipeline frames and to feed the RCCL gather without touching the host. */
 int unina_infer_async(unina_engine_t *e, const float *d_images_nchw, float conf_threshold, float iou_threshold,
@@ -201,10 +216,6 @@ hipError_t copy_valid_detections_to_host(const GpuDetection *d_detections, GpuDe
  * The step right before the engine in processGpuBuffer (perception_node.cpp:601-604): camera buffer -> fp32 RGB
  * planar "images" tensor. Same names, argument order and error behaviour as the reference (allocators and the
  * stream factory return NULL on failure, cuda_preprocess.cu:395-428); arithmetic per cuda_preprocess.cu:99-253. */
-typedef struct {
-  float mean_r, mean_g, mean_b;
-  float std_r, std_g, std_b;
-} NormParams; /* cuda_preprocess.h:38-45 */
 
 NormParams create_norm_params_imagenet(void);
 NormParams create_norm_params(float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b);

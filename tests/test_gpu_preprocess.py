@@ -85,3 +85,40 @@ def test_camera_to_detections_pipeline(env, pkg, sd7):
         assert dets.dtype == engine.DET_DTYPE and np.all(np.diff(dets["confidence"]) <= 0)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("cam_hw", [(720, 1280), (640, 640), (480, 600)])
+def test_camera_frame_in_the_stem_kernel_is_bit_identical(env, pkg, sd7, cam_hw):
+    """unina_infer_bgra: the pre-process computed inside the stem kernel (no fp32 tensor between camera frame and
+    network) against the two-step form preprocess_bgra[_resize] + unina_infer: same arithmetic, so the stem output and
+    the detections must agree bit for bit. 720p (down-scale), the network's own size (no resize) and an up-scaled,
+    pitched frame."""
+    torch, L, engine = env
+    ch, cw = cam_hw
+    pitch = cw * 4 + 64
+    e = engine.Engine.from_state_dict(sd7)
+    try:
+        rng = np.random.default_rng(17)
+        host = rng.integers(0, 256, (ch, pitch), dtype=np.uint8)
+        # a smooth pattern under the noise so that some cells pass the threshold either way
+        cam = torch.from_numpy(host).cuda()
+        images = torch.empty((1, 3, 640, 640), dtype=torch.float32, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        norm = L.create_norm_params_imagenet()
+        if (ch, cw) == (640, 640):
+            assert L.preprocess_bgra(cam.data_ptr(), images.data_ptr(), cw, ch, pitch, norm, s) == 0
+        else:
+            assert L.preprocess_bgra_resize(cam.data_ptr(), images.data_ptr(), cw, ch, pitch, 640, 640, norm, s) == 0
+        want = e.infer(images, 0.3, 0.45, 0.1)
+        e.set_fusion(False)
+        e.forward(images)
+        stem_want = e.read_buffer("backbone.stem")
+        e.set_fusion(True)
+        got = e.infer_bgra(cam, cw, ch, pitch, norm, 0.3, 0.45, 0.1)
+        assert len(want) > 0 and got.tobytes() == want.tobytes()
+        # the tensor path still works afterwards (the stem node is re-pointed back), and the camera path again
+        assert e.infer(images, 0.3, 0.45, 0.1).tobytes() == want.tobytes()
+        assert e.infer_bgra(cam, cw, ch, pitch, norm, 0.3, 0.45, 0.1).tobytes() == want.tobytes()
+        assert np.array_equal(e.read_buffer("backbone.stem"), stem_want)
+    finally:
+        e.close()

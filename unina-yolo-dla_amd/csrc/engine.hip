@@ -91,6 +91,7 @@ struct unina_engine {
   DeviceResult* d_result = nullptr;
   DeviceResult* h_result = nullptr;  // pinned
   DeviceResult* h_result_dev = nullptr;  // the same block as the device addresses it (hipHostGetDevicePointer)
+  bool camera_active = false;            // inside unina_infer_bgra: the stem reads a camera frame, "images" need not be bound
   unsigned int result_seq = 0;           // unina_infer calls so far
   unsigned int* done_flag = nullptr;     // set around unina_infer's launch: the post-process signals completion there
   unsigned int done_value = 0;
@@ -1484,7 +1485,7 @@ int unina_tensor_address(const unina_engine_t* e, const char* name, void** devic
 int unina_enqueue(unina_engine_t* e, hipStream_t stream) {
   if (!e) return UNINA_ERR_ARG;
   HIPCHK(e, hipSetDevice(e->device));
-  if (!e->bufs[e->images_buf].ptr) return fail(e, UNINA_ERR_STATE, "tensor 'images' is not bound");
+  if (!e->bufs[e->images_buf].ptr && !e->camera_active) return fail(e, UNINA_ERR_STATE, "tensor 'images' is not bound");
   if (e->plan_dirty) {
     int rc = plan(e);
     if (rc != UNINA_OK) return rc;
@@ -1520,7 +1521,7 @@ int unina_infer_async(unina_engine_t* e, const float* d_images, float conf, floa
   if (e->full_graph && e->use_graph && e->n_streams <= 1) {
     if (!d_out || !d_out_count) return UNINA_ERR_ARG;
     HIPCHK(e, hipSetDevice(e->device));
-    if (!e->bufs[e->images_buf].ptr) return fail(e, UNINA_ERR_STATE, "tensor 'images' is not bound");
+    if (!e->bufs[e->images_buf].ptr && !e->camera_active) return fail(e, UNINA_ERR_STATE, "tensor 'images' is not bound");
     if (e->plan_dirty) {
       int rc = plan(e);
       if (rc != UNINA_OK) return rc;
@@ -1580,6 +1581,49 @@ int unina_infer(unina_engine_t* e, const float* d_images, float conf, float iou,
   memcpy(out, e->h_result->det, sizeof(GpuDetection) * (size_t)n);
   *out_count = n;
   return UNINA_OK;
+}
+
+// Camera frame -> detections: unina_infer with the pre-process (preprocess.hip: BGRA -> RGB, optional half-pixel-centre
+// bilinear resize, normalise) computed inside the stem kernel instead of written to an fp32 tensor by one launch and
+// read back by the next (4 B/px in instead of 12 B/px out + 12 B/px in, one launch less). Same arithmetic, so the
+// detections are those of preprocess_bgra[_resize] + unina_infer bit for bit (tests/test_gpu_preprocess.py).
+int unina_infer_bgra(unina_engine_t* e, const uint8_t* d_bgra, int src_width, int src_height, int src_pitch,
+                     const NormParams* norm, float conf, float iou, float q, GpuDetection* out, int* out_count,
+                     hipStream_t stream) {
+  if (!e || !d_bgra || !norm || !out || !out_count) return UNINA_ERR_ARG;
+  if (src_width <= 0 || src_height <= 0 || src_pitch < 4 * src_width || (src_pitch & 3) || ((uintptr_t)d_bgra & 3))
+    return fail(e, UNINA_ERR_ARG, "unina_infer_bgra: bad frame geometry");
+  HIPCHK(e, hipSetDevice(e->device));
+  if (e->plan_dirty) {
+    int rc = plan(e);
+    if (rc != UNINA_OK) return rc;
+  }
+  int nstem = 0;
+  for (size_t k = 0; k < e->ops.size(); ++k) {
+    PlannedOp& op = e->ops[k];
+    if (!is_eager(e, k) || op.d.kind != kOpStem) continue;
+    if (e->fuse && op.fuse_role == 1 && op.fuse_kind == 3) return fail(e, UNINA_ERR_UNSUPPORTED, "unina_infer_bgra with the fused stem+conv kernel");
+    op.sp.src_kind = (src_width == op.sp.W && src_height == op.sp.H) ? 1 : 2;
+    op.sp.cam = d_bgra;
+    op.sp.cam_w = src_width;
+    op.sp.cam_h = src_height;
+    op.sp.cam_pitch = src_pitch;
+    op.sp.norm = *norm;
+    ++nstem;
+  }
+  if (!nstem) return fail(e, UNINA_ERR_STATE, "no stem op reads the input tensor");
+  e->camera_active = true;
+  const int rc = unina_infer(e, nullptr, conf, iou, q, out, out_count, stream);
+  e->camera_active = false;
+  for (size_t k = 0; k < e->ops.size(); ++k) {
+    PlannedOp& op = e->ops[k];
+    if (!is_eager(e, k) || op.d.kind != kOpStem) continue;
+    op.sp.src_kind = 0;
+    op.sp.cam = nullptr;
+    op.sp.cam_w = op.sp.cam_h = op.sp.cam_pitch = 0;
+    memset(&op.sp.norm, 0, sizeof op.sp.norm);
+  }
+  return rc;
 }
 
 int unina_debug_post_stamps(unina_engine_t* e, long long* out8) {
@@ -1693,7 +1737,7 @@ int unina_set_op_config(unina_engine_t* e, int op_index, int cfg) {
 int unina_autotune(unina_engine_t* e, int iters, hipStream_t stream) {
   if (!e || iters < 1) return UNINA_ERR_ARG;
   HIPCHK(e, hipSetDevice(e->device));
-  if (!e->bufs[e->images_buf].ptr) return fail(e, UNINA_ERR_STATE, "tensor 'images' is not bound");
+  if (!e->bufs[e->images_buf].ptr && !e->camera_active) return fail(e, UNINA_ERR_STATE, "tensor 'images' is not bound");
   if (e->plan_dirty) {
     int rc = plan(e);
     if (rc != UNINA_OK) return rc;
@@ -1730,7 +1774,7 @@ int unina_autotune(unina_engine_t* e, int iters, hipStream_t stream) {
 int unina_profile_ops(unina_engine_t* e, int iters, float* ms_per_op, hipStream_t stream) {
   if (!e || !ms_per_op || iters < 1) return UNINA_ERR_ARG;
   HIPCHK(e, hipSetDevice(e->device));
-  if (!e->bufs[e->images_buf].ptr) return fail(e, UNINA_ERR_STATE, "tensor 'images' is not bound");
+  if (!e->bufs[e->images_buf].ptr && !e->camera_active) return fail(e, UNINA_ERR_STATE, "tensor 'images' is not bound");
   if (e->plan_dirty) {
     int rc = plan(e);
     if (rc != UNINA_OK) return rc;

@@ -206,6 +206,12 @@ bool head_tile_is(const HeadParams& p, int th, int tw);
 // ------------------------------------------------------------------------------------------------
 struct StemParams {
   int dtype;           // DType of dst
+  int src_kind;        // 0: fp32 planar tensor `src`; 1: BGRA u8 camera frame of the network's size; 2: BGRA u8 frame of
+                       // cam_w x cam_h, bilinear-resized to W x H -- 1 / 2 compute the pre-process (preprocess.hip, same
+                       // arithmetic) on the fly instead of reading a tensor it would have written (unina_infer_bgra)
+  const unsigned char* cam;   // src_kind 1 / 2: pitched BGRA
+  int cam_w, cam_h, cam_pitch;
+  NormParams norm;
   const float* src;    // [3][H][W]
   const float* w;      // [Co][27], (c,kh,kw)
   const float* bias;   // [Co]

@@ -19,6 +19,37 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // distinct addresses per wave, and each thread stores its pixel's CO/2 contiguous NHWC channels.
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
+// Network-input pixel (y, x) of a camera frame: the arithmetic of preprocess.hip (cuda_preprocess.cu:99-128 plain BGRA,
+// :144-204 half-pixel-centre bilinear resize), expression trees rounded exactly as written there.
+__device__ __forceinline__ void camera_pixel(const StemParams& p, int y, int x, float (&rgb)[3]) {
+#pragma clang fp contract(off)
+  float r, g, b;
+  if (p.src_kind == 1) {
+    const uchar4 px = *reinterpret_cast<const uchar4*>(p.cam + (size_t)y * p.cam_pitch + (size_t)x * 4);  // B,G,R,A
+    r = (float)px.z; g = (float)px.y; b = (float)px.x;
+  } else {
+    const int sw = p.cam_w, sh = p.cam_h;
+    const float scale_x = (float)sw / p.W, scale_y = (float)sh / p.H;
+    float sx = (x + 0.5f) * scale_x - 0.5f, sy = (y + 0.5f) * scale_y - 0.5f;
+    sx = fmaxf(0.0f, fminf(sx, sw - 1.0f));
+    sy = fmaxf(0.0f, fminf(sy, sh - 1.0f));
+    const int x0 = (int)sx, y0 = (int)sy;
+    const int x1 = min(x0 + 1, sw - 1), y1 = min(y0 + 1, sh - 1);
+    const float fx = sx - x0, fy = sy - y0;
+    const float w00 = (1.0f - fx) * (1.0f - fy), w01 = fx * (1.0f - fy), w10 = (1.0f - fx) * fy, w11 = fx * fy;
+    const uchar4 p00 = *reinterpret_cast<const uchar4*>(p.cam + (size_t)y0 * p.cam_pitch + (size_t)x0 * 4);
+    const uchar4 p01 = *reinterpret_cast<const uchar4*>(p.cam + (size_t)y0 * p.cam_pitch + (size_t)x1 * 4);
+    const uchar4 p10 = *reinterpret_cast<const uchar4*>(p.cam + (size_t)y1 * p.cam_pitch + (size_t)x0 * 4);
+    const uchar4 p11 = *reinterpret_cast<const uchar4*>(p.cam + (size_t)y1 * p.cam_pitch + (size_t)x1 * 4);
+    r = w00 * p00.z + w01 * p01.z + w10 * p10.z + w11 * p11.z;
+    g = w00 * p00.y + w01 * p01.y + w10 * p10.y + w11 * p11.y;
+    b = w00 * p00.x + w01 * p01.x + w10 * p10.x + w11 * p11.x;
+  }
+  rgb[0] = ((r / 255.0f) - p.norm.mean_r) / p.norm.std_r;
+  rgb[1] = ((g / 255.0f) - p.norm.mean_g) / p.norm.std_g;
+  rgb[2] = ((b / 255.0f) - p.norm.mean_b) / p.norm.std_b;
+}
+
 template <typename T, int CO>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
   constexpr int CH = CO / 2;  // channels per thread
@@ -33,18 +64,34 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
   const int oy = m / p.Wo, ox = m - oy * p.Wo;
   float x[27];
   const size_t plane = (size_t)p.H * p.W;
+  if (p.src_kind == 0) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int iy = oy * 2 + kh - 1;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int ix = ox * 2 + kw - 1;
+          const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+          x[(c * 3 + kh) * 3 + kw] = ok ? p.src[c * plane + (size_t)iy * p.W + ix] : 0.f;
+        }
+      }
+  } else {
+    // camera frame: the network-input pixel (iy, ix) is computed as preprocess.hip would have written it
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int iy = oy * 2 + kh - 1;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int ix = ox * 2 + kw - 1;
-        const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        x[(c * 3 + kh) * 3 + kw] = ok ? p.src[c * plane + (size_t)iy * p.W + ix] : 0.f;
+        float rgb[3] = {0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) camera_pixel(p, iy, ix, rgb);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[(c * 3 + kh) * 3 + kw] = rgb[c];
       }
     }
+  }
   floatx2 acc[CH / 2];
 #pragma unroll
   for (int r = 0; r < CH / 2; ++r) acc[r] = *reinterpret_cast<const floatx2*>(&sb[c0 + 2 * r]);

@@ -46,7 +46,7 @@ _lib: Optional[C.CDLL] = None
 # every symbol include/unina_mi355.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "unina_load_engine", "unina_unload_engine", "unina_engine_input_dims", "unina_set_tensor_address",
-    "unina_tensor_address", "unina_enqueue", "unina_infer", "unina_infer_async", "unina_postprocess_async",
+    "unina_tensor_address", "unina_enqueue", "unina_infer", "unina_infer_bgra", "unina_infer_async", "unina_postprocess_async",
     "unina_last_error", "unina_op_count", "unina_get_op_info", "unina_profile_ops", "unina_debug_read_buffer",
     "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune", "unina_debug_post_stamps", "unina_debug_conv_stamps",
     "unina_set_fusion", "unina_fusion_groups", "unina_debug_fusable_groups",
@@ -76,6 +76,7 @@ def load_library() -> C.CDLL:
     L.unina_enqueue.argtypes = [vp, vp]
     L.unina_infer.argtypes = [vp, vp, cf, cf, cf, vp, C.POINTER(ci), vp]
     L.unina_infer_async.argtypes = [vp, vp, cf, cf, cf, vp, vp, vp]
+    L.unina_infer_bgra.argtypes = [vp, vp, ci, ci, ci, C.POINTER(NormParams), cf, cf, cf, vp, C.POINTER(ci), vp]
     L.unina_postprocess_async.argtypes = [vp, cf, cf, cf, vp, vp, vp]
     L.unina_last_error.argtypes = [vp]
     L.unina_last_error.restype = C.c_char_p
@@ -217,6 +218,18 @@ class Engine:
         n = C.c_int()
         self._check(self.L.unina_infer(self.h, None, conf_thr, iou_thr, conformal_q, out.ctypes.data, C.byref(n),
                                        _stream_ptr(stream)))
+        return out[:n.value].copy()
+
+    def infer_bgra(self, frame, width: int, height: int, pitch: int, norm: Optional[NormParams] = None,
+                   conf_thr: float = 0.5, iou_thr: float = 0.45, conformal_q: float = 0.1, stream=None):
+        """Camera frame (uint8 CUDA tensor, pitched BGRA) -> detections: the pre-process runs inside the stem kernel
+        (perception_node.cpp:601-656 as one launch sequence, no fp32 tensor in between)."""
+        if norm is None:
+            norm = self.L.create_norm_params_imagenet()
+        out = np.zeros(MAX_DETECTIONS, dtype=DET_DTYPE)
+        n = C.c_int()
+        self._check(self.L.unina_infer_bgra(self.h, frame.data_ptr(), width, height, pitch, C.byref(norm), conf_thr, iou_thr,
+                                            conformal_q, out.ctypes.data, C.byref(n), _stream_ptr(stream)))
         return out[:n.value].copy()
 
     def infer_async(self, images, conf_thr: float = 0.5, iou_thr: float = 0.45, conformal_q: float = 0.1,
