@@ -830,6 +830,16 @@ __global__ __launch_bounds__(512, 4) void conv_dual_head3x3_i8(const ConvParams 
   if ((int)blockIdx.x < na) conv3x3_regq_body<8, 16, 64, 128, 8, 8, 1, false, 1, signed char>(pa, (int)blockIdx.x, na);
   else conv3x3_regq_body<8, 8, 64, 256, 8, 8, 1, false, 1, signed char>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
 }
+// Twice the pixels per workgroup (16x16 | 8x16): 100 + 104 workgroups at 640^2 -- ONE per CU instead of up to two, so the
+// busiest CU streams one workgroup's weights (147 / 295 KB) instead of two's, with a full-depth queue.
+__global__ __launch_bounds__(512) void conv_dual_head3x3_big(const ConvParams pa, const ConvParams pb, int na) {
+  if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 16, 1>(pa, (int)blockIdx.x, na);
+  else conv3x3_regq_body<8, 16, 64, 256, 8, 16, 1>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
+}
+__global__ __launch_bounds__(512) void conv_dual_head3x3_big_i8(const ConvParams pa, const ConvParams pb, int na) {
+  if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 16, 1, false, 1, signed char>(pa, (int)blockIdx.x, na);
+  else conv3x3_regq_body<8, 16, 64, 256, 8, 16, 1, false, 1, signed char>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
+}
 // Variant with 128-channel workgroup tiles and two subtiles per wave (half the LDS fragment reads per MFMA): 100 + 100
 // workgroups, one per CU.
 __global__ __launch_bounds__(512) void conv_dual_head3x3_w2(const ConvParams pa, const ConvParams pb, int na) {
@@ -944,6 +954,8 @@ const CfgInfo kCfg[3][kCfgCount] = {
         // two channel subtiles per wave: each activation fragment feeds two MFMAs
         REGQW(8, 16, 128, 128, 8, 16),                // kCfgRegqW8x16n128c128
         REGQW(8, 8, 128, 256, 8, 16),                 // kCfgRegqW8x8n128c256
+        REGQ(16, 16, 64, 128, 8, 16),                 // kCfgRegq16x16n64c128  (P3 head layers, one workgroup per CU with the next)
+        REGQ(8, 16, 64, 256, 8, 16),                  // kCfgRegq8x16n64c256   (P4 head layers)
     },
     {
         CFG(float, "f32", 64, 64, 64, 2, 2, 4),
@@ -974,8 +986,8 @@ const CfgInfo kCfg[3][kCfgCount] = {
         HALO(float, "f32", 8, 16, 64, 128, 2, 2, 4),
         CFG(float, "f32", 32, 64, 128, 1, 4, 4),
         CFG(float, "f32", 64, 64, 128, 2, 2, 4),
-        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,     // register-queue kernels are fp16 only
-        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,     // register-queue kernels: fp16 / int8 only
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
     },
     {
         CFG(signed char, "i8", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
@@ -1020,6 +1032,8 @@ const CfgInfo kCfg[3][kCfgCount] = {
         NOCFG,                                        // kCfgRegqS2_8x16n64c32    (Cin 32 < one int8 block)
         REGQI2(8, 8, 32, 128, 8, 16),                 // kCfgRegqS2_8x8n32c128
         NOCFG, NOCFG,
+        REGQI(16, 16, 64, 128, 8, 16),                // kCfgRegq16x16n64c128
+        REGQI(8, 16, 64, 256, 8, 16),                 // kCfgRegq8x16n64c256
     },
 };
 #undef CFG
@@ -1057,6 +1071,7 @@ int n_tiles(const ConvParams& p, int bn) {
 hipError_t conv_init() {
   for (const void* f : {reinterpret_cast<const void*>(conv_dual_head3x3), reinterpret_cast<const void*>(conv_dual_head1x1),
                         reinterpret_cast<const void*>(conv_dual_head3x3_w2), reinterpret_cast<const void*>(conv_dual_head3x3_i8),
+                        reinterpret_cast<const void*>(conv_dual_head3x3_big), reinterpret_cast<const void*>(conv_dual_head3x3_big_i8),
                         reinterpret_cast<const void*>(stem_conv3x3s2_kernel)}) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (e != hipSuccess) return e;
@@ -1208,16 +1223,25 @@ const DualKind kDual[] = {
     {kCfg128x16k64, kCfg128x16k64, 256, "conv_dual_head1x1<glds 128,16,64 x2>", conv_dual_head1x1},
     {kCfgRegqW8x16n128c128, kCfgRegqW8x8n128c256, 512, "conv_dual_head3x3_w2<regq 8x16,128,128,wn2 | regq 8x8,128,256,wn2>", conv_dual_head3x3_w2},
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3_i8<regq i8,8x16,64,128 | regq i8,8x8,64,256>", conv_dual_head3x3_i8},
+    {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big<regq 16x16,64,128 | regq 8x16,64,256>", conv_dual_head3x3_big},
+    {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big_i8<regq i8,16x16,64,128 | regq i8,8x16,64,256>", conv_dual_head3x3_big_i8},
 };
-constexpr int kDualKinds = 4;
+constexpr int kDualKinds = 6;
 }  // namespace
 
 int conv_dual_match(const ConvParams& a, const ConvParams& b) {
   if (a.stamps || b.stamps) return -1;
-  if (a.dtype == kI8 && b.dtype == kI8)
+  // 16x16 | 8x16 pixel tiles (one workgroup per CU): default for fp16 (39.5 vs 41.4 us per frame for the two pairs,
+  // +2.5 % frames/s), opt-in for int8 (measured slower: 0.229 vs 0.2245 ms). UNINA_DUAL_BIG=0 / 1 overrides.
+  const char* bigenv = getenv("UNINA_DUAL_BIG");
+  const bool big = bigenv ? bigenv[0] == '1' : (a.dtype == kF16);
+  if (a.dtype == kI8 && b.dtype == kI8) {
+    if (big && a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[5].cfg_a) && conv_config_valid(b, kDual[5].cfg_b)) return 5;
     return (a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[3].cfg_a) && conv_config_valid(b, kDual[3].cfg_b)) ? 3 : -1;
+  }
   if (a.dtype != kF16 || b.dtype != kF16) return -1;
   static const bool w2 = getenv("UNINA_DUAL_W2") && getenv("UNINA_DUAL_W2")[0] == '1';
+  if (big && a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[4].cfg_a) && conv_config_valid(b, kDual[4].cfg_b)) return 4;
   if (w2 && a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[2].cfg_a) && conv_config_valid(b, kDual[2].cfg_b)) return 2;
   if (a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[0].cfg_a) && conv_config_valid(b, kDual[0].cfg_b)) return 0;
   auto tiny = [](const ConvParams& p) {

@@ -70,6 +70,7 @@ enum ConvConfig : int {
   kCfgRegq8x8n64c256w4, kCfgRegq8x16n64c128w4, kCfgRegq8x8n128c256,
   kCfgRegqS2_8x8n64c64, kCfgRegqS2_8x16n64c64, kCfgRegqS2_8x8n64c128, kCfgRegqS2_4x8n64c128, kCfgRegqS2_8x16n64c32, kCfgRegqS2_8x8n32c128,
   kCfgRegqW8x16n128c128, kCfgRegqW8x8n128c256,
+  kCfgRegq16x16n64c128, kCfgRegq8x16n64c256,
   kCfgCount
 };
 struct ConvLaunch {
