@@ -39,12 +39,12 @@ struct HClass {
 const HClass kHeadClasses[] = {
     {64, 8, 16, 8, "head_fused<64,8x16,8w>", head_fused_kernel<64, 8, 16, 8, 16>},
     {64, 8, 8, 8, "head_fused<64,8x8,8w>", head_fused_kernel<64, 8, 8, 8, 16>},     // UNINA_HEAD_ALT=1 (A/B experiments)
+    {64, 16, 16, 8, "head_fused<64,16x16,8w>", head_fused_kernel<64, 16, 16, 8, 16>},  // UNINA_HEAD_ALT=2
 };
 const HClass* find_hclass(int c) {
   static const int alt = getenv("UNINA_HEAD_ALT") ? atoi(getenv("UNINA_HEAD_ALT")) : 0;
   const int n = (int)(sizeof(kHeadClasses) / sizeof(kHeadClasses[0]));
-  for (int i = alt ? 1 : 0; i < (alt ? n : 1); ++i)
-    if (kHeadClasses[i].c == c) return &kHeadClasses[i];
+  if (alt >= 0 && alt < n && kHeadClasses[alt].c == c) return &kHeadClasses[alt];
   return nullptr;
 }
 constexpr int kMaxLds = 160 * 1024;
