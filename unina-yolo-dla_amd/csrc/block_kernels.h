@@ -15,12 +15,23 @@ namespace dev {
 // TAIL = 3 is TAIL = 1 for an int8 block whose lateral writes an fp16 tensor (INT8 engines: fpn_c3k2_1 -> lateral_p2
 // into the fp16 concat buffer of the narrow fpn_c3k2_2 block).
 // KBLK = k per weight block (32 fp16 / 64 int8).
-template <int H_, int NB, int CIN, int NW, int TAIL, int KBLK = 32>
+// CPRE != 0 prepends the 3x3 / stride-2 ConvBlock (CPRE -> CIN channels) that produces the block's input (stage1_conv ->
+// stage1_block, model.py:177-190): its output on the block's input region is computed in place instead of being written
+// to HBM by one launch and DMA'd back by the next.
+template <int H_, int NB, int CIN, int NW, int TAIL, int KBLK = 32, int CPRE = 0>
 struct C3k2Plan {
-  static constexpr int CV3 = 1 + 2 * NB;        // index of the cv3 step
-  static constexpr int N = 2 + 2 * NB + (TAIL ? 1 : 0);
-  static constexpr int kb(int s) { return s == 0 ? CIN / KBLK : (s >= CV3 ? 2 * H_ / KBLK : ((s & 1) ? H_ / KBLK : 9 * H_ / KBLK)); }
-  static constexpr int ns(int s) { return (s == 0 || s == CV3) ? 2 * H_ / 16 : H_ / 16; }
+  static constexpr int PRE = CPRE ? 1 : 0;
+  static constexpr int CV3 = PRE + 1 + 2 * NB;  // index of the cv3 step
+  static constexpr int N = PRE + 2 + 2 * NB + (TAIL ? 1 : 0);
+  static constexpr int kb(int s) {
+    if (PRE && s == 0) return 9 * CPRE / KBLK;
+    const int t = s - PRE;
+    return t == 0 ? CIN / KBLK : (s >= CV3 ? 2 * H_ / KBLK : ((t & 1) ? H_ / KBLK : 9 * H_ / KBLK));
+  }
+  static constexpr int ns(int s) {
+    if (PRE && s == 0) return CIN / 16;
+    return (s == PRE || s == CV3) ? 2 * H_ / 16 : H_ / 16;
+  }
   static constexpr int wnt(int s) { return ns(s) <= NW ? 1 : ns(s) / NW; }
   static constexpr int nch(int s) { return 16 * ns(s); }              // output channels of step s
   static constexpr int cfirst(int s) {                                 // channels of all earlier steps
@@ -36,10 +47,12 @@ struct C3k2Plan {
 // compiler's counted s_waitcnt vmcnt keeps D loads in flight across every step boundary.
 // E = EltH (fp16 engines and carve-outs) or EltI8 (INT8 engines: every tensor of the block is an int8 code image with
 // its per-tensor scale; the epilogues re-quantise exactly as the per-op kernels do, conv_igemm.hip conv_epilogue).
-template <int H_, int TH, int TW, int NB, int CIN, int NW, int D, int TAIL = 0, typename E = EltH>
+template <int H_, int TH, int TW, int NB, int CIN, int NW, int D, int TAIL = 0, typename E = EltH, int CPRE = 0>
 __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, unsigned char* smem) {
   static_assert(NB == 1 || NB == 2, "bottleneck count");
-  typedef C3k2Plan<H_, NB, CIN, NW, TAIL, E::KBLK> PL;
+  typedef C3k2Plan<H_, NB, CIN, NW, TAIL, E::KBLK, CPRE> PL;
+  constexpr int PRE = PL::PRE;
+  static_assert(CPRE % E::KBLK == 0, "a weight block must not straddle a tap");
   typedef StepTable<PL, NW> ST;
   static_assert(ST::valid(), "wave roles");
   static_assert((NW & (NW - 1)) == 0 && NW >= 2 && NW <= 16, "waves per workgroup");
@@ -63,11 +76,16 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
   // per-channel constants of every step -> LDS
   float* bias_lds = reinterpret_cast<float*>(smem + p.off_bias);
   for (int i = threadIdx.x; i < p.n_bias; i += NT) bias_lds[i] = p.bias[i];
-#define CST(S) (bias_lds + E::CM * PL::cfirst(S))
+#define CST(S) (bias_lds + E::CM * PL::cfirst((S) + PRE))
 
-  // input patch (tile + NB-pixel halo, all CIN channels) -> LDS image
+  // input patch (tile + NB-pixel halo, all CIN channels) -> LDS image; with a pre-conv: ITS input footprint instead
   constexpr Img X = make_img(0, CIN / E::CH);
-  load_patch<TH + 2 * NB, R0W, CIN, NT, E>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0 - NB, tx0 - NB, p.zeros, wid, lane);
+  constexpr int PH = 2 * (TH + 2 * NB - 1) + 3, PW = 2 * (R0W - 1) + 3;   // footprint of R0 under a 3x3 / stride-2 conv
+  if constexpr (PRE)
+    load_patch<PH, PW, (CPRE ? CPRE : E::KBLK), NT, E>(smem + p.off_p, p.src, p.src_ld, p.preH, p.preW, 2 * (ty0 - NB) - 1,
+                                                     2 * (tx0 - NB) - 1, p.zeros, wid, lane);
+  else
+    load_patch<TH + 2 * NB, R0W, CIN, NT, E>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0 - NB, tx0 - NB, p.zeros, wid, lane);
   static_for<0, D>([&](auto gc) { wq_fetch<ST, D, decltype(gc)::value>(q, wbase, wid); });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed (LDS-DMA is not tracked by the compiler)
   lds_barrier();
@@ -82,8 +100,28 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
   auto run_step = [&](auto sc, auto pc, auto baddr, auto epi) {
     dev::run_step<ST, D, decltype(sc)::value, decltype(pc)::value, E>(q, wbase, smem, wid, lane, baddr, epi);
   };
-#define STEP(S, P) std::integral_constant<int, (S)>{}, std::integral_constant<int, (P)>{}
+#define STEP(S, P) std::integral_constant<int, (S) + PRE>{}, std::integral_constant<int, (P)>{}
   typedef typename E::acc_t acc_t;
+
+  if constexpr (PRE) {
+    // ---- pre-step: x = ReLU(3x3/s2 conv of the patch + b) on R0 -> the block's input image ----
+    constexpr Img PI0 = make_img(0, (CPRE ? CPRE : E::KBLK) / E::CH);
+    const Img PI = Img{p.off_p, PI0.nch, PI0.sh, PI0.mask};
+    constexpr int CBP = (CPRE ? CPRE : E::KBLK) / E::KBLK;
+    const float* c0 = bias_lds;
+    dev::run_step<ST, D, 0, P0, E>(q, wbase, smem, wid, lane,
+        [&](int sub, auto kc) {
+          constexpr int kb = decltype(kc)::value, tap = kb / CBP, cb = kb - tap * CBP, th3 = tap / 3;
+          int r = sub * 16 + l15;
+          r = r < P0 ? r : P0 - 1;
+          const int ry = r / R0W, rx = r - ry * R0W;
+          return PI.addr((2 * ry + th3) * PW + 2 * rx + (tap - th3 * 3), cb * 4 + lq);
+        },
+        [&](int sub, int n, const acc_t& acc) {
+          const int r = sub * 16 + l15;
+          if (r < P0) store4<E, CIN>(smem + img_at<E>(Xi, r, n), act_relu<E, CIN>(acc, c0, n), c0, n);
+        });
+  }
 
   // ---- step 0: a | b = ReLU(W12 x + b12) on R0 --------------------------------------------------------------------
   run_step(STEP(0, P0),

@@ -53,6 +53,7 @@ struct PlannedOp {
   bool dual_absorbed = false;   // runs inside an earlier op's dual launch
   int tail_op = -1;         // role 1, C3k2: index of the 1x1 conv that runs as the block kernel's last step
   int tail_kind = 0;        // 1: lateral 1x1 + x2 upsample store; 2: plain 1x1 ConvBlock (same resolution); 3: 1 with int8 in, fp16 out
+  int fuse_pre = 0;         // role 1, C3k2: 1 = this op is the 3x3/s2 conv in front of the block (the block's cv1|cv2 is the NEXT op)
   int quant_op = -1;        // role 1, fp16 C3k2 in an INT8 engine: the QUANT op of the block's output that the kernel's store absorbs
   int hid = 0, nb = 0;      // role 1: hidden width, bottleneck count
   uint64_t stream_off = 0, fbias_off = 0;   // role 1: blob offsets of the packed stage stream / concatenated biases
@@ -474,23 +475,29 @@ int plan(unina_engine* e) {
       snprintf(info.name, sizeof info.name, "%.*s[head]", (int)(strchr(a.name, '.') ? strchr(a.name, '.') - a.name : 60), a.name);
       continue;
     }
-    const OpDesc& a = op.d;
+    const OpDesc& a = e->ops[i + op.fuse_pre].d;   // the block's cv1|cv2
     const OpDesc& z = e->ops[op.group_last].d;
-    const Buffer& src = e->bufs[a.src_buf];
+    const OpDesc& in = op.d;                       // the op whose input the kernel reads (the pre-conv, or cv1|cv2 itself)
+    const Buffer& src = e->bufs[in.src_buf];
     const Buffer& dst = e->bufs[z.seg[0].dst_buf];
     C3k2Params& f = op.fp;
     memset(&f, 0, sizeof f);
     f.dtype = act_dtype_of(src.d.dtype);
     const size_t fesz = dtype_size(f.dtype);
-    f.src = static_cast<const char*>(src.ptr) + a.seg[0].src_coff * fesz;
+    f.src = static_cast<const char*>(src.ptr) + in.seg[0].src_coff * fesz;
     f.src_ld = (int)src.d.c;
+    if (op.fuse_pre) {
+      f.cpre = (int)in.cin;
+      f.preH = (int)in.in_h;
+      f.preW = (int)in.in_w;
+    }
     f.Cin = (int)a.cin;
     f.H = (int)a.in_h;
     f.W = (int)a.in_w;
     f.dst = static_cast<char*>(dst.ptr) + z.seg[0].dst_coff * fesz;
     f.dst_ld = (int)dst.d.c;
     for (int b = 0; b < op.nb; ++b) {   // int8: scale of each bottleneck's shortcut tensor (the 3x3's residual buffer)
-      const OpDesc& c2 = e->ops[i + 2 + 2 * b].d;
+      const OpDesc& c2 = e->ops[i + op.fuse_pre + 2 + 2 * b].d;
       f.res_scale[b] = c2.res_buf >= 0 ? e->bufs[c2.res_buf].d.scale : 1.0f;
     }
     f.wstream = reinterpret_cast<const unsigned char*>(blob + op.stream_off);
@@ -535,13 +542,13 @@ int plan(unina_engine* e) {
       }
     }
     info.flops = flops;
-    info.bytes = (double)fesz * f.H * f.W * f.Cin + wbytes + (double)fesz * f.H * f.W * 2 * f.hid +   // input once, weights once, output once
+    info.bytes = (f.cpre ? (double)fesz * f.preH * f.preW * f.cpre : (double)fesz * f.H * f.W * f.Cin) + wbytes + (double)fesz * f.H * f.W * 2 * f.hid +   // input once, weights once, output once
                  (f.tail ? (double)fesz * (f.tail == 1 ? 4 : 1) * f.H * f.W * f.hid : 0.0);            // (+ the tail conv's output)
     info.n = 2 * f.hid;
     info.k = 0;
     info.grid = f.tiles_x * f.tiles_y;
-    info.block = c3k2_block_threads(f.hid, f.nb, f.Cin, f.tail, f.dtype);
-    snprintf(info.kernel, sizeof info.kernel, "%s", c3k2_kernel_name(f.hid, f.nb, f.Cin, f.tail, f.dtype));
+    info.block = c3k2_block_threads(f.hid, f.nb, f.Cin, f.tail, f.dtype, f.cpre);
+    snprintf(info.kernel, sizeof info.kernel, "%s", c3k2_kernel_name(f.hid, f.nb, f.Cin, f.tail, f.dtype, f.cpre));
     snprintf(info.name, sizeof info.name, "%.*s[c3k2 x%d]", (int)(strchr(a.name, '+') ? strchr(a.name, '+') - a.name - 4 : 60), a.name, f.nb);
   }
   // dual launches: pair independent convs of one kernel family (the P3 / P4 head layers) into one grid each. The later
@@ -871,13 +878,29 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
           e->bufs[qd.seg[0].dst_buf].d.c == 2 * h && !e->ops[jt + 1].fuse_role)
         quant_op = (int)(jt + 1);
     }
+    // the 3x3 / stride-2 ConvBlock that produces the block's input (stage1_conv -> stage1_block) as a first step, when the
+    // block is its only reader (the input tensor then never exists in HBM) and a class exists
+    size_t i0 = i;   // first op of the group
+    if (i > 0 && !e->ops[i - 1].fuse_role) {
+      const OpDesc& pz = e->ops[i - 1].d;
+      if (pz.kind == kOpConv && pz.ksize == 3 && pz.stride == 2 && pz.relu && pz.nseg == 1 && pz.res_buf < 0 && !pz.seg[0].flags &&
+          (pz.seg[0].m_off != 0) == i8 && pz.seg[0].n_pad == pz.seg[0].n_count && pz.seg[0].dst_buf == a.src_buf &&
+          pz.seg[0].dst_coff == a.seg[0].src_coff && pz.seg[0].n_count == a.cin && e->bufs[a.src_buf].d.c == a.cin &&
+          e->bufs[pz.src_buf].d.dtype == bdt && pz.seg[0].src_coff % al == 0 && e->bufs[pz.src_buf].d.c % al == 0 &&
+          pz.out_h == a.in_h && pz.out_w == a.in_w && pz.src_buf != a.src_buf &&
+          c3k2_supported((int)h, nb, (int)a.cin, tail_kind, dt, (int)pz.cin)) {
+        i0 = i - 1;
+        inter.push_back(a.src_buf);
+      }
+    }
+    const OpDesc& first = e->ops[i0].d;
     // the group's intermediates must be private to it, and must not be its own input or output
     bool priv = true;
     for (uint32_t b : inter) {
       if (e->bufs[b].d.dtype != bdt) priv = false;   // (an INT8 engine's fp16 conv may still write an int8 buffer)
-      if (b == a.src_buf || b == z.seg[0].dst_buf || (e->bufs[b].d.flags & (kBufInput | kBufOutput))) priv = false;
+      if (b == first.src_buf || b == z.seg[0].dst_buf || (e->bufs[b].d.flags & (kBufInput | kBufOutput))) priv = false;
       for (size_t k = 0; k < n && priv; ++k) {
-        if (k >= i && k <= j) continue;
+        if (k >= i0 && k <= j) continue;
         const OpDesc& o = e->ops[k].d;
         if (o.src_buf == b || o.res_buf == (int)b) priv = false;
         for (uint32_t s = 0; s < o.nseg; ++s)
@@ -887,7 +910,7 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     if (!priv) continue;
     // pack
     std::vector<C3k2Conv> convs;
-    for (size_t k = i; k <= jt; ++k) {
+    for (size_t k = i0; k <= jt; ++k) {
       const OpDesc& o = e->ops[k].d;
       C3k2Conv cv;
       memset(&cv, 0, sizeof cv);
@@ -905,16 +928,17 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     }
     std::vector<unsigned char> stream;
     std::vector<float> bias;
-    if (!c3k2_pack((int)h, nb, (int)a.cin, tail_kind, convs.data(), &stream, &bias, dt)) continue;
+    if (!c3k2_pack((int)h, nb, (int)a.cin, tail_kind, convs.data(), &stream, &bias, dt, i0 < i ? (int)first.cin : 0)) continue;
     blob->resize((blob->size() + 255) & ~(size_t)255);
     const uint64_t so = blob->size();
     blob->insert(blob->end(), stream.begin(), stream.end());
     blob->resize((blob->size() + 255) & ~(size_t)255);
     const uint64_t bo = blob->size();
     blob->insert(blob->end(), reinterpret_cast<const char*>(bias.data()), reinterpret_cast<const char*>(bias.data() + bias.size()));
-    PlannedOp& head = e->ops[i];
+    PlannedOp& head = e->ops[i0];
     head.fuse_role = 1;
     head.fuse_kind = 1;
+    head.fuse_pre = i0 < i ? 1 : 0;
     head.group_last = (int)j;
     head.hid = (int)h;
     head.nb = nb;
@@ -924,7 +948,7 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     head.tail_kind = tail_kind;
     head.quant_op = quant_op;
     if (quant_op >= 0) e->ops[quant_op].fuse_role = 2;
-    for (size_t k = i + 1; k <= jt; ++k) e->ops[k].fuse_role = 2;
+    for (size_t k = i0 + 1; k <= jt; ++k) e->ops[k].fuse_role = 2;
     ++e->n_groups;
     i = jt;
   }
