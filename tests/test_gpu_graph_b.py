@@ -71,8 +71,9 @@ def test_graph_b_fusion_is_bit_identical(pkg, sd7b, torch_cuda, size):
         fused_bufs = {b: e.read_buffer(b) for b in bufs}
         assert e.set_fusion(False) == 0
         plain = e.forward(x)
+        from test_gpu_parity import written     # (down1 / down2 run inside the PAN blocks: their half of the concat is not written)
         for b in bufs:
-            assert np.array_equal(fused_bufs[b], e.read_buffer(b)), b
+            assert np.array_equal(written(b, fused_bufs[b]), written(b, e.read_buffer(b))), b
         for k in plain:
             assert np.array_equal(fused[k], plain[k]), k
     finally:

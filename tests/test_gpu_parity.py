@@ -421,6 +421,16 @@ def test_tile_configs_and_autotune_are_bit_identical(pkg, sd7, torch_cuda, preci
         e.close()
 
 
+# With fusion on, a down-sampling conv (down1 / down2) runs as the first step of the PAN block that consumes it and its
+# output -- the first channels of the concat buffer -- never reaches HBM: those channels are compared through the block's
+# output only.
+NOT_WRITTEN_WHEN_FUSED = {"neck.cat_pan1": 64, "neck.cat_pan2": 128, "cat_pan1": 64, "cat_pan2": 128}
+
+
+def written(bname, arr):
+    return arr[NOT_WRITTEN_WHEN_FUSED.get(bname, 0):]
+
+
 BLOCK_OUTPUTS = ("neck.cat_fpn2", "neck.cat_fpn1", "neck.cat_pan2", "neck.cat_pan1", "p2_fused", "p3_out", "p4_out",
                  "backbone.sppf.cat")    # (sppf.cv1 runs as the last step of stage3's block kernel)
 
@@ -445,7 +455,7 @@ def test_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
         assert e.set_fusion(False) == 0
         plain = e.forward(x)
         for b in BLOCK_OUTPUTS:
-            assert np.array_equal(fused_bufs[b], e.read_buffer(b)), b
+            assert np.array_equal(written(b, fused_bufs[b]), written(b, e.read_buffer(b))), b
         for k in plain:
             assert np.array_equal(fused[k], plain[k]), k
         assert e.set_fusion(True) == 9
@@ -477,12 +487,12 @@ def test_int8_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
         assert len(bufs) == 9
         fused_bufs = {b: e.read_buffer(b) for b in bufs}
         kernels = [o["kernel"] for o in e.op_infos()]
-        assert sum("c3k2_fused<i8" in k or "block_dual_c3k2i8" in k for k in kernels) == 5, kernels
+        assert sum("c3k2_fused<i8" in k or "c3k2i8" in k for k in kernels) == 5, kernels
         assert not any("quant_f16_i8" in k for k in kernels) and sum("lat f16" in k for k in kernels) == 1, kernels
         assert e.set_fusion(False) == 0
         plain = e.forward(x)
         for b in bufs:
-            assert np.array_equal(fused_bufs[b], e.read_buffer(b)), b
+            assert np.array_equal(written(b, fused_bufs[b]), written(b, e.read_buffer(b))), b
         for k in plain:
             assert np.array_equal(fused[k], plain[k]), k
         assert e.set_fusion(True) == 9

@@ -15,10 +15,11 @@ namespace dev {
 // TAIL = 3 is TAIL = 1 for an int8 block whose lateral writes an fp16 tensor (INT8 engines: fpn_c3k2_1 -> lateral_p2
 // into the fp16 concat buffer of the narrow fpn_c3k2_2 block).
 // KBLK = k per weight block (32 fp16 / 64 int8).
-// CPRE != 0 prepends the 3x3 / stride-2 ConvBlock (CPRE -> CIN channels) that produces the block's input (stage1_conv ->
-// stage1_block, model.py:177-190): its output on the block's input region is computed in place instead of being written
-// to HBM by one launch and DMA'd back by the next.
-template <int H_, int NB, int CIN, int NW, int TAIL, int KBLK = 32, int CPRE = 0>
+// CPRE != 0 prepends the 3x3 / stride-2 ConvBlock (CPRE -> CX channels) that produces the first CX channels of the block's
+// input: all of it (stage1_conv -> stage1_block, model.py:177-190) or the down-sampling half of a PAN concat (down1 ->
+// pan_c3k2_1 over [p2_down | p3_fused], model.py:263-268; the other CIN - CX channels come from HBM as before). Its output
+// on the block's input region is computed in place instead of being written to HBM by one launch and DMA'd back by the next.
+template <int H_, int NB, int CIN, int NW, int TAIL, int KBLK = 32, int CPRE = 0, int CX = CIN>
 struct C3k2Plan {
   static constexpr int PRE = CPRE ? 1 : 0;
   static constexpr int CV3 = PRE + 1 + 2 * NB;  // index of the cv3 step
@@ -29,7 +30,7 @@ struct C3k2Plan {
     return t == 0 ? CIN / KBLK : (s >= CV3 ? 2 * H_ / KBLK : ((t & 1) ? H_ / KBLK : 9 * H_ / KBLK));
   }
   static constexpr int ns(int s) {
-    if (PRE && s == 0) return CIN / 16;
+    if (PRE && s == 0) return CX / 16;
     return (s == PRE || s == CV3) ? 2 * H_ / 16 : H_ / 16;
   }
   static constexpr int wnt(int s) { return ns(s) <= NW ? 1 : ns(s) / NW; }
@@ -47,12 +48,13 @@ struct C3k2Plan {
 // compiler's counted s_waitcnt vmcnt keeps D loads in flight across every step boundary.
 // E = EltH (fp16 engines and carve-outs) or EltI8 (INT8 engines: every tensor of the block is an int8 code image with
 // its per-tensor scale; the epilogues re-quantise exactly as the per-op kernels do, conv_igemm.hip conv_epilogue).
-template <int H_, int TH, int TW, int NB, int CIN, int NW, int D, int TAIL = 0, typename E = EltH, int CPRE = 0>
+template <int H_, int TH, int TW, int NB, int CIN, int NW, int D, int TAIL = 0, typename E = EltH, int CPRE = 0, int CX = CIN>
 __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, unsigned char* smem) {
   static_assert(NB == 1 || NB == 2, "bottleneck count");
-  typedef C3k2Plan<H_, NB, CIN, NW, TAIL, E::KBLK, CPRE> PL;
+  typedef C3k2Plan<H_, NB, CIN, NW, TAIL, E::KBLK, CPRE, CX> PL;
   constexpr int PRE = PL::PRE;
-  static_assert(CPRE % E::KBLK == 0, "a weight block must not straddle a tap");
+  static_assert(CPRE % E::KBLK == 0 && CX % E::KBLK == 0 && CX <= CIN && (PRE || CX == CIN), "pre-conv channel split");
+  constexpr int CREST = CIN - CX;   // input channels that still come from HBM when a pre-conv produces the first CX
   typedef StepTable<PL, NW> ST;
   static_assert(ST::valid(), "wave roles");
   static_assert((NW & (NW - 1)) == 0 && NW >= 2 && NW <= 16, "waves per workgroup");
@@ -79,18 +81,24 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
 #define CST(S) (bias_lds + E::CM * PL::cfirst((S) + PRE))
 
   // input patch (tile + NB-pixel halo, all CIN channels) -> LDS image; with a pre-conv: ITS input footprint instead
-  constexpr Img X = make_img(0, CIN / E::CH);
+  constexpr Img X = make_img(0, CX / E::CH);                               // (CX == CIN without a pre-conv)
+  constexpr Img XR = make_img(0, (CREST ? CREST : E::KBLK) / E::CH);       // the HBM part next to a pre-conv's output
   constexpr int PH = 2 * (TH + 2 * NB - 1) + 3, PW = 2 * (R0W - 1) + 3;   // footprint of R0 under a 3x3 / stride-2 conv
-  if constexpr (PRE)
+  if constexpr (PRE) {
     load_patch<PH, PW, (CPRE ? CPRE : E::KBLK), NT, E>(smem + p.off_p, p.src, p.src_ld, p.preH, p.preW, 2 * (ty0 - NB) - 1,
                                                      2 * (tx0 - NB) - 1, p.zeros, wid, lane);
-  else
+    if constexpr (CREST > 0)
+      load_patch<TH + 2 * NB, R0W, (CREST ? CREST : E::KBLK), NT, E>(smem + p.off_xr, p.src2, p.src2_ld, p.H, p.W, ty0 - NB, tx0 - NB,
+                                                                   p.zeros, wid, lane);
+  } else {
     load_patch<TH + 2 * NB, R0W, CIN, NT, E>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0 - NB, tx0 - NB, p.zeros, wid, lane);
+  }
   static_for<0, D>([&](auto gc) { wq_fetch<ST, D, decltype(gc)::value>(q, wbase, wid); });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed (LDS-DMA is not tracked by the compiler)
   lds_barrier();
 
   const Img Xi = Img{p.off_x, X.nch, X.sh, X.mask};
+  const Img XRi = Img{p.off_xr, XR.nch, XR.sh, XR.mask};
   const Img Y = make_img(p.off_y, 2 * H_ / E::CH);   // a | b on R0
   const Img T = make_img(p.off_t, H_ / E::CH);       // t of the current bottleneck (R0, then R1)
   const Img U1 = make_img(p.off_u1, H_ / E::CH);     // NB == 2: first bottleneck's output on R1
@@ -119,15 +127,17 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
         },
         [&](int sub, int n, const acc_t& acc) {
           const int r = sub * 16 + l15;
-          if (r < P0) store4<E, CIN>(smem + img_at<E>(Xi, r, n), act_relu<E, CIN>(acc, c0, n), c0, n);
+          if (r < P0) store4<E, CX>(smem + img_at<E>(Xi, r, n), act_relu<E, CX>(acc, c0, n), c0, n);
         });
   }
 
   // ---- step 0: a | b = ReLU(W12 x + b12) on R0 --------------------------------------------------------------------
   run_step(STEP(0, P0),
       [&](int sub, auto kc) {
+        constexpr int kb = decltype(kc)::value;
         const int r = sub * 16 + l15;
-        return Xi.addr(r < P0 ? r : P0 - 1, decltype(kc)::value * 4 + lq);
+        if constexpr (kb < CX / E::KBLK) return Xi.addr(r < P0 ? r : P0 - 1, kb * 4 + lq);
+        else return XRi.addr(r < P0 ? r : P0 - 1, (kb - CX / E::KBLK) * 4 + lq);
       },
       [&](int sub, int n, const acc_t& acc) {
         const int r = sub * 16 + l15;

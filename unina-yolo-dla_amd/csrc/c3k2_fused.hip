@@ -36,9 +36,9 @@ using namespace dev;
 
 extern __shared__ __align__(16) unsigned char c3_smem[];
 
-template <int H_, int TH, int TW, int NB, int CIN, int NW, int D, int TAIL = 0, typename E = EltH, int CPRE = 0>
+template <int H_, int TH, int TW, int NB, int CIN, int NW, int D, int TAIL = 0, typename E = EltH, int CPRE = 0, int CX = CIN>
 __global__ __launch_bounds__(NW * 64) void c3k2_fused_kernel(const C3k2Params p) {
-  c3k2_fused_body<H_, TH, TW, NB, CIN, NW, D, TAIL, E, CPRE>(p, (int)blockIdx.x, c3_smem);
+  c3k2_fused_body<H_, TH, TW, NB, CIN, NW, D, TAIL, E, CPRE, CX>(p, (int)blockIdx.x, c3_smem);
 }
 
 // ------------------------------------------------------------------------------------------------- host side
@@ -49,27 +49,32 @@ struct Class {
   const char* name;
   void (*fn)(const C3k2Params);
   int cpre;   // 0, or the pre-conv's input channels
+  int cx;     // channels the pre-conv produces (0 without one)
 };
 #define C3K2(H_, TH, TW, NB, CIN, NW, D) \
-  {kF16, H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0>, 0}
-#define C3K2S(H_, TH, TW, NB, CIN, NW, D, CPRE) \
-  {kF16, H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,s2conv " #CPRE ">", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0, EltH, CPRE>, CPRE}
+  {kF16, H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0>, 0, 0}
+#define C3K2S(H_, TH, TW, NB, CIN, NW, D, CPRE, CX) \
+  {kF16, H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,s2conv " #CPRE ">", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0, EltH, CPRE, CX>, CPRE, CX}
+#define C3K2IS(H_, TH, TW, NB, CIN, NW, D, CPRE, CX) \
+  {kI8, H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,s2conv " #CPRE ">", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0, EltI8, CPRE, CX>, CPRE, CX}
 #define C3K2T(H_, TH, TW, NB, CIN, NW, D) \
-  {kF16, H_, NB, CIN, 1, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,lat>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 1>, 0}
+  {kF16, H_, NB, CIN, 1, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,lat>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 1>, 0, 0}
 #define C3K2P(H_, TH, TW, NB, CIN, NW, D) \
-  {kF16, H_, NB, CIN, 2, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,+1x1>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 2>, 0}
+  {kF16, H_, NB, CIN, 2, TH, TW, NW, "c3k2_fused<" #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,+1x1>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 2>, 0, 0}
 #define C3K2IP(H_, TH, TW, NB, CIN, NW, D) \
-  {kI8, H_, NB, CIN, 2, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,+1x1>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 2, EltI8>, 0}
+  {kI8, H_, NB, CIN, 2, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,+1x1>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 2, EltI8>, 0, 0}
 #define C3K2IL(H_, TH, TW, NB, CIN, NW, D) \
-  {kI8, H_, NB, CIN, 3, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,lat f16>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 3, EltI8>, 0}
+  {kI8, H_, NB, CIN, 3, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,lat f16>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 3, EltI8>, 0, 0}
 #define C3K2I(H_, TH, TW, NB, CIN, NW, D) \
-  {kI8, H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0, EltI8>, 0}
+  {kI8, H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0, EltI8>, 0, 0}
 const Class kClasses[] = {
     // Tiles chosen by end-to-end A/B at 640^2: twice the workgroups of the first choice (8x16 / 8x8 / 4x8) cost more
     // halo recompute but cut the serial frame by ~10 us at equal throughput; one step smaller still (4x8 / 4x4 / 4x4)
     // lost 4-6 % throughput; deeper weight queues (D x2, x1.5) changed nothing.
     C3K2(32, 8, 8, 1, 64, 8, 4),       // backbone.stage1_block        160^2 at 640: 400 workgroups
-    C3K2S(32, 8, 8, 1, 64, 8, 4, 32),  // backbone.stage1_conv (3x3/s2, 32 -> 64) + backbone.stage1_block
+    C3K2S(32, 8, 8, 1, 64, 8, 4, 32, 64),     // backbone.stage1_conv (3x3/s2, 32 -> 64) + backbone.stage1_block
+    C3K2S(64, 4, 8, 1, 192, 8, 8, 64, 64),    // neck.down1 (3x3/s2, 64 -> 64 = the first half of [p2_down | p3_fused]) + neck.pan_c3k2_1
+    C3K2S(128, 4, 4, 1, 384, 8, 16, 128, 128),  // neck.down2 + neck.pan_c3k2_2
     C3K2(32, 8, 8, 1, 128, 8, 4),      // neck.fpn_c3k2_2
     C3K2(64, 4, 8, 2, 128, 8, 8),      // backbone.stage2_c3k2          80^2: 200
     C3K2(64, 4, 8, 1, 256, 8, 8),      // neck.fpn_c3k2_1
@@ -85,6 +90,8 @@ const Class kClasses[] = {
     C3K2I(64, 4, 8, 1, 256, 8, 8),     // neck.fpn_c3k2_1
     C3K2IL(64, 4, 8, 1, 256, 8, 8),    // neck.fpn_c3k2_1 + neck.lateral_p2 (+ x2 upsample) into the fp16 concat of fpn_c3k2_2
     C3K2I(64, 4, 8, 1, 192, 8, 8),     // neck.pan_c3k2_1
+    C3K2IS(64, 4, 8, 1, 192, 8, 8, 64, 64),     // neck.down1 + neck.pan_c3k2_1
+    C3K2IS(128, 4, 4, 1, 384, 8, 8, 128, 128),  // neck.down2 + neck.pan_c3k2_2
     C3K2I(128, 4, 4, 2, 256, 8, 8),    // backbone.stage3_c3k2
     C3K2IP(128, 4, 4, 2, 256, 8, 8),   // backbone.stage3_c3k2 + backbone.sppf.cv1
     C3K2I(128, 4, 4, 1, 384, 8, 8),    // neck.pan_c3k2_2
@@ -93,13 +100,14 @@ const Class kClasses[] = {
 #undef C3K2
 #undef C3K2T
 #undef C3K2S
+#undef C3K2IS
 #undef C3K2I
 #undef C3K2P
 #undef C3K2IL
 #undef C3K2IP
-const Class* find_class(int hid, int nb, int cin, int tail, int dtype, int cpre = 0) {
+const Class* find_class(int hid, int nb, int cin, int tail, int dtype, int cpre = 0, int cx = 0) {
   for (const Class& c : kClasses)
-    if (c.dtype == dtype && c.hid == hid && c.nb == nb && c.cin == cin && c.tail == tail && c.cpre == cpre) return &c;
+    if (c.dtype == dtype && c.hid == hid && c.nb == nb && c.cin == cin && c.tail == tail && c.cpre == cpre && (!cpre || c.cx == cx)) return &c;
   return nullptr;
 }
 constexpr int kMaxLds = 160 * 1024;
@@ -115,18 +123,19 @@ hipError_t c3k2_init() {
   return hipSuccess;
 }
 
-bool c3k2_supported(int hid, int nb, int cin, int tail, int dtype, int cpre) {
+bool c3k2_supported(int hid, int nb, int cin, int tail, int dtype, int cpre, int cx) {
   C3k2Params p;
   memset(&p, 0, sizeof p);
   p.dtype = dtype;
   p.cpre = cpre;
+  p.cx = cx;
   p.hid = hid; p.nb = nb; p.Cin = cin; p.tail = tail; p.H = p.W = 64;
   return c3k2_layout(&p);
 }
 
 // Fills tile geometry and the LDS layout of `p` (needs hid, nb, Cin, H, W). False = no such class / no fit.
 bool c3k2_layout(C3k2Params* p) {
-  const Class* c = find_class(p->hid, p->nb, p->Cin, p->tail, p->dtype, p->cpre);
+  const Class* c = find_class(p->hid, p->nb, p->Cin, p->tail, p->dtype, p->cpre, p->cx);
   if (!c) return false;
   const int h = p->hid, nb = p->nb;
   const int esz = p->dtype == kI8 ? 1 : 2, cm = p->dtype == kI8 ? 3 : 1;
@@ -134,8 +143,11 @@ bool c3k2_layout(C3k2Params* p) {
   p->tiles_x = (p->W + c->tw - 1) / c->tw;
   p->tiles_y = (p->H + c->th - 1) / c->th;
   p->tiles_x_magic = div_magic((unsigned)p->tiles_x);
-  p->n_bias = cm * (2 * h * (2 + nb) + (p->tail ? h : 0) + (p->cpre ? p->Cin : 0));
-  const int x_bytes = align_up(p0 * p->Cin * esz, 1024) + 1024;  // the last patch DMA instruction may overrun by < 1 KiB
+  p->n_bias = cm * (2 * h * (2 + nb) + (p->tail ? h : 0) + (p->cpre ? p->cx : 0));
+  // input image(s): DMA'd whole; or the pre-conv's output (written by its epilogue) followed by the DMA'd rest of a concat
+  const int xa_bytes = p->cpre ? align_up(p0 * p->cx * esz, 1024) : 0;
+  const int x_bytes = p->cpre ? xa_bytes + (p->Cin > p->cx ? align_up(p0 * (p->Cin - p->cx) * esz, 1024) + 1024 : 0)
+                              : align_up(p0 * p->Cin * esz, 1024) + 1024;  // the last patch DMA instruction may overrun by < 1 KiB
   const int t_bytes = p0 * h * esz, u1_bytes = nb == 2 ? p1 * h * esz : 0, u2_bytes = pt * h * esz;
   const int stage_bytes = pt * (2 * h * esz + 16);
   // region A: the input patch; once step 0 has consumed it, t (and later the output staging tile), u1 and u2 live there
@@ -145,6 +157,7 @@ bool c3k2_layout(C3k2Params* p) {
   int off = 0;
   p->off_bias = off; off += align_up(p->n_bias * 4, 1024);
   p->off_x = off;
+  p->off_xr = off + xa_bytes;
   p->off_t = off;
   p->off_stage = off;
   p->off_u1 = off + align_up(head, 16);
@@ -193,10 +206,10 @@ void block_pack(const C3k2Conv* convs, int nconv, std::vector<unsigned char>* st
 
 // C3k2 convs in execution order: cv1|cv2, {b.cv1, b.cv2} x nb, cv3.
 bool c3k2_pack(int hid, int nb, int cin, int tail, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias,
-               int dtype, int cpre) {
-  if (!find_class(hid, nb, cin, tail, dtype, cpre)) return false;
+               int dtype, int cpre, int cx) {
+  if (!find_class(hid, nb, cin, tail, dtype, cpre, cx)) return false;
   const int pre = cpre ? 1 : 0;
-  if (pre && (convs[0].n[0] != cin || convs[0].n[1] || convs[0].K != 9 * cpre)) return false;
+  if (pre && (convs[0].n[0] != cx || convs[0].n[1] || convs[0].K != 9 * cpre)) return false;
   const int ncv3 = 1 + 2 * nb, nconv = 2 + 2 * nb + (tail ? 1 : 0);
   for (int ci = 0; ci < nconv; ++ci) {
     const C3k2Conv& cv = convs[pre + ci];
@@ -210,24 +223,24 @@ bool c3k2_pack(int hid, int nb, int cin, int tail, const C3k2Conv* convs, std::v
 }
 
 hipError_t c3k2_launch(const C3k2Params& p, hipStream_t stream) {
-  const Class* c = find_class(p.hid, p.nb, p.Cin, p.tail, p.dtype, p.cpre);
+  const Class* c = find_class(p.hid, p.nb, p.Cin, p.tail, p.dtype, p.cpre, p.cx);
   if (!c) return hipErrorInvalidValue;
   hipLaunchKernelGGL(c->fn, dim3(p.tiles_x * p.tiles_y, 1, 1), dim3(c->nw * 64, 1, 1), p.smem_bytes, stream, p);
   return hipGetLastError();
 }
 
 bool c3k2_tile_is(const C3k2Params& p, int th, int tw) {
-  const Class* c = find_class(p.hid, p.nb, p.Cin, p.tail, p.dtype, p.cpre);
+  const Class* c = find_class(p.hid, p.nb, p.Cin, p.tail, p.dtype, p.cpre, p.cx);
   return c && c->th == th && c->tw == tw;
 }
 
-const char* c3k2_kernel_name(int hid, int nb, int cin, int tail, int dtype, int cpre) {
-  const Class* c = find_class(hid, nb, cin, tail, dtype, cpre);
+const char* c3k2_kernel_name(int hid, int nb, int cin, int tail, int dtype, int cpre, int cx) {
+  const Class* c = find_class(hid, nb, cin, tail, dtype, cpre, cx);
   return c ? c->name : "c3k2_fused<?>";
 }
 
-int c3k2_block_threads(int hid, int nb, int cin, int tail, int dtype, int cpre) {
-  const Class* c = find_class(hid, nb, cin, tail, dtype, cpre);
+int c3k2_block_threads(int hid, int nb, int cin, int tail, int dtype, int cpre, int cx) {
+  const Class* c = find_class(hid, nb, cin, tail, dtype, cpre, cx);
   return c ? c->nw * 64 : 0;
 }
 

@@ -199,6 +199,11 @@ void op_regions(const unina_engine* e, size_t i, std::vector<Region>* reads, std
   if (e->fuse && e->ops[i].fuse_role == 1) {
     const OpDesc& last = e->ops[e->ops[i].group_last].d;
     reads->push_back({(int)d.src_buf, (int)d.seg[0].src_coff, (int)(d.seg[0].src_coff + d.cin)});
+    if (e->ops[i].fuse_kind == 1 && e->ops[i].fuse_pre) {   // pre-conv: the block also reads the part of its input the pre-conv does not produce
+      const OpDesc& blk = e->ops[i + 1].d;
+      if (d.seg[0].n_count < blk.cin)
+        reads->push_back({(int)blk.src_buf, (int)(blk.seg[0].src_coff + d.seg[0].n_count), (int)(blk.seg[0].src_coff + blk.cin)});
+    }
     if (e->ops[i].fuse_kind == 4)   // the first conv's output goes to HBM too
       writes->push_back({(int)d.seg[0].dst_buf, (int)d.seg[0].dst_coff, (int)(d.seg[0].dst_coff + d.seg[0].n_count)});
     for (uint32_t s = 0; s < last.nseg; ++s)
@@ -490,6 +495,10 @@ int plan(unina_engine* e) {
       f.cpre = (int)in.cin;
       f.preH = (int)in.in_h;
       f.preW = (int)in.in_w;
+      f.cx = (int)in.seg[0].n_count;
+      const Buffer& xb = e->bufs[a.src_buf];   // the rest of the block's input (a concat's other part) still comes from HBM
+      f.src2 = static_cast<const char*>(xb.ptr) + (a.seg[0].src_coff + f.cx) * fesz;
+      f.src2_ld = (int)xb.d.c;
     }
     f.Cin = (int)a.cin;
     f.H = (int)a.in_h;
@@ -542,13 +551,13 @@ int plan(unina_engine* e) {
       }
     }
     info.flops = flops;
-    info.bytes = (f.cpre ? (double)fesz * f.preH * f.preW * f.cpre : (double)fesz * f.H * f.W * f.Cin) + wbytes + (double)fesz * f.H * f.W * 2 * f.hid +   // input once, weights once, output once
+    info.bytes = (f.cpre ? (double)fesz * (f.preH * f.preW * f.cpre + f.H * f.W * (f.Cin - f.cx)) : (double)fesz * f.H * f.W * f.Cin) + wbytes + (double)fesz * f.H * f.W * 2 * f.hid +   // input once, weights once, output once
                  (f.tail ? (double)fesz * (f.tail == 1 ? 4 : 1) * f.H * f.W * f.hid : 0.0);            // (+ the tail conv's output)
     info.n = 2 * f.hid;
     info.k = 0;
     info.grid = f.tiles_x * f.tiles_y;
-    info.block = c3k2_block_threads(f.hid, f.nb, f.Cin, f.tail, f.dtype, f.cpre);
-    snprintf(info.kernel, sizeof info.kernel, "%s", c3k2_kernel_name(f.hid, f.nb, f.Cin, f.tail, f.dtype, f.cpre));
+    info.block = c3k2_block_threads(f.hid, f.nb, f.Cin, f.tail, f.dtype, f.cpre, f.cx);
+    snprintf(info.kernel, sizeof info.kernel, "%s", c3k2_kernel_name(f.hid, f.nb, f.Cin, f.tail, f.dtype, f.cpre, f.cx));
     snprintf(info.name, sizeof info.name, "%.*s[c3k2 x%d]", (int)(strchr(a.name, '+') ? strchr(a.name, '+') - a.name - 4 : 60), a.name, f.nb);
   }
   // dual launches: pair independent convs of one kernel family (the P3 / P4 head layers) into one grid each. The later
@@ -584,7 +593,7 @@ int plan(unina_engine* e) {
         a.info.flops += b.info.flops;
         a.info.bytes += b.info.bytes;
         a.info.grid += b.info.grid;
-        snprintf(a.info.kernel, sizeof a.info.kernel, "%s", block_dual_name(a.fp.dtype));
+        snprintf(a.info.kernel, sizeof a.info.kernel, "%s", block_dual_name(a.fp.dtype, a.fp.cpre));
         b.info.flops = 0;
         b.info.bytes = 0;
         b.info.grid = 0;
@@ -883,15 +892,29 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     size_t i0 = i;   // first op of the group
     if (i > 0 && !e->ops[i - 1].fuse_role) {
       const OpDesc& pz = e->ops[i - 1].d;
-      if (pz.kind == kOpConv && pz.ksize == 3 && pz.stride == 2 && pz.relu && pz.nseg == 1 && pz.res_buf < 0 && !pz.seg[0].flags &&
-          (pz.seg[0].m_off != 0) == i8 && pz.seg[0].n_pad == pz.seg[0].n_count && pz.seg[0].dst_buf == a.src_buf &&
-          pz.seg[0].dst_coff == a.seg[0].src_coff && pz.seg[0].n_count == a.cin && e->bufs[a.src_buf].d.c == a.cin &&
-          e->bufs[pz.src_buf].d.dtype == bdt && pz.seg[0].src_coff % al == 0 && e->bufs[pz.src_buf].d.c % al == 0 &&
-          pz.out_h == a.in_h && pz.out_w == a.in_w && pz.src_buf != a.src_buf &&
-          c3k2_supported((int)h, nb, (int)a.cin, tail_kind, dt, (int)pz.cin)) {
-        i0 = i - 1;
-        inter.push_back(a.src_buf);
+      const uint32_t cx = pz.seg[0].n_count;   // the pre-conv writes the FIRST cx channels of the block's input (all of it, or
+                                               // the down-sampling half of a PAN concat)
+      bool ok = pz.kind == kOpConv && pz.ksize == 3 && pz.stride == 2 && pz.relu && pz.nseg == 1 && pz.res_buf < 0 && !pz.seg[0].flags &&
+                (pz.seg[0].m_off != 0) == i8 && pz.seg[0].n_pad == pz.seg[0].n_count && pz.seg[0].dst_buf == a.src_buf &&
+                pz.seg[0].dst_coff == a.seg[0].src_coff && cx <= a.cin && cx % al == 0 &&
+                e->bufs[pz.src_buf].d.dtype == bdt && pz.seg[0].src_coff % al == 0 && e->bufs[pz.src_buf].d.c % al == 0 &&
+                pz.out_h == a.in_h && pz.out_w == a.in_w && pz.src_buf != a.src_buf &&
+                c3k2_supported((int)h, nb, (int)a.cin, tail_kind, dt, (int)pz.cin, (int)cx);
+      // its output must be private to the group: nothing else reads or writes those channels
+      const Region out{(int)a.src_buf, (int)pz.seg[0].dst_coff, (int)(pz.seg[0].dst_coff + cx)};
+      for (size_t k = 0; k < n && ok; ++k) {
+        if (k >= i - 1 && k <= j) continue;
+        const OpDesc& o = e->ops[k].d;
+        if (o.kind == kOpConv || o.kind == kOpQuant || o.kind == kOpSppfPool || o.kind == kOpUpsample)
+          for (uint32_t sgi = 0; sgi < o.nseg; ++sgi) {
+            const int rc0 = (int)o.seg[sgi].src_coff, rc1 = rc0 + (int)(o.kind == kOpConv ? o.cin : o.seg[sgi].n_count);
+            if (overlaps(out, Region{(int)o.src_buf, rc0, o.kind == kOpSppfPool ? (int)e->bufs[o.src_buf].d.c : rc1})) ok = false;
+            if (overlaps(out, Region{(int)o.seg[sgi].dst_buf, (int)o.seg[sgi].dst_coff, (int)(o.seg[sgi].dst_coff + o.seg[sgi].n_count)})) ok = false;
+          }
+        if (o.res_buf == (int)a.src_buf) ok = false;
       }
+      if (e->bufs[a.src_buf].d.flags & (kBufInput | kBufOutput)) ok = false;
+      if (ok) i0 = i - 1;
     }
     const OpDesc& first = e->ops[i0].d;
     // the group's intermediates must be private to it, and must not be its own input or output
@@ -928,7 +951,8 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     }
     std::vector<unsigned char> stream;
     std::vector<float> bias;
-    if (!c3k2_pack((int)h, nb, (int)a.cin, tail_kind, convs.data(), &stream, &bias, dt, i0 < i ? (int)first.cin : 0)) continue;
+    if (!c3k2_pack((int)h, nb, (int)a.cin, tail_kind, convs.data(), &stream, &bias, dt, i0 < i ? (int)first.cin : 0,
+                   i0 < i ? (int)first.seg[0].n_count : 0)) continue;
     blob->resize((blob->size() + 255) & ~(size_t)255);
     const uint64_t so = blob->size();
     blob->insert(blob->end(), stream.begin(), stream.end());

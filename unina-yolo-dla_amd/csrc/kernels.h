@@ -105,9 +105,12 @@ struct C3k2Params {
   const float* bias;             // per-step constants, same order: fp16 [bias(n)]; int8 [bias(n) | mult(n) | 1/s_out(n)]
   const void* zeros;             // >= 16 bytes of zeros in HBM
   int hid, nb;                   // hidden width h = Cout/2, number of bottlenecks
-  int cpre;                      // != 0: the 3x3 / stride-2 ConvBlock (cpre -> Cin channels) in front of the block runs as a first
+  int cpre;                      // != 0: the 3x3 / stride-2 ConvBlock (cpre -> cx channels) in front of the block runs as a first
                                  // step; src / src_ld then describe ITS input (preH x preW pixels), H x W stays the block's size
   int preH, preW;
+  int cx;                        // channels of the block input the pre-conv produces (== Cin, or the first part of a concat)
+  const void* src2;              // cx < Cin: the remaining Cin - cx input channels (block resolution), channel offset applied
+  int src2_ld;
   float res_scale[2];            // int8: scale of each bottleneck's shortcut tensor
   signed char* dst_q;            // fp16 blocks in INT8 engines: int8 twin of the block output (the QUANT op that follows), or nullptr
   int dst_q_ld;
@@ -120,7 +123,7 @@ struct C3k2Params {
   int n_bias;
   int tiles_x, tiles_y;
   unsigned tiles_x_magic;
-  int off_bias, off_x, off_y, off_t, off_u1, off_u2, off_stage, off_tail, off_p, smem_bytes;   // LDS layout (bytes)
+  int off_bias, off_x, off_y, off_t, off_u1, off_u2, off_stage, off_tail, off_p, off_xr, smem_bytes;   // LDS layout (bytes)
 };
 struct C3k2Conv {                // one conv of the block as the exporter stored it (host pointers)
   const unsigned char* w[2];     // packed 1-KiB fragment blocks [n/16][K/32 | K/64] per output slice (slice 1 only for cv1|cv2)
@@ -132,12 +135,12 @@ struct C3k2Conv {                // one conv of the block as the exporter stored
 };
 hipError_t c3k2_init();
 bool c3k2_layout(C3k2Params* p);
-bool c3k2_supported(int hid, int nb, int cin, int tail = 0, int dtype = kF16, int cpre = 0);
+bool c3k2_supported(int hid, int nb, int cin, int tail = 0, int dtype = kF16, int cpre = 0, int cx = 0);
 bool c3k2_pack(int hid, int nb, int cin, int tail, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias,
-               int dtype = kF16, int cpre = 0);   // with cpre: convs[0] is the pre-conv
+               int dtype = kF16, int cpre = 0, int cx = 0);   // with cpre: convs[0] is the pre-conv (cpre -> cx channels)
 hipError_t c3k2_launch(const C3k2Params& p, hipStream_t stream);
-const char* c3k2_kernel_name(int hid, int nb, int cin, int tail = 0, int dtype = kF16, int cpre = 0);
-int c3k2_block_threads(int hid, int nb, int cin, int tail = 0, int dtype = kF16, int cpre = 0);
+const char* c3k2_kernel_name(int hid, int nb, int cin, int tail = 0, int dtype = kF16, int cpre = 0, int cx = 0);
+int c3k2_block_threads(int hid, int nb, int cin, int tail = 0, int dtype = kF16, int cpre = 0, int cx = 0);
 
 // Generic packer of the block kernels' weight stream: per conv, k-block-major [K/32][N/16] 1-KiB blocks (slice 0's
 // channel subtiles first), then the concatenated biases (n entries per slice).
@@ -200,7 +203,7 @@ int pair_block_threads(const PairParams& p);
 // A fused C3k2 block and a fused head that do not depend on each other, side by side in one grid (block_dual.hip).
 hipError_t block_dual_init();
 bool block_dual_match(const C3k2Params& pc, const HeadParams& ph);
-const char* block_dual_name(int dtype = kF16);
+const char* block_dual_name(int dtype = kF16, int cpre = 0);
 hipError_t block_dual_launch(const C3k2Params& pc, const HeadParams& ph, hipStream_t stream, int* grid_out = nullptr);
 bool c3k2_tile_is(const C3k2Params& p, int th, int tw);    // the tile the layout of `p` was computed for
 bool head_tile_is(const HeadParams& p, int th, int tw);
