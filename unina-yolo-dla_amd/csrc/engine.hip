@@ -53,6 +53,7 @@ struct PlannedOp {
   bool dual_absorbed = false;   // runs inside an earlier op's dual launch
   int tail_op = -1;         // role 1, C3k2: index of the 1x1 conv that runs as the block kernel's last step
   int tail_kind = 0;        // 1: lateral 1x1 + x2 upsample store; 2: plain 1x1 ConvBlock (same resolution); 3: 1 with int8 in, fp16 out
+  uint64_t wt_off = 0;      // stem: blob offset of the transposed weights [27][Co] (appended at load)
   int fuse_pre = 0;         // role 1, C3k2: 1 = this op is the 3x3/s2 conv in front of the block (the block's cv1|cv2 is the NEXT op)
   int quant_op = -1;        // role 1, fp16 C3k2 in an INT8 engine: the QUANT op of the block's output that the kernel's store absorbs
   int hid = 0, nb = 0;      // role 1: hidden width, bottleneck count
@@ -335,6 +336,7 @@ int plan(unina_engine* e) {
       p.dtype = odt;
       p.src = static_cast<const float*>(src.ptr);
       p.w = reinterpret_cast<const float*>(blob + sd.w_off);
+      p.wt = reinterpret_cast<const float*>(blob + op.wt_off);
       p.bias = reinterpret_cast<const float*>(blob + sd.b_off);
       p.dst = static_cast<char*>(db.ptr) + (size_t)sd.dst_coff * dtype_size(odt);
       p.H = (int)d.in_h; p.W = (int)d.in_w; p.Ho = (int)d.out_h; p.Wo = (int)d.out_w;
@@ -1405,6 +1407,20 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   }
   if (e->images_buf < 0) return bail(UNINA_ERR_FORMAT, "engine file lacks the images input buffer");
 
+  // stem: a [27][Co] transposed copy of its weights (wave-uniform scalar loads in stem_conv_kernel)
+  for (auto& op : e->ops) {
+    if (op.d.kind != kOpStem) continue;
+    const SegDesc& sd = op.d.seg[0];
+    const uint32_t co = sd.n_count;
+    if (sd.w_off + (uint64_t)co * 27 * 4 > blob.size()) return bail(UNINA_ERR_FORMAT, "stem weights out of range");
+    std::vector<float> wt((size_t)27 * co);
+    const float* w = reinterpret_cast<const float*>(blob.data() + sd.w_off);
+    for (uint32_t c = 0; c < co; ++c)
+      for (int k = 0; k < 27; ++k) wt[(size_t)k * co + c] = w[(size_t)c * 27 + k];
+    blob.resize((blob.size() + 255) & ~(size_t)255);
+    op.wt_off = blob.size();
+    blob.insert(blob.end(), reinterpret_cast<const char*>(wt.data()), reinterpret_cast<const char*>(wt.data() + wt.size()));
+  }
   // fusable groups: their packed weight streams are appended to the blob before upload. The matchers accept all-fp16
   // groups (in an INT8 engine: the carved-out P2 head, train.py:779) and, for C3k2 blocks, all-int8 groups
   if (e->h.precision == kFp16 || e->h.precision == kInt8) {

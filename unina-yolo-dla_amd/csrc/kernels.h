@@ -221,6 +221,7 @@ struct StemParams {
   NormParams norm;
   const float* src;    // [3][H][W]
   const float* w;      // [Co][27], (c,kh,kw)
+  const float* wt;     // the same weights transposed to [27][Co] (prepared at load): wave-uniform scalar loads in the stem kernel
   const float* bias;   // [Co]
   void* dst;           // [Ho][Wo][dst_ld]
   int H, W, Ho, Wo, Co, dst_ld;

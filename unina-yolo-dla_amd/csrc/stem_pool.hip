@@ -14,9 +14,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // each with half of the output channels: 3 200 waves at 640^2 spread evenly over the 1 024 SIMDs (one thread per
 // pixel gave 1.56 waves per SIMD, i.e. two uneven rounds), and the accumulators are float2 pairs so every FMA
 // instruction is a v_pk_fma_f32 (two channels per issue slot; element-wise, so each channel still sees exactly the
-// sequential fma chain k = 0..26 of the scalar form). A wave's 27 input loads each cover 32 neighbouring pixels
-// (stride-2 fp32, both threads of a pixel hit the same address), the 27 x CO folded weights are LDS reads with two
-// distinct addresses per wave, and each thread stores its pixel's CO/2 contiguous NHWC channels.
+// sequential fma chain k = 0..26 of the scalar form). A wave's 27 input loads each cover 64 neighbouring pixels
+// (stride-2 fp32), the 27 x CO/2 folded weights of its channel half are scalar loads, and each thread stores its
+// pixel's CO/2 contiguous NHWC channels.
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 // Network-input pixel (y, x) of a camera frame: the arithmetic of preprocess.hip (cuda_preprocess.cu:99-128 plain BGRA,
@@ -53,14 +53,17 @@ __device__ __forceinline__ void camera_pixel(const StemParams& p, int y, int x, 
 template <typename T, int CO>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
   constexpr int CH = CO / 2;  // channels per thread
-  __shared__ __align__(16) float sw[27 * CO];
-  __shared__ __align__(16) float sb[CO];
-  for (int i = threadIdx.x; i < CO * 27; i += blockDim.x) sw[(i % 27) * CO + (i / 27)] = p.w[i];  // -> [k][co]
-  for (int i = threadIdx.x; i < CO; i += blockDim.x) sb[i] = p.bias[i];
-  __syncthreads();
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  const int m = g >> 1, c0 = (g & 1) * CH;
+  // A WAVE owns 64 consecutive output pixels and ONE half of the output channels (even waves the first, odd waves the
+  // second), so the 27 x CH folded weights it needs are wave-uniform: scalar loads (s_load into SGPRs, read by the FMAs as
+  // scalar operands), no LDS at all. (The previous form kept both halves in a wave and read the weights from an LDS copy,
+  // 108 ds_read_b128 per thread; measured the same 12.5 us at 640^2 -- the kernel is not LDS-bound -- but this one needs
+  // no LDS, no barrier and 70 instead of 84 VGPRs.)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int c0 = (wave & 1) * CH;
+  const int m = blockIdx.x * 128 + (wave >> 1) * 64 + (int)(threadIdx.x & 63);
   if (m >= p.Ho * p.Wo) return;
+  const float* __restrict__ wt = p.wt + c0;
+  const float* __restrict__ bs = p.bias + c0;
   const int oy = m / p.Wo, ox = m - oy * p.Wo;
   float x[27];
   const size_t plane = (size_t)p.H * p.W;
@@ -94,16 +97,12 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
   }
   floatx2 acc[CH / 2];
 #pragma unroll
-  for (int r = 0; r < CH / 2; ++r) acc[r] = *reinterpret_cast<const floatx2*>(&sb[c0 + 2 * r]);
+  for (int r = 0; r < CH / 2; ++r) acc[r] = floatx2{bs[2 * r], bs[2 * r + 1]};
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
     const floatx2 xk = {x[k], x[k]};
 #pragma unroll
-    for (int r = 0; r < CH / 2; r += 2) {
-      const float4 w4 = *reinterpret_cast<const float4*>(&sw[k * CO + c0 + 2 * r]);
-      acc[r] = __builtin_elementwise_fma(xk, floatx2{w4.x, w4.y}, acc[r]);
-      acc[r + 1] = __builtin_elementwise_fma(xk, floatx2{w4.z, w4.w}, acc[r + 1]);
-    }
+    for (int r = 0; r < CH / 2; ++r) acc[r] = __builtin_elementwise_fma(xk, floatx2{wt[k * CO + 2 * r], wt[k * CO + 2 * r + 1]}, acc[r]);
   }
   T* d = static_cast<T*>(p.dst) + (size_t)m * p.dst_ld + c0;
   constexpr int V = 16 / sizeof(T);  // elements per 16-byte store
@@ -121,7 +120,8 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
 }
 
 hipError_t stem_desc(const StemParams& p, LaunchDesc* out) {
-  out->grid = dim3((2 * p.Ho * p.Wo + 255) / 256);   // two threads per output pixel
+  out->grid = dim3((p.Ho * p.Wo + 127) / 128);        // 128 pixels x two channel halves per 256-thread workgroup
+  if (!p.wt) return hipErrorInvalidValue;
   out->block = dim3(256);
   out->shmem = 0;
   if (p.Co == 32 && p.dtype == kF16) out->func = reinterpret_cast<const void*>(&stem_conv_kernel<half_t, 32>);
