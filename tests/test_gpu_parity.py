@@ -205,6 +205,35 @@ def test_narrow_model_base_channels_16(pkg, oracle_mod, torch_cuda):
         osd.close()
 
 
+def test_non_square_input_and_empty_result(pkg, sd7, oracle_mod, oracle_sd7, torch_cuda):
+    """192 x 320 input (TensorRTEngine::getInputDimensions reports w and h separately, perception_node.cpp:297-325):
+    48x80 / 24x40 / 12x20 maps, partial tiles in both directions. Heads vs the fp32 oracle, detections within the fp16
+    tolerance, fused = per-op bit for bit, and an empty result (threshold no cell passes) is count 0, not an error."""
+    from unina_yolo_dla_amd.engine import Engine
+    g = pkg.graph.Graph(in_h=192, in_w=320)
+    e = Engine.from_state_dict(sd7, g)
+    try:
+        x = pkg.rng.frame(1234, 192, 320)
+        xd = torch_cuda.from_numpy(x).cuda()
+        heads = {k: v.copy() for k, v in e.forward(xd).items()}
+        o = oracle_mod.forward(oracle_sd7, x)
+        for n in pkg.graph.OUTPUT_NAMES:
+            assert heads[n].shape == o[n].shape
+            np.testing.assert_allclose(heads[n], o[n], atol=HEAD_ATOL, rtol=0, err_msg=n)
+        got = e.infer(xd, 0.5, 0.45, 0.1)
+        want, ncand = oracle_mod.postprocess([o[n] for n in pkg.graph.OUTPUT_NAMES], 0.5, 0.45, 0.1)
+        assert ncand > 10
+        check_fp16_detections(got, want, 0.5)
+        assert len(e.infer(xd, 1.0, 0.45, 0.1)) == 0
+        e.set_fusion(False)
+        plain = e.forward(xd)
+        for k in plain:
+            assert np.array_equal(heads[k], plain[k]), k
+        assert e.infer(xd, 0.5, 0.45, 0.1).tobytes() == got.tobytes()
+    finally:
+        e.close()
+
+
 def test_infer_matches_reference_fixture_detections(pkg, eng640, torch_cuda):
     """Against detections produced by the reference's own model.py + postprocess.hpp (committed fixture)."""
     gold = load_golden("frame640_seed1234.npz")
