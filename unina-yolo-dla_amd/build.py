@@ -50,19 +50,28 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     cc = hipcc()
     dep_mtime = max(os.path.getmtime(h) for h in _deps())
     objs = []
-    rebuilt = False
+    jobs = []
     for unit, extra in UNITS.items():
         src = os.path.join(CSRC, unit)
         obj = os.path.join(OBJ, unit + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), dep_mtime):
-            cmd = [cc, *COMMON, *extra, "-c", src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
-            r = subprocess.run(cmd, capture_output=True, text=True)
-            if r.returncode:
-                raise RuntimeError(f"hipcc failed on {unit}:\n{r.stderr}")
-            rebuilt = True
+            jobs.append((unit, [cc, *COMMON, *extra, "-c", src, "-o", obj]))
+
+    def compile_one(job):
+        unit, cmd = job
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return unit, r.returncode, r.stderr
+
+    # the units are independent: compile them side by side (a cold build is ~3 min of hipcc time, ~1.5 min wall on 4 jobs)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(4, os.cpu_count() or 1))) as pool:
+        for unit, rc, err in pool.map(compile_one, jobs):
+            if rc:
+                raise RuntimeError(f"hipcc failed on {unit}:\n{err}")
+    rebuilt = bool(jobs)
     if rebuilt or not os.path.exists(LIB):
         cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
