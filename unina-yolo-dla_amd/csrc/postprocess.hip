@@ -211,6 +211,55 @@ __device__ __forceinline__ void greedy_scan(const unsigned long long* mask, cons
   if (lane < kWords) removed[lane] = removed_reg;
 }
 
+// lane ^ J within a wave, J a compile-time power of two < 64
+template <int J>
+__device__ __forceinline__ unsigned xor_lane(unsigned v, int lane) {
+  if constexpr (J == 1) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  } else if constexpr (J == 2) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  } else if constexpr (J == 8) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);   // row_ror:8 (rotation by half a row = xor 8)
+  } else if constexpr (J == 4) {
+    const unsigned a = (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xF, 0xF, true);   // row_ror:4  : lane i <- lane (i - 4) mod 16
+    const unsigned b = (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x12C, 0xF, 0xF, true);   // row_ror:12 : lane i <- lane (i + 4) mod 16
+    return (lane & 4) ? a : b;
+  } else if constexpr (J == 16) {
+    return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);               // bitmask mode: and 0x1F, or 0, xor 16
+  } else {
+    return (unsigned)__shfl_xor((int)v, J);
+  }
+}
+
+template <int K, int J>
+__device__ __forceinline__ void sort_step(unsigned long long& key, int tid, unsigned long long* (&buf)[2], int& pb) {
+  unsigned long long other;
+  if constexpr (J >= 64) {
+    buf[pb][tid] = key;
+    __syncthreads();
+    other = buf[pb][tid ^ J];
+    pb ^= 1;
+  } else {
+    const int lane = tid & 63;
+    const unsigned lo = xor_lane<J>((unsigned)key, lane), hi = xor_lane<J>((unsigned)(key >> 32), lane);
+    other = ((unsigned long long)hi << 32) | lo;
+  }
+  const bool take_max = ((tid & J) == 0) == ((tid & K) == 0);   // lower index of a descending pair keeps the larger key
+  key = take_max ? (key > other ? key : other) : (key < other ? key : other);
+  if constexpr (J > 1) sort_step<K, J / 2>(key, tid, buf, pb);
+}
+
+// stages K, 2K, ... up to N (N a power of two <= kT, block-uniform)
+template <int K>
+__device__ __forceinline__ void sort_stages(unsigned long long& key, int N, int tid, unsigned long long* (&buf)[2], int& pb) {
+  if constexpr (K <= kT) {
+    if (K <= N) {
+      sort_step<K, K / 2>(key, tid, buf, pb);
+      sort_stages<2 * K>(key, N, tid, buf, pb);
+    }
+  }
+}
+
 // Records 0..n) sit in s.box / s.cc in enumeration order; on return they are in SORTED order (confidence descending,
 // ties by enumeration order), padded to a multiple of 64 with never-suppressed dummies. The 64-bit keys
 // (confidence bits << 32 | ~enumeration position: all distinct, so the order is total and deterministic) are sorted
@@ -223,28 +272,16 @@ __device__ void rank_sort_records(Smem& s, int n) {
   while (N < n) N <<= 1;   // power of two >= n, <= kMaxDet == kT
   static_assert(kTriWords >= kT, "s.mask doubles as the second key buffer");
   // Every thread holds one key in a register (threads >= N hold 0 and only ever meet each other). Compare-exchange
-  // partners tid ^ j with j < 64 sit in the same wave: those 45 of the 55 steps (N = 1024) are register shuffles with
+  // partners tid ^ j with j < 64 sit in the same wave: those 45 of the 55 steps (N = 1024) are register exchanges with
   // no barrier; the 10 steps with j >= 64 go through LDS, ping-ponging between s.keys and s.mask (free at this point)
   // so that each costs ONE barrier.
   unsigned long long key = tid < n ? (((unsigned long long)__float_as_uint(s.cc[tid].x) << 32) | (0xFFFFFFFFu - (unsigned)tid)) : 0ull;
   unsigned long long* buf[2] = {s.keys, s.mask};
   int pb = 0;
-  for (int k = 2; k <= N; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      unsigned long long other;
-      if (j >= 64) {
-        buf[pb][tid] = key;
-        __syncthreads();
-        other = buf[pb][tid ^ j];
-        pb ^= 1;
-      } else {
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)key, j), hi = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), j);
-        other = ((unsigned long long)hi << 32) | lo;
-      }
-      const bool take_max = ((tid & j) == 0) == ((tid & k) == 0);   // lower index of a descending pair keeps the larger key
-      key = take_max ? (key > other ? key : other) : (key < other ? key : other);
-    }
-  }
+  // The network is unrolled at compile time so that every partner distance is a constant: j = 1, 2, 8 are single DPP
+  // moves (quad_perm / row_ror -- VALU latency instead of a trip through the LDS crossbar), j = 4 two of them and a
+  // select, j = 16 a ds_swizzle (no address operand), j = 32 a bpermute; 34 of the 55 steps at N = 1024 have j <= 8.
+  sort_stages<2>(key, N, tid, buf, pb);
   __syncthreads();
   s.keys[tid] = key;
   __syncthreads();
