@@ -225,9 +225,16 @@ __device__ __forceinline__ unsigned xor_lane(unsigned v, int lane) {
     const unsigned b = (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x12C, 0xF, 0xF, true);   // row_ror:12 : lane i <- lane (i + 4) mod 16
     return (lane & 4) ? a : b;
   } else if constexpr (J == 16) {
-    return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);               // bitmask mode: and 0x1F, or 0, xor 16
+    // v_permlane16_swap (gfx950): swaps the odd rows of its first operand with the even rows of its second. With v in
+    // both: [0] = rows (r0, r0, r2, r2), [1] = rows (r1, r1, r3, r3) -> an even row takes [1], an odd row [0].
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (lane & 16) ? r[0] : r[1];
   } else {
-    return (unsigned)__shfl_xor((int)v, J);
+    // v_permlane32_swap: swaps the upper half of its first operand with the lower half of its second:
+    // [0] = (lo, lo), [1] = (hi, hi) -> the lower half takes [1], the upper half [0].
+    static_assert(J == 32, "intra-wave distance");
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (lane & 32) ? r[0] : r[1];
   }
 }
 
@@ -280,7 +287,7 @@ __device__ void rank_sort_records(Smem& s, int n) {
   int pb = 0;
   // The network is unrolled at compile time so that every partner distance is a constant: j = 1, 2, 8 are single DPP
   // moves (quad_perm / row_ror -- VALU latency instead of a trip through the LDS crossbar), j = 4 two of them and a
-  // select, j = 16 a ds_swizzle (no address operand), j = 32 a bpermute; 34 of the 55 steps at N = 1024 have j <= 8.
+  // select, j = 16 / 32 a v_permlane16_swap / v_permlane32_swap and a select; 34 of the 55 steps at N = 1024 have j <= 8.
   sort_stages<2>(key, N, tid, buf, pb);
   __syncthreads();
   s.keys[tid] = key;
