@@ -572,7 +572,23 @@ __global__ __launch_bounds__(kTileThreads) void nms_tiles_kernel(const PostParam
   if (p.stamps && tid == 0) p.stamps[4] = wall_clock64();
 
   // ---- last block: scan + compaction + output ----
-  for (int k = tid; k < 64 * ntiles; k += kTileThreads) s.mask[k] = p.ws_mask[k];
+  {  // tiles -> LDS, 8 independent loads in flight per thread (one load per trip costs an L2 round trip each)
+    constexpr int B = 8;
+    const int total = 64 * ntiles;
+    for (int k0 = tid; k0 < total; k0 += kTileThreads * B) {
+      unsigned long long v[B];
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int k = k0 + b * kTileThreads;
+        v[b] = k < total ? p.ws_mask[k] : 0ull;
+      }
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int k = k0 + b * kTileThreads;
+        if (k < total) s.mask[k] = v[b];
+      }
+    }
+  }
   if (tid < kWords) {
     unsigned long long nz = 0ull;
     if (tid < nw)
