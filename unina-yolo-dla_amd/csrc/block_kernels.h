@@ -77,7 +77,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
   typename E::frag q[D];
   // per-channel constants of every step -> LDS
   float* bias_lds = reinterpret_cast<float*>(smem + p.off_bias);
-  for (int i = threadIdx.x; i < p.n_bias; i += NT) bias_lds[i] = p.bias[i];
+  floatx4 cregs[kConstVecs];
 #define CST(S) (bias_lds + E::CM * PL::cfirst((S) + PRE))
 
   // input patch (tile + NB-pixel halo, all CIN channels) -> LDS image; with a pre-conv: ITS input footprint instead
@@ -94,7 +94,9 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
     load_patch<TH + 2 * NB, R0W, CIN, NT, E>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0 - NB, tx0 - NB, p.zeros, wid, lane);
   }
   static_for<0, D>([&](auto gc) { wq_fetch<ST, D, decltype(gc)::value>(q, wbase, wid); });
+  consts_issue<NT>(cregs, p.bias, p.n_bias);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed (LDS-DMA is not tracked by the compiler)
+  consts_commit<NT>(cregs, bias_lds, p.n_bias);
   lds_barrier();
 
   const Img Xi = Img{p.off_x, X.nch, X.sh, X.mask};
@@ -351,11 +353,13 @@ __device__ __forceinline__ void head_fused_body(const HeadParams& p, int bid, un
   half8 q[D];
 
   float* bias_lds = reinterpret_cast<float*>(smem + p.off_bias);
-  for (int i = threadIdx.x; i < p.n_bias; i += NT) bias_lds[i] = p.bias[i];
+  floatx4 cregs[kConstVecs];
   constexpr Img X = make_img(0, C / 8);
   load_patch<R0H, R0W, C, NT>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0 - 2, tx0 - 2, p.zeros, wid, lane);
   static_for<0, D>([&](auto gc) { wq_fetch<ST, D, decltype(gc)::value>(q, wbase, wid); });
+  consts_issue<NT>(cregs, p.bias, p.n_bias);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
+  consts_commit<NT>(cregs, bias_lds, p.n_bias);
   lds_barrier();
 
   const Img Xi = Img{p.off_x, X.nch, X.sh, X.mask};

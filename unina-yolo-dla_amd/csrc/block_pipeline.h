@@ -231,6 +231,31 @@ __device__ __forceinline__ int img_at(const Img& im, int row, int n) {   // byte
   return im.addr(row, n / E::CH) + (n % E::CH) * E::ESZ;
 }
 
+// Per-channel constants (biases ...) global -> LDS in two halves, so that their loads are IN FLIGHT together with the
+// patch DMA and the first weight blocks instead of in front of them: consts_issue() right after those are issued
+// (branch-free: clamped index, every lane loads), consts_commit() after the s_waitcnt vmcnt(0) that the patch needs anyway.
+// n is a multiple of 4, at most 4 * kConstVecs * NT floats; the array is 16-byte aligned.
+constexpr int kConstVecs = 4;
+template <int NT>
+__device__ __forceinline__ void consts_issue(floatx4 (&v)[kConstVecs], const float* src, int n) {
+  const int nv = n >> 2;
+#pragma unroll
+  for (int b = 0; b < kConstVecs; ++b) {
+    int i = (int)threadIdx.x + b * NT;
+    i = i < nv ? i : nv - 1;
+    v[b] = reinterpret_cast<const floatx4*>(src)[i];
+  }
+}
+template <int NT>
+__device__ __forceinline__ void consts_commit(const floatx4 (&v)[kConstVecs], float* lds, int n) {
+  const int nv = n >> 2;
+#pragma unroll
+  for (int b = 0; b < kConstVecs; ++b) {
+    const int i = (int)threadIdx.x + b * NT;
+    if (i < nv) reinterpret_cast<floatx4*>(lds)[i] = v[b];
+  }
+}
+
 // Input patch -> LDS image by LDS-DMA: 16-byte slot s = (region pixel r of an RH x RW region whose origin is image
 // pixel (y0, x0), chunk cs); out-of-image pixels read the zero page. NT threads; every wave must afterwards wait
 // vmcnt(0) (its own DMAs) and pass a barrier before anyone reads the image.

@@ -46,11 +46,13 @@ __global__ __launch_bounds__(NW * 64) void conv_pair_kernel(const PairParams p) 
   const unsigned char* wbase = p.wstream + (4 * l15 + (lq ^ swz_g(l15))) * 16;
   typename E::frag q[D];
   float* cst = reinterpret_cast<float*>(smem + p.off_bias);
-  for (int i = threadIdx.x; i < p.n_bias; i += NT) cst[i] = p.bias[i];
+  floatx4 cregs[kConstVecs];
   constexpr Img X = make_img(0, C0 / E::CH);
   load_patch<TH, TW, C0, NT, E>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0, tx0, p.zeros, wid, lane);
   static_for<0, D>([&](auto gc) { wq_fetch<ST, D, decltype(gc)::value>(q, wbase, wid); });
+  consts_issue<NT>(cregs, p.bias, p.n_bias);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
+  consts_commit<NT>(cregs, cst, p.n_bias);
   lds_barrier();
 
   const Img Xi = Img{p.off_x, X.nch, X.sh, X.mask};
