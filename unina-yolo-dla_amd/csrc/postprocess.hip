@@ -520,6 +520,7 @@ struct Smem2 {
   unsigned long long mask[kTriWords];
   unsigned long long rownz[kWords];
   unsigned long long removed[kWords];
+  unsigned long long tilenz[kMaxTiles];
   int wave_cnt[4];
   int is_last;
 };
@@ -589,10 +590,12 @@ __global__ __launch_bounds__(kTileThreads) void nms_tiles_kernel(const PostParam
       }
     }
   }
+  if (tid < ntiles) s.tilenz[tid] = p.ws_tilenz[tid];   // ntiles <= kMaxTiles = 136 <= kTileThreads: ONE round trip (the
+  __syncthreads();                                       // per-row OR below was up to nw dependent global loads)
   if (tid < kWords) {
     unsigned long long nz = 0ull;
     if (tid < nw)
-      for (int w = tid; w < nw; ++w) nz |= p.ws_tilenz[(tid * nw - (tid * (tid - 1)) / 2) + (w - tid)];
+      for (int w = tid; w < nw; ++w) nz |= s.tilenz[(tid * nw - (tid * (tid - 1)) / 2) + (w - tid)];
     s.rownz[tid] = nz;
   }
   __syncthreads();
