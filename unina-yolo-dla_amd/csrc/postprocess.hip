@@ -196,16 +196,31 @@ __device__ __forceinline__ int tri_off(int c, int nw) { return 64 * (c * nw - (c
 __device__ __forceinline__ void greedy_scan(const unsigned long long* mask, const unsigned long long* rownz,
                                             unsigned long long* removed, int nw, int lane) {
   unsigned long long removed_reg = 0ull;
+  // word c of the removed set lives in lane c: a wave-uniform v_readlane (c is a scalar loop counter), not a bpermute
+  auto word_of = [&](int c) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)removed_reg, c);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(removed_reg >> 32), c);
+    return ((unsigned long long)hi << 32) | lo;
+  };
   for (int c = 0; c < nw; ++c) {
     unsigned long long todo = rownz[c];
-    unsigned long long cur = __shfl(removed_reg, c);
+    unsigned long long cur = word_of(c);
     const int base = tri_off(c, nw), stride = nw - c;
+    const bool mine = lane >= c && lane < nw;
+    const unsigned long long* row0 = mask + base + (mine ? lane - c : 0);
+    // the next candidate row is known before the current one is decided: its words are fetched one row ahead
+    int r = todo ? __ffsll((long long)todo) - 1 : 0;
+    unsigned long long next_words = row0[r * stride];
     while (todo) {
-      const int r = __ffsll((long long)todo) - 1;
       todo &= todo - 1ull;
-      if ((cur >> r) & 1ull) continue;  // row r was itself suppressed: it suppresses nothing
-      if (lane >= c && lane < nw) removed_reg |= mask[base + r * stride + (lane - c)];
-      cur = __shfl(removed_reg, c);
+      const unsigned long long words = next_words;
+      const int rn = todo ? __ffsll((long long)todo) - 1 : r;
+      next_words = row0[rn * stride];
+      if (!((cur >> r) & 1ull)) {   // (a row that was itself suppressed suppresses nothing)
+        if (mine) removed_reg |= words;
+        cur = word_of(c);
+      }
+      r = rn;
     }
   }
   if (lane < kWords) removed[lane] = removed_reg;
