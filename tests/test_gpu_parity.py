@@ -234,6 +234,37 @@ def test_non_square_input_and_empty_result(pkg, sd7, oracle_mod, oracle_sd7, tor
         e.close()
 
 
+@pytest.mark.parametrize("nc,cls_scale,thr", [(1, 30.0, 0.05), (7, 10.0, 0.2)])
+def test_other_class_counts(pkg, oracle_mod, torch_cuda, nc, cls_scale, thr):
+    """num_classes is a model parameter (model.py:331-333; the node hard-codes 4, perception_node.cpp:630-639): the engine
+    takes it from the engine file. 1 and 7 classes (the head's output rows are padded to 16 per branch): heads and
+    detections vs the fp32 oracle, fused = per-op bit for bit."""
+    from unina_yolo_dla_amd.engine import Engine
+    g = pkg.graph.Graph(num_classes=nc, in_h=256, in_w=256)
+    sd = pkg.synth.make_state_dict(7, g, head_scales={n: (cls_scale if n.endswith("cls") else 2.0) for n in pkg.graph.OUTPUT_NAMES})
+    osd = oracle_mod.StateDict(sd)
+    e = Engine.from_state_dict(sd, g)
+    try:
+        x = pkg.rng.frame(1234, 256, 256)
+        xd = torch_cuda.from_numpy(x).cuda()
+        heads = {k: v.copy() for k, v in e.forward(xd).items()}
+        o = oracle_mod.forward(osd, x, num_classes=nc)
+        for n in pkg.graph.OUTPUT_NAMES:
+            assert heads[n].shape == o[n].shape and heads[n].shape[0] == (nc if n.endswith("cls") else 4)
+            np.testing.assert_allclose(heads[n], o[n], atol=HEAD_ATOL, rtol=0, err_msg=n)
+        got = e.infer(xd, thr, 0.45, 0.1)
+        want, ncand = oracle_mod.postprocess([o[n] for n in pkg.graph.OUTPUT_NAMES], thr, 0.45, 0.1)
+        assert 0 < ncand < 1024 and set(np.unique(got["class_id"])) <= set(range(nc))
+        check_fp16_detections(got, want, thr)
+        e.set_fusion(False)
+        plain = e.forward(xd)
+        for k in plain:
+            assert np.array_equal(heads[k], plain[k]), k
+    finally:
+        e.close()
+        osd.close()
+
+
 def test_infer_matches_reference_fixture_detections(pkg, eng640, torch_cuda):
     """Against detections produced by the reference's own model.py + postprocess.hpp (committed fixture)."""
     gold = load_golden("frame640_seed1234.npz")
