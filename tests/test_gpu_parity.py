@@ -484,11 +484,13 @@ def test_tile_configs_and_autotune_are_bit_identical(pkg, sd7, torch_cuda, preci
 # With fusion on, a down-sampling conv (down1 / down2) runs as the first step of the PAN block that consumes it and its
 # output -- the first channels of the concat buffer -- never reaches HBM: those channels are compared through the block's
 # output only.
-NOT_WRITTEN_WHEN_FUSED = {"neck.cat_pan1": 64, "neck.cat_pan2": 128, "cat_pan1": 64, "cat_pan2": 128}
+WRITTEN_WHEN_FUSED = {"neck.cat_pan1": (64, None), "neck.cat_pan2": (128, None), "cat_pan1": (64, None), "cat_pan2": (128, None),
+                      "backbone.sppf.cat": (0, 128)}    # (the three pooled maps of the SPPF are formed in LDS by the cv2 / lateral kernel)
 
 
 def written(bname, arr):
-    return arr[NOT_WRITTEN_WHEN_FUSED.get(bname, 0):]
+    a, b = WRITTEN_WHEN_FUSED.get(bname, (0, None))
+    return arr[a:b]
 
 
 BLOCK_OUTPUTS = ("neck.cat_fpn2", "neck.cat_fpn1", "neck.cat_pan2", "neck.cat_pan1", "p2_fused", "p3_out", "p4_out",

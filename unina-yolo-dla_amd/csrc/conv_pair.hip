@@ -28,7 +28,23 @@ struct PairPlan {
   static constexpr int cfirst(int s) { return s == 0 ? 0 : nch(0); }
 };
 
-template <int C0, int C1, int C2, int TH, int TW, int NW, int D, int UP2, typename E>
+// element-wise maximum of two 16-byte chunks (8 fp16 / 16 int8 values; SPPF inputs are post-ReLU, i.e. >= 0)
+template <typename E>
+__device__ __forceinline__ typename E::frag chunk_max(const typename E::frag& a, const typename E::frag& b) {
+  if constexpr (E::I8) {
+    typedef signed char c16 __attribute__((ext_vector_type(16)));
+    const c16 x = __builtin_bit_cast(c16, a), y = __builtin_bit_cast(c16, b);
+    return __builtin_bit_cast(typename E::frag, __builtin_elementwise_max(x, y));
+  } else {
+    return __builtin_elementwise_max(a, b);
+  }
+}
+
+// POOL = 1: the three chained MaxPool2d(5, 1, 2) of SPPF_DLA (model.py:125, 129-131) run inside the launch too: the
+// kernel reads only x = sppf.cv1's output (C0 / 4 channels) on the tile + 6-pixel halo, forms the 5x5 / 9x9 / 13x13
+// clipped-window maxima (= the chained pools; zero fill outside the image is neutral for post-ReLU values) separably in
+// LDS, and feeds [x | p1 | p2 | p3] to step 0 -- the 3 pooled maps never exist in HBM.
+template <int C0, int C1, int C2, int TH, int TW, int NW, int D, int UP2, typename E, int POOL = 0>
 __global__ __launch_bounds__(NW * 64) void conv_pair_kernel(const PairParams p) {
   typedef PairPlan<C0, C1, C2, NW, E::KBLK> PL;
   typedef StepTable<PL, NW> ST;
@@ -48,7 +64,12 @@ __global__ __launch_bounds__(NW * 64) void conv_pair_kernel(const PairParams p) 
   float* cst = reinterpret_cast<float*>(smem + p.off_bias);
   floatx4 cregs[kConstVecs];
   constexpr Img X = make_img(0, C0 / E::CH);
-  load_patch<TH, TW, C0, NT, E>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0, tx0, p.zeros, wid, lane);
+  constexpr int CXP = C0 / 4, NCX = CXP / E::CH;            // POOL: channels / chunks of x
+  constexpr int RH = TH + 12, RW = TW + 12;                 // POOL: tile + 6-pixel halo
+  if constexpr (POOL)
+    load_patch<RH, RW, CXP, NT, E>(smem + p.off_r, p.src, p.src_ld, p.H, p.W, ty0 - 6, tx0 - 6, p.zeros, wid, lane);
+  else
+    load_patch<TH, TW, C0, NT, E>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0, tx0, p.zeros, wid, lane);
   static_for<0, D>([&](auto gc) { wq_fetch<ST, D, decltype(gc)::value>(q, wbase, wid); });
   consts_issue<NT>(cregs, p.bias, p.n_bias);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
@@ -56,6 +77,46 @@ __global__ __launch_bounds__(NW * 64) void conv_pair_kernel(const PairParams p) 
   lds_barrier();
 
   const Img Xi = Img{p.off_x, X.nch, X.sh, X.mask};
+  if constexpr (POOL) {
+    typedef typename E::frag frag;
+    constexpr Img R0 = make_img(0, NCX);
+    const Img R = Img{p.off_r, R0.nch, R0.sh, R0.mask};
+    frag* V = reinterpret_cast<frag*>(smem + p.off_v);       // [3][TH][RW][NCX] vertical maxima (5 / 9 / 13 rows)
+    constexpr int VN = TH * RW * NCX;
+    for (int t = threadIdx.x; t < VN; t += NT) {
+      const int c = t % NCX, rx = (t / NCX) % RW, ty = t / (NCX * RW);
+      frag v[13];
+#pragma unroll
+      for (int d = 0; d < 13; ++d) v[d] = *reinterpret_cast<const frag*>(smem + R.addr((ty + d) * RW + rx, c));
+      frag m = v[6];
+#pragma unroll
+      for (int d = 1; d <= 2; ++d) m = chunk_max<E>(m, chunk_max<E>(v[6 - d], v[6 + d]));
+      V[t] = m;
+#pragma unroll
+      for (int d = 3; d <= 4; ++d) m = chunk_max<E>(m, chunk_max<E>(v[6 - d], v[6 + d]));
+      V[VN + t] = m;
+#pragma unroll
+      for (int d = 5; d <= 6; ++d) m = chunk_max<E>(m, chunk_max<E>(v[6 - d], v[6 + d]));
+      V[2 * VN + t] = m;
+    }
+    lds_barrier();
+    for (int t = threadIdx.x; t < PT * NCX; t += NT) {
+      const int c = t % NCX, pp = t / NCX, ty = pp / TW, tx = pp - ty * TW;
+      const frag* row = V + (ty * RW + tx + 6) * NCX + c;     // centre column of this pixel in the v5 plane
+      frag o5 = row[0], o9 = row[VN], o13 = row[2 * VN];
+#pragma unroll
+      for (int d = 1; d <= 6; ++d) {
+        o13 = chunk_max<E>(o13, chunk_max<E>(row[2 * VN - d * NCX], row[2 * VN + d * NCX]));
+        if (d <= 4) o9 = chunk_max<E>(o9, chunk_max<E>(row[VN - d * NCX], row[VN + d * NCX]));
+        if (d <= 2) o5 = chunk_max<E>(o5, chunk_max<E>(row[-d * NCX], row[d * NCX]));
+      }
+      *reinterpret_cast<frag*>(smem + Xi.addr(pp, c)) = *reinterpret_cast<const frag*>(smem + R.addr((ty + 6) * RW + tx + 6, c));
+      *reinterpret_cast<frag*>(smem + Xi.addr(pp, NCX + c)) = o5;
+      *reinterpret_cast<frag*>(smem + Xi.addr(pp, 2 * NCX + c)) = o9;
+      *reinterpret_cast<frag*>(smem + Xi.addr(pp, 3 * NCX + c)) = o13;
+    }
+    lds_barrier();
+  }
   typedef typename E::acc_t acc_t;
   typedef float vec16 __attribute__((ext_vector_type(4)));  // 16 opaque bytes
   auto pixel = [&](int sub) {
@@ -121,15 +182,18 @@ struct PClass {
   int dtype, c0, c1, c2, up2, th, tw, nw;
   const char* name;
   void (*fn)(const PairParams);
+  int pool;
 };
 const PClass kPairClasses[] = {
     // backbone.sppf.cv2 -> neck.lateral_p3 (+ x2 upsample): 100 workgroups at 40^2
-    {kF16, 512, 256, 128, 1, 4, 4, 8, "conv_pair<512,256,128,4x4,8w,up2>", conv_pair_kernel<512, 256, 128, 4, 4, 8, 16, 1, EltH>},
-    {kI8, 512, 256, 128, 1, 4, 4, 8, "conv_pair<i8,512,256,128,4x4,8w,up2>", conv_pair_kernel<512, 256, 128, 4, 4, 8, 8, 1, EltI8>},
+    {kF16, 512, 256, 128, 1, 4, 4, 8, "conv_pair<512,256,128,4x4,8w,up2>", conv_pair_kernel<512, 256, 128, 4, 4, 8, 16, 1, EltH>, 0},
+    {kF16, 512, 256, 128, 1, 4, 4, 8, "conv_pair<pool5x3,512,256,128,4x4,8w,up2>", conv_pair_kernel<512, 256, 128, 4, 4, 8, 16, 1, EltH, 1>, 1},
+    {kI8, 512, 256, 128, 1, 4, 4, 8, "conv_pair<i8,512,256,128,4x4,8w,up2>", conv_pair_kernel<512, 256, 128, 4, 4, 8, 8, 1, EltI8>, 0},
+    {kI8, 512, 256, 128, 1, 4, 4, 8, "conv_pair<i8,pool5x3,512,256,128,4x4,8w,up2>", conv_pair_kernel<512, 256, 128, 4, 4, 8, 8, 1, EltI8, 1>, 1},
 };
-const PClass* find_pclass(int dtype, int c0, int c1, int c2, int up2) {
+const PClass* find_pclass(int dtype, int c0, int c1, int c2, int up2, int pool = 0) {
   for (const PClass& c : kPairClasses)
-    if (c.dtype == dtype && c.c0 == c0 && c.c1 == c1 && c.c2 == c2 && c.up2 == up2) return &c;
+    if (c.dtype == dtype && c.c0 == c0 && c.c1 == c1 && c.c2 == c2 && c.up2 == up2 && c.pool == pool) return &c;
   return nullptr;
 }
 int align_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -144,10 +208,10 @@ hipError_t pair_init() {
   return hipSuccess;
 }
 
-bool pair_supported(int dtype, int c0, int c1, int c2, int up2) { return find_pclass(dtype, c0, c1, c2, up2) != nullptr; }
+bool pair_supported(int dtype, int c0, int c1, int c2, int up2, int pool) { return find_pclass(dtype, c0, c1, c2, up2, pool) != nullptr; }
 
 bool pair_layout(PairParams* p) {
-  const PClass* c = find_pclass(p->dtype, p->c0, p->c1, p->c2, p->up2);
+  const PClass* c = find_pclass(p->dtype, p->c0, p->c1, p->c2, p->up2, p->pool);
   if (!c) return false;
   const int esz = p->dtype == kI8 ? 1 : 2, cm = p->dtype == kI8 ? 3 : 1, pt = c->th * c->tw;
   p->tiles_x = (p->W + c->tw - 1) / c->tw;
@@ -161,23 +225,29 @@ bool pair_layout(PairParams* p) {
   const int x_bytes = align_up(pt * p->c0 * esz, 1024) + 1024, out_bytes = pt * (p->c2 * esz + 16);
   off += align_up(x_bytes > out_bytes ? x_bytes : out_bytes, 1024);
   p->off_stage = off; off += align_up(pt * (p->c1 * esz + 16), 1024);
+  p->off_r = p->off_v = 0;
+  if (p->pool) {   // x on the tile + 6-pixel halo, and the three planes of vertical maxima
+    const int cx = p->c0 / 4, rh = c->th + 12, rw = c->tw + 12;
+    p->off_r = off; off += align_up(rh * rw * cx * esz, 1024) + 1024;
+    p->off_v = off; off += align_up(3 * c->th * rw * cx * esz, 1024);
+  }
   p->smem_bytes = off;
   return off <= 160 * 1024;
 }
 
 hipError_t pair_launch(const PairParams& p, hipStream_t stream) {
-  const PClass* c = find_pclass(p.dtype, p.c0, p.c1, p.c2, p.up2);
+  const PClass* c = find_pclass(p.dtype, p.c0, p.c1, p.c2, p.up2, p.pool);
   if (!c) return hipErrorInvalidValue;
   hipLaunchKernelGGL(c->fn, dim3(p.tiles_x * p.tiles_y, 1, 1), dim3(c->nw * 64, 1, 1), p.smem_bytes, stream, p);
   return hipGetLastError();
 }
 
 const char* pair_kernel_name(const PairParams& p) {
-  const PClass* c = find_pclass(p.dtype, p.c0, p.c1, p.c2, p.up2);
+  const PClass* c = find_pclass(p.dtype, p.c0, p.c1, p.c2, p.up2, p.pool);
   return c ? c->name : "conv_pair<?>";
 }
 int pair_block_threads(const PairParams& p) {
-  const PClass* c = find_pclass(p.dtype, p.c0, p.c1, p.c2, p.up2);
+  const PClass* c = find_pclass(p.dtype, p.c0, p.c1, p.c2, p.up2, p.pool);
   return c ? c->nw * 64 : 0;
 }
 

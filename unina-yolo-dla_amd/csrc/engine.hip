@@ -205,8 +205,10 @@ void op_regions(const unina_engine* e, size_t i, std::vector<Region>* reads, std
       if (d.seg[0].n_count < blk.cin)
         reads->push_back({(int)blk.src_buf, (int)(blk.seg[0].src_coff + d.seg[0].n_count), (int)(blk.seg[0].src_coff + blk.cin)});
     }
-    if (e->ops[i].fuse_kind == 4)   // the first conv's output goes to HBM too
-      writes->push_back({(int)d.seg[0].dst_buf, (int)d.seg[0].dst_coff, (int)(d.seg[0].dst_coff + d.seg[0].n_count)});
+    if (e->ops[i].fuse_kind == 4) {   // the first conv's output goes to HBM too
+      const OpDesc& c1 = e->ops[i + e->ops[i].fuse_pre].d;
+      writes->push_back({(int)c1.seg[0].dst_buf, (int)c1.seg[0].dst_coff, (int)(c1.seg[0].dst_coff + c1.seg[0].n_count)});
+    }
     for (uint32_t s = 0; s < last.nseg; ++s)
       writes->push_back({(int)last.seg[s].dst_buf, (int)last.seg[s].dst_coff, (int)(last.seg[s].dst_coff + last.seg[s].n_count)});
     if (e->ops[i].tail_op >= 0) {
@@ -402,7 +404,7 @@ int plan(unina_engine* e) {
       continue;
     }
     if (op.fuse_kind == 4) {
-      const OpDesc& a = op.d;
+      const OpDesc& a = e->ops[i + op.fuse_pre].d;
       PlannedOp& zb = e->ops[op.group_last];
       const OpDesc& z = zb.d;
       const Buffer& src = e->bufs[a.src_buf];
@@ -421,11 +423,20 @@ int plan(unina_engine* e) {
       f.dst2 = static_cast<char*>(out.ptr) + z.seg[0].dst_coff * esz;
       f.dst2_ld = (int)out.d.c;
       f.up2 = (z.seg[0].flags & kSegUp2) ? 1 : 0;
+      f.pool = op.fuse_pre;
       f.wstream = reinterpret_cast<const unsigned char*>(blob + op.stream_off);
       f.bias = reinterpret_cast<const float*>(blob + op.fbias_off);
       f.zeros = e->d_zeros;
       if (!pair_layout(&f)) return fail(e, UNINA_ERR_UNSUPPORTED, "op %zu: fused conv pair does not fit", i);
       if (!e->fuse) continue;
+      if (op.fuse_pre) {   // the pool op is the group's head: the infos of cv2 move onto it
+        unina_op_info& ai = e->ops[i + 1].info;
+        op.info.flops = ai.flops;
+        op.info.bytes = ai.bytes - (double)esz * f.H * f.W * 3 * (f.c0 / 4);   // the pooled maps are formed in LDS
+        op.info.m = ai.m; op.info.n = ai.n;
+        ai.flops = 0; ai.bytes = 0; ai.grid = 0;
+        snprintf(ai.kernel, sizeof ai.kernel, "(fused into op %zu)", i);
+      }
       op.info.flops += zb.info.flops;
       op.info.bytes += zb.info.bytes - (double)esz * f.H * f.W * f.c1;     // the second conv reads the first's output from LDS
       op.info.grid = f.tiles_x * f.tiles_y;
@@ -989,6 +1000,26 @@ void find_pair_groups(unina_engine* e, std::vector<char>* blob) {
     const OpDesc& a = e->ops[i].d;
     const OpDesc& z = e->ops[i + 1].d;
     if (a.kind != kOpConv || z.kind != kOpConv) continue;
+    // SPPF: the pool op right in front (x -> [p1 | p2 | p3] next to x in the same buffer) whose 4-way concat `a` reads can
+    // run inside the pair's launch when nothing else reads the pooled maps
+    int pool = 0;
+    if (i > 0 && !e->ops[i - 1].fuse_role && e->ops[i - 1].d.kind == kOpSppfPool) {
+      const OpDesc& pl = e->ops[i - 1].d;
+      bool ok = pl.src_buf == a.src_buf && pl.seg[0].src_coff == a.seg[0].src_coff && a.cin == 4 * pl.cin;
+      const Region pooled{(int)pl.src_buf, (int)(pl.seg[0].src_coff + pl.cin), (int)(pl.seg[0].src_coff + 4 * pl.cin)};
+      for (size_t k = 0; k < n && ok; ++k) {
+        if (k == i - 1 || k == i) continue;
+        const OpDesc& o = e->ops[k].d;
+        if (o.kind == kOpStem) continue;
+        for (uint32_t sgi = 0; sgi < o.nseg; ++sgi) {
+          const int rc0 = (int)o.seg[sgi].src_coff, rc1 = rc0 + (int)(o.kind == kOpConv ? o.cin : o.seg[sgi].n_count);
+          if (overlaps(pooled, Region{(int)o.src_buf, rc0, rc1})) ok = false;
+          if (overlaps(pooled, Region{(int)o.seg[sgi].dst_buf, (int)o.seg[sgi].dst_coff, (int)(o.seg[sgi].dst_coff + o.seg[sgi].n_count)})) ok = false;
+        }
+        if (o.res_buf == (int)pl.src_buf) ok = false;
+      }
+      if (ok) pool = 1;
+    }
     const uint32_t bdt = e->bufs[a.src_buf].d.dtype;
     if (bdt != kBufF16Nhwc && bdt != kBufI8Nhwc) continue;
     const bool i8 = bdt == kBufI8Nhwc;
@@ -1002,7 +1033,8 @@ void find_pair_groups(unina_engine* e, std::vector<char>* blob) {
         z.seg[0].dst_coff % al || e->bufs[z.seg[0].dst_buf].d.c % al) continue;
     if (z.seg[0].dst_buf == a.seg[0].dst_buf || z.seg[0].dst_buf == a.src_buf || a.seg[0].dst_buf == a.src_buf) continue;
     const int dt = i8 ? kI8 : kF16, up2 = (z.seg[0].flags & kSegUp2) ? 1 : 0;
-    if (!pair_supported(dt, (int)a.cin, (int)a.seg[0].n_count, (int)z.seg[0].n_count, up2)) continue;
+    if (pool && !pair_supported(dt, (int)a.cin, (int)a.seg[0].n_count, (int)z.seg[0].n_count, up2, 1)) pool = 0;
+    if (!pair_supported(dt, (int)a.cin, (int)a.seg[0].n_count, (int)z.seg[0].n_count, up2, pool)) continue;
     C3k2Conv cv[2];
     memset(cv, 0, sizeof cv);
     const OpDesc* od[2] = {&a, &z};
@@ -1026,12 +1058,14 @@ void find_pair_groups(unina_engine* e, std::vector<char>* blob) {
     blob->resize((blob->size() + 255) & ~(size_t)255);
     const uint64_t bo = blob->size();
     blob->insert(blob->end(), reinterpret_cast<const char*>(bias.data()), reinterpret_cast<const char*>(bias.data() + bias.size()));
-    PlannedOp& head = e->ops[i];
+    PlannedOp& head = e->ops[i - pool];
     head.fuse_role = 1;
     head.fuse_kind = 4;
+    head.fuse_pre = pool;            // 1: this op is the SPPF pool, the conv pair are the next two ops
     head.group_last = (int)(i + 1);
     head.stream_off = so;
     head.fbias_off = bo;
+    if (pool) e->ops[i].fuse_role = 2;
     e->ops[i + 1].fuse_role = 2;
     ++e->n_groups;
     ++i;

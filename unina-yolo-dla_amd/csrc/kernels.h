@@ -185,16 +185,18 @@ struct PairParams {
   void* dst2;                    // second conv's output; up2: a (2H x 2W) destination, every pixel written to its 2x2 block
   int dst2_ld;
   int up2;
+  int pool;                      // 1: src holds only x = the first c0/4 channels of the input; the kernel forms [x | p1 | p2 | p3]
+                                 // (SPPF's three chained 5x5 max-pools) itself
   const unsigned char* wstream;  // block_pack of the two convs
   const float* bias;             // per-step constants (fp16 [bias]; int8 [bias | mult | 1/s_out])
   const void* zeros;
   // filled by pair_layout():
   int n_bias, tiles_x, tiles_y;
   unsigned tiles_x_magic;
-  int off_bias, off_x, off_stage, off_out, smem_bytes;
+  int off_bias, off_x, off_stage, off_out, off_r, off_v, smem_bytes;
 };
 hipError_t pair_init();
-bool pair_supported(int dtype, int c0, int c1, int c2, int up2);
+bool pair_supported(int dtype, int c0, int c1, int c2, int up2, int pool = 0);
 bool pair_layout(PairParams* p);
 hipError_t pair_launch(const PairParams& p, hipStream_t stream);
 const char* pair_kernel_name(const PairParams& p);
