@@ -11,14 +11,24 @@ import torch.nn.functional as F
 from unina_yolo_dla_amd import export
 
 
-def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = True, teacher: dict = None):
+def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = True, teacher: dict = None,
+                 precise_w=None, precise_a=None, builder32: "export.EngineBuilder" = None):
     """x: [1,3,H,W] fp32. Returns ({output name: [C,H,W] fp32}, {buffer name: [C,H,W] fp32}).
     int8 buffers are returned as their integer codes (multiply by the buffer scale to dequantise).
 
     teacher = {buffer name: stored values (codes for int8 buffers) read back from the ENGINE after a per-op forward}:
     every op then reads the engine's own buffers and writes into a separate set, so the returned buffers hold each
     op's emulated output GIVEN THE ENGINE'S INPUTS -- a per-op comparison that rounding flips cannot snowball through
-    (deep in an int8 network a handful of +-1 input codes moves a third of the outputs by one code)."""
+    (deep in an int8 network a handful of +-1 input codes moves a third of the outputs by one code).
+
+    Error-budget switches (tools/fp16_error_budget.py): ops whose index is in `precise_w` take their weights from
+    `builder32` (an FP32 builder of the same state_dict: same op order, fp32 folded weights) instead of the fp16 blob;
+    ops in `precise_a` store their output without the fp16 rounding. Everything else is unchanged, so the head error
+    of such a run against the fp32 oracle is the contribution of the roundings left switched on."""
+    precise_w = precise_w or ()
+    precise_a = precise_a or ()
+    blob32 = bytes(builder32.blob) if builder32 is not None else None
+    cur_op = [0]
     prec = builder.precision
     wdt = {export.FP16: "<f2", export.FP32: "<f4", export.INT8: "<f2"}[prec]
     blob = bytes(builder.blob)
@@ -40,7 +50,7 @@ def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = Tr
         d = bdtype[dst_buf]
         if d == export.BUF_I8:
             return torch.clamp(torch.round(y.float() * np.float32(1.0 / bscale[dst_buf])), -127, 127).to(y.dtype)
-        if d == export.BUF_F16 and fp16:
+        if d == export.BUF_F16 and fp16 and cur_op[0] not in precise_a:
             return y.half().to(y.dtype)
         return y.float().to(y.dtype)
 
@@ -50,6 +60,7 @@ def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = Tr
 
     for oi, op in enumerate(builder.ops):
         src = bufs[op.src_buf]
+        cur_op[0] = oi
         if op.kind == export.OP_STEM:
             s = op.segs[0]
             w = torch.from_numpy(np.frombuffer(blob, dtype="<f4", count=s.n_count * 27, offset=s.w_off).reshape(s.n_count, 3, 3, 3).copy())
@@ -81,6 +92,12 @@ def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = Tr
                     acc = F.conv2d(xin.double(), w, None, stride=op.s, padding=k // 2)[0]          # exact integers
                     # kernel: fmaf(acc, mult, bias) -> one fp32 rounding; the product is exact in fp64 (|acc| < 2^26)
                     y = (acc * mult.double()[:, None, None] + b.double()[:, None, None]).float().double()
+                elif oi in precise_w:
+                    s32 = builder32.ops[oi].segs[op.segs.index(s)]
+                    w = np.frombuffer(blob32, dtype="<f4", count=s.n_pad * K, offset=s32.w_off)
+                    w = export.unpack_weights(w, s.n_pad, K).reshape(s.n_pad, k, k, op.cin)[:s.n_count]
+                    w = torch.from_numpy(w.astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+                    y = F.conv2d(real(op.src_buf, xin).float(), w, b, stride=op.s, padding=k // 2)[0].to(src.dtype)
                 else:
                     w = np.frombuffer(blob, dtype=wdt, count=s.n_pad * K, offset=s.w_off)
                     w = export.unpack_weights(w, s.n_pad, K).reshape(s.n_pad, k, k, op.cin)[:s.n_count]

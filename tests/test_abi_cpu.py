@@ -135,3 +135,39 @@ def test_c3k2_groups_are_recognised_at_load(lib, pkg, sd7, tmp_path):
     amax = export.calibrate(run_op_table(b16, pkg.rng.frame(5000 + i, 64, 64))[1] for i in range(2))
     export.export_engine(sd7, path, g, precision=export.INT8, amax=amax)
     assert lib.unina_debug_fusable_groups(path.encode()) == 9
+
+
+def test_header_is_plain_c_and_record_is_32_bytes(tmp_path):
+    """include/unina_mi355.h must be consumable by a C compiler without the HIP headers (cgo / ctypes-gen / a C node):
+    gcc -std=c99 -pedantic on the header itself, then a C translation unit that checks the record layout the reference
+    fixes (gpu_postprocess.h:27-33) at compile time."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "unina_mi355.h")
+    r = subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Wpedantic", "-Werror",
+                        "-DUNINA_NO_HIP_HEADERS", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    src = tmp_path / "layout.c"
+    src.write_text('#define UNINA_NO_HIP_HEADERS\n#include "unina_mi355.h"\n#include <stddef.h>\n'
+                   'typedef char rec32[(sizeof(GpuDetection) == 32) ? 1 : -1];\n'
+                   'typedef char conf16[(offsetof(GpuDetection, confidence) == 16) ? 1 : -1];\n'
+                   'typedef char valid24[(offsetof(GpuDetection, valid) == 24) ? 1 : -1];\n'
+                   'int use(unina_engine_t *e) { int w, h, n; return unina_engine_input_dims(e, &w, &h, &n); }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                        "-o", str(tmp_path / "layout.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_node_harness_builds_and_links_against_the_library(pkg):
+    """tools/node_harness.cpp (the reference node's per-frame body, perception_node.cpp:581-689, over the header alone)
+    compiles with hipcc and resolves every symbol it uses from libunina_mi355.so; without arguments it prints its usage
+    before touching the GPU."""
+    import subprocess
+    from unina_yolo_dla_amd import build
+    build.build_native()
+    exe = build.build_harness()
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage:" in r.stderr
+    nm = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
+    for sym in ("unina_load_engine", "unina_enqueue", "unina_infer", "unina_infer_bgra", "decode_yolo_head", "run_gpu_nms",
+                "copy_valid_detections_to_host", "preprocess_bgra_resize", "reset_detection_counter", "get_detection_count"):
+        assert sym in nm, sym

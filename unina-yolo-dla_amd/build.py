@@ -80,5 +80,25 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+HARNESS_SRC = os.path.join(os.path.dirname(PKG), "tools", "node_harness.cpp")
+HARNESS = os.path.join(os.path.dirname(PKG), "tools", "node_harness")
+
+
+def build_harness(force: bool = False) -> str:
+    """tools/node_harness: the compiled C++ consumer of include/unina_mi355.h (the reference node's per-frame body,
+    perception_node.cpp:581-689), linked against libunina_mi355.so exactly as the node would be."""
+    if not force and os.path.exists(HARNESS) and os.path.getmtime(HARNESS) >= max(
+            os.path.getmtime(HARNESS_SRC), os.path.getmtime(os.path.join(os.path.dirname(PKG), "include", "unina_mi355.h"))):
+        return HARNESS
+    cmd = [hipcc(), "-O2", "-std=c++17", "-Wall", "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(os.path.dirname(PKG), "include"),
+           "-I", "/opt/rocm/include", HARNESS_SRC, "-o", HARNESS, "-L", PKG, "-lunina_mi355", "-L", "/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath,$ORIGIN/../unina-yolo-dla_amd", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError(f"node_harness build failed:\n{r.stderr}")
+    return HARNESS
+
+
 if __name__ == "__main__":
     print(build_native(force="--force" in sys.argv, verbose=True))
+    print(build_harness(force="--force" in sys.argv))
