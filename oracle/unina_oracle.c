@@ -156,38 +156,58 @@ static void keep(uo_run *r, const char *name, ten t, int always) {
 }
 
 /* ------------------------------------------------------------- convolution */
+/* Register-tiled GEMM micro-kernels over GCC vector extensions: MR output channels x NV vectors of output pixels
+ * (one row segment), k-sequential fp32 FMA accumulation per output -- so every variant below produces the same bits.
+ * AVX2 (the baseline the .so is built for, x86-64-v3): 4 x 16 pixels. AVX-512 (picked at run time when the host has
+ * it): 8 x 32 and 8 x 16 pixels. */
 typedef float v8f __attribute__((vector_size(32)));
-static inline v8f ld8(const float *p) {
-  v8f v;
-  memcpy(&v, p, 32);
-  return v;
-}
-static inline void st8(float *p, v8f v) { memcpy(p, &v, 32); }
-
-#define MR 4  /* output channels per register tile */
-#define NR 16 /* output pixels (one row segment) per register tile */
+typedef float v16f __attribute__((vector_size(64)));
 #define KC 256
+#define MC 64 /* output channels per work unit: its weight block (MC x K floats) is streamed once per pixel-row unit */
 
-/* acc[MR][NR] += sum_k wp[k][0..MR) * src[koff[k] + 0..NR)   (k-sequential fp32 accumulation) */
-static inline void micro_4x16(const float *restrict wp, const float *restrict base,
-                              const int64_t *restrict koff, int kn, float *restrict acc) {
-  v8f a00 = ld8(acc + 0), a01 = ld8(acc + 8), a10 = ld8(acc + 16), a11 = ld8(acc + 24);
-  v8f a20 = ld8(acc + 32), a21 = ld8(acc + 40), a30 = ld8(acc + 48), a31 = ld8(acc + 56);
-  for (int k = 0; k < kn; ++k) {
-    const float *bp = base + koff[k];
-    v8f b0 = ld8(bp), b1 = ld8(bp + 8);
-    const float *w = wp + (size_t)k * MR;
-    v8f w0 = {w[0], w[0], w[0], w[0], w[0], w[0], w[0], w[0]};
-    v8f w1 = {w[1], w[1], w[1], w[1], w[1], w[1], w[1], w[1]};
-    v8f w2 = {w[2], w[2], w[2], w[2], w[2], w[2], w[2], w[2]};
-    v8f w3 = {w[3], w[3], w[3], w[3], w[3], w[3], w[3], w[3]};
-    a00 += w0 * b0; a01 += w0 * b1;
-    a10 += w1 * b0; a11 += w1 * b1;
-    a20 += w2 * b0; a21 += w2 * b1;
-    a30 += w3 * b0; a31 += w3 * b1;
+#define SPLAT8(x) {x, x, x, x, x, x, x, x}
+#define SPLAT16(x) {x, x, x, x, x, x, x, x, x, x, x, x, x, x, x, x}
+#define DEF_MICRO(NAME, VT, VL, MR_, NV_, ATTR, SPLAT)                                                                    \
+  ATTR static void NAME(const float *restrict wp, const float *restrict base, const int64_t *restrict koff, int kn, \
+                        float *restrict acc) {                                                                      \
+    VT a[MR_][NV_];                                                                                                 \
+    _Pragma("GCC unroll 16") for (int m = 0; m < MR_; ++m)                                                         \
+        _Pragma("GCC unroll 4") for (int v = 0; v < NV_; ++v) memcpy(&a[m][v], acc + (m * NV_ + v) * VL, sizeof(VT)); \
+    for (int k = 0; k < kn; ++k) {                                                                                  \
+      const float *bp = base + koff[k];                                                                             \
+      const float *w = wp + (size_t)k * MR_;                                                                        \
+      VT b[NV_];                                                                                                    \
+      _Pragma("GCC unroll 4") for (int v = 0; v < NV_; ++v) memcpy(&b[v], bp + v * VL, sizeof(VT));                 \
+      _Pragma("GCC unroll 16") for (int m = 0; m < MR_; ++m) {                                                     \
+        const VT wv = SPLAT(w[m]);                                                                                  \
+        _Pragma("GCC unroll 4") for (int v = 0; v < NV_; ++v) a[m][v] += wv * b[v];                                 \
+      }                                                                                                             \
+    }                                                                                                               \
+    _Pragma("GCC unroll 16") for (int m = 0; m < MR_; ++m)                                                         \
+        _Pragma("GCC unroll 4") for (int v = 0; v < NV_; ++v) memcpy(acc + (m * NV_ + v) * VL, &a[m][v], sizeof(VT)); \
   }
-  st8(acc + 0, a00); st8(acc + 8, a01); st8(acc + 16, a10); st8(acc + 24, a11);
-  st8(acc + 32, a20); st8(acc + 40, a21); st8(acc + 48, a30); st8(acc + 56, a31);
+#define T_AVX512 __attribute__((target("avx512f,avx512vl,fma")))
+DEF_MICRO(micro_avx2_4x16, v8f, 8, 4, 2, , SPLAT8)
+DEF_MICRO(micro_avx512_8x32, v16f, 16, 8, 2, T_AVX512, SPLAT16)
+DEF_MICRO(micro_avx512_8x16, v16f, 16, 8, 1, T_AVX512, SPLAT16)
+
+typedef void (*micro_fn)(const float *, const float *, const int64_t *, int, float *);
+
+/* scratch that lives across calls (grown on demand): a per-call calloc of the padded planes page-faults on every layer */
+static float *g_src, *g_wp;
+static int64_t *g_koff;
+static size_t g_src_cap, g_wp_cap, g_koff_cap;
+static int grow(void **p, size_t *cap, size_t bytes) {
+  if (bytes <= *cap) return 0;
+  free(*p);
+  *p = NULL;
+  if (posix_memalign(p, 64, bytes + 4096)) {
+    *cap = 0;
+    return -1;
+  }
+  memset(*p, 0, bytes + 4096);
+  *cap = bytes;
+  return 0;
 }
 
 /* Conv2d, cross-correlation, zero padding k/2, stride s in {1,2}, k in {1,3}, optional bias
@@ -200,28 +220,60 @@ static ten conv2d(uo_run *r, ten in, const float *wgt, const float *bias, int O,
   if (r->failed) return out;
   const int K = C * k * k;
 
-  /* 1. source planes with contiguous x for every tap */
-  int64_t *koff = malloc(sizeof(int64_t) * (size_t)K);
-  float *src;
+  /* micro-kernel for this host and this row width */
+  int MR = 4, NR = 16;
+  micro_fn micro = micro_avx2_4x16;
+  if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl")) {
+    MR = 8;
+    if (Wo % 32 == 0 || Wo >= 96) {
+      NR = 32;
+      micro = micro_avx512_8x32;
+    } else {
+      micro = micro_avx512_8x16;
+    }
+  }
+
+  /* 1. source planes with contiguous x for every tap (zero padded; + NR floats of slack for the row tails) */
+  const int Hp = H + 2 * p, Wp = W + 2 * p;
+  const int Hh = (Hp + 1) / 2, Wh = (Wp + 1) / 2;
+  const size_t plane = (size_t)C * Hh * Wh;
+  const size_t src_floats = (s == 1 ? (size_t)C * Hp * Wp : 4 * plane) + 64;
+  const int panels = (O + MR - 1) / MR;
+  if (grow((void **)&g_src, &g_src_cap, src_floats * sizeof(float)) || grow((void **)&g_koff, &g_koff_cap, sizeof(int64_t) * (size_t)K) ||
+      grow((void **)&g_wp, &g_wp_cap, sizeof(float) * (size_t)panels * K * MR)) {
+    r->failed = 1;
+    set_err("oracle: conv scratch allocation failed");
+    return out;
+  }
+  float *src = g_src;
+  int64_t *koff = g_koff;
+  float *wp = g_wp;
   int64_t rs; /* row stride of the planes */
   if (s == 1) {
-    const int Hp = H + 2 * p, Wp = W + 2 * p;
     rs = Wp;
-    src = calloc((size_t)C * Hp * Wp + 64, sizeof(float));
-    for (int c = 0; c < C; ++c)
-      for (int y = 0; y < H; ++y)
-        memcpy(src + ((size_t)c * Hp + y + p) * Wp + p, in.d + ((size_t)c * H + y) * W, sizeof(float) * W);
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < C; ++c) {
+      float *pl = src + (size_t)c * Hp * Wp;
+      if (p) {
+        memset(pl, 0, sizeof(float) * (size_t)Wp * p);
+        memset(pl + (size_t)(Hp - p) * Wp, 0, sizeof(float) * (size_t)Wp * p);
+      }
+      for (int y = 0; y < H; ++y) {
+        float *row = pl + (size_t)(y + p) * Wp;
+        for (int j = 0; j < p; ++j) row[j] = 0.0f, row[Wp - 1 - j] = 0.0f;
+        memcpy(row + p, in.d + ((size_t)c * H + y) * W, sizeof(float) * W);
+      }
+    }
+    memset(src + (size_t)C * Hp * Wp, 0, 64 * sizeof(float));
     for (int c = 0, kk = 0; c < C; ++c)
       for (int kh = 0; kh < k; ++kh)
         for (int kw = 0; kw < k; ++kw, ++kk) koff[kk] = ((int64_t)c * Hp + kh) * Wp + kw;
   } else {
     /* stride 2: split the padded input into 4 parity planes Q[a][b][c][yy][xx] = pad[c][2yy+a][2xx+b] */
-    const int Hp = H + 2 * p, Wp = W + 2 * p;
-    const int Hh = (Hp + 1) / 2, Wh = (Wp + 1) / 2;
     rs = Wh;
-    const size_t plane = (size_t)C * Hh * Wh;
-    src = calloc(4 * plane + 64, sizeof(float));
-    for (int c = 0; c < C; ++c)
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < C; ++c) {
+      for (int q = 0; q < 4; ++q) memset(src + (size_t)q * plane + (size_t)c * Hh * Wh, 0, sizeof(float) * (size_t)Hh * Wh);
       for (int y = 0; y < H; ++y) {
         const int py = y + p;
         for (int x = 0; x < W; ++x) {
@@ -230,6 +282,8 @@ static ten conv2d(uo_run *r, ten in, const float *wgt, const float *bias, int O,
               in.d[((size_t)c * H + y) * W + x];
         }
       }
+    }
+    memset(src + 4 * plane, 0, 64 * sizeof(float));
     for (int c = 0, kk = 0; c < C; ++c)
       for (int kh = 0; kh < k; ++kh)
         for (int kw = 0; kw < k; ++kw, ++kk)
@@ -237,55 +291,60 @@ static ten conv2d(uo_run *r, ten in, const float *wgt, const float *bias, int O,
   }
 
   /* 2. weights packed per MR-panel: wp[panel][K][MR], zero-padded rows */
-  const int panels = (O + MR - 1) / MR;
-  float *wp = calloc((size_t)panels * K * MR, sizeof(float));
-  for (int o = 0; o < O; ++o)
-    for (int kk = 0; kk < K; ++kk) wp[((size_t)(o / MR) * K + kk) * MR + (o % MR)] = wgt[(size_t)o * K + kk];
+#pragma omp parallel for schedule(static)
+  for (int pn = 0; pn < panels; ++pn)
+    for (int kk = 0; kk < K; ++kk)
+      for (int m = 0; m < MR; ++m) {
+        const int o = pn * MR + m;
+        wp[((size_t)pn * K + kk) * MR + m] = o < O ? wgt[(size_t)o * K + kk] : 0.0f;
+      }
 
-  /* 3. tiles */
+  /* 3. work units: (block of MC channels, output row); the row's pixel tiles reuse the block's weights from cache */
   const int xt = (Wo + NR - 1) / NR;
+  const int ppb = MC / MR; /* panels per channel block */
+  const int cblocks = (panels + ppb - 1) / ppb;
 #pragma omp parallel
   {
-    float *tmp = malloc(sizeof(float) * (size_t)panels * MR * NR);
+    float tmp[MC * 32] __attribute__((aligned(64)));
 #pragma omp for collapse(2) schedule(dynamic, 1)
-    for (int y = 0; y < Ho; ++y)
-      for (int xi = 0; xi < xt; ++xi) {
-        const int x0 = xi * NR;
-        const float *base = src + (int64_t)y * rs + x0;
-        memset(tmp, 0, sizeof(float) * (size_t)panels * MR * NR);
-        for (int k0 = 0; k0 < K; k0 += KC) {
-          const int kn = K - k0 < KC ? K - k0 : KC;
-          for (int pn = 0; pn < panels; ++pn)
-            micro_4x16(wp + ((size_t)pn * K + k0) * MR, base, koff + k0, kn, tmp + (size_t)pn * MR * NR);
-        }
-        const int nx = Wo - x0 < NR ? Wo - x0 : NR;
-        for (int o = 0; o < O; ++o) {
-          const float b = bias ? bias[o] : 0.0f;
-          float *dst = out.d + ((size_t)o * Ho + y) * Wo + x0;
-          const float *t = tmp + (size_t)o * NR;
-          for (int j = 0; j < nx; ++j) dst[j] = t[j] + b;
+    for (int cb = 0; cb < cblocks; ++cb)
+      for (int y = 0; y < Ho; ++y) {
+        const int pn0 = cb * ppb, pn1 = pn0 + ppb < panels ? pn0 + ppb : panels;
+        for (int xi = 0; xi < xt; ++xi) {
+          const int x0 = xi * NR;
+          const float *base = src + (int64_t)y * rs + x0;
+          memset(tmp, 0, sizeof(float) * (size_t)(pn1 - pn0) * MR * NR);
+          for (int k0 = 0; k0 < K; k0 += KC) {
+            const int kn = K - k0 < KC ? K - k0 : KC;
+            for (int pn = pn0; pn < pn1; ++pn)
+              micro(wp + ((size_t)pn * K + k0) * MR, base, koff + k0, kn, tmp + (size_t)(pn - pn0) * MR * NR);
+          }
+          const int nx = Wo - x0 < NR ? Wo - x0 : NR;
+          const int o1 = pn1 * MR < O ? pn1 * MR : O;
+          for (int o = pn0 * MR; o < o1; ++o) {
+            const float b = bias ? bias[o] : 0.0f;
+            float *dst = out.d + ((size_t)o * Ho + y) * Wo + x0;
+            const float *t = tmp + (size_t)(o - pn0 * MR) * NR;
+            for (int j = 0; j < nx; ++j) dst[j] = t[j] + b;
+          }
         }
       }
-    free(tmp);
   }
-  free(wp);
-  free(src);
-  free(koff);
   return out;
 }
 
 /* BatchNorm2d (eval) + ReLU, in place: y = (x-mean)/sqrt(var+eps)*gamma+beta  (model.py:46-50) */
 static void bn_relu(ten t, const float *gamma, const float *beta, const float *mean, const float *var) {
-  const size_t hw = (size_t)t.h * t.w;
-#pragma omp parallel for schedule(static)
-  for (int c = 0; c < t.c; ++c) {
-    const float invstd = 1.0f / sqrtf(var[c] + 1e-5f);
-    float *d = t.d + (size_t)c * hw;
-    for (size_t i = 0; i < hw; ++i) {
-      float v = (d[i] - mean[c]) * invstd * gamma[c] + beta[c];
-      d[i] = v > 0.0f ? v : 0.0f;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int c = 0; c < t.c; ++c)
+    for (int y = 0; y < t.h; ++y) {
+      const float invstd = 1.0f / sqrtf(var[c] + 1e-5f);
+      float *d = t.d + ((size_t)c * t.h + y) * t.w;
+      for (int i = 0; i < t.w; ++i) {
+        float v = (d[i] - mean[c]) * invstd * gamma[c] + beta[c];
+        d[i] = v > 0.0f ? v : 0.0f;
+      }
     }
-  }
 }
 
 /* ------------------------------------------------------------------ modules */
@@ -331,8 +390,10 @@ static ten conv_block(net *n, const char *name, ten x, int cout, int k, int s) {
 static ten add(net *n, const char *name, ten a, ten b) {
   ten y = new_ten(n->r, a.c, a.h, a.w);
   if (n->r->failed) return y;
-  const size_t cnt = (size_t)a.c * a.h * a.w;
-  for (size_t i = 0; i < cnt; ++i) y.d[i] = a.d[i] + b.d[i];
+  const size_t hw = (size_t)a.h * a.w;
+#pragma omp parallel for schedule(static)
+  for (int c = 0; c < a.c; ++c)
+    for (size_t i = 0; i < hw; ++i) y.d[c * hw + i] = a.d[c * hw + i] + b.d[c * hw + i];
   keep(n->r, name, y, 0);
   return y;
 }
@@ -343,10 +404,13 @@ static ten cat(net *n, const char *name, const ten *ts, int cnt) {
   ten y = new_ten(n->r, c, ts[0].h, ts[0].w);
   if (n->r->failed) return y;
   size_t off = 0;
+  const size_t hw = (size_t)ts[0].h * ts[0].w;
   for (int i = 0; i < cnt; ++i) {
-    size_t sz = (size_t)ts[i].c * ts[i].h * ts[i].w;
-    memcpy(y.d + off, ts[i].d, sz * sizeof(float));
-    off += sz;
+    float *dst = y.d + off;
+    const float *srcp = ts[i].d;
+#pragma omp parallel for schedule(static)
+    for (int ch = 0; ch < ts[i].c; ++ch) memcpy(dst + ch * hw, srcp + ch * hw, hw * sizeof(float));
+    off += (size_t)ts[i].c * hw;
   }
   keep(n->r, name, y, 0);
   return y;
@@ -436,6 +500,7 @@ static ten sppf(net *n, const char *name, ten x, int cout) {
 static ten up2(net *n, const char *name, ten x) {
   ten y = new_ten(n->r, x.c, 2 * x.h, 2 * x.w);
   if (n->r->failed) return y;
+#pragma omp parallel for schedule(static)
   for (int c = 0; c < x.c; ++c)
     for (int i = 0; i < y.h; ++i)
       for (int j = 0; j < y.w; ++j)

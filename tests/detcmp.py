@@ -16,8 +16,17 @@ def iou_matrix(a, b):
     return inter / np.maximum(aa[:, None] + ab[None, :] - inter, 1e-12)
 
 
-def compare(test, ref, conf_thr, min_iou=0.999, score_tol=1e-3, max_unmatched_frac=0.02):
-    """Returns a dict of statistics; raises AssertionError on a violation."""
+def compare(test, ref, conf_thr, min_iou=0.999, score_tol=1e-3, max_unmatched_frac=0.02, iou_thr=0.45, iou_margin=5e-3):
+    """Returns a dict of statistics; raises AssertionError on a violation.
+
+    Matched pairs must satisfy IoU >= min_iou and |score difference| < score_tol. A detection WITHOUT a partner must be
+    an evidenced borderline keep/drop decision (SURVEY.md section 8c 'Tolerances'):
+      (1) its score lies within score_tol of the confidence threshold, or
+      (2) an NMS decision that provably hinges on a near-threshold quantity: a same-class box of the OTHER set overlaps it
+          with an IoU within iou_margin of the NMS threshold `iou_thr` (the suppression flipped), or overlaps it above the
+          threshold while (a) being unmatched itself (a borderline neighbour: the chain starts at a detection that is
+          excused on its own) or (b) scoring within score_tol of it (the greedy order flipped).
+    Anything else -- e.g. a box that merely sits near some other box -- is a real divergence and fails."""
     if len(test) == 0 and len(ref) == 0:
         return {"matched": 0, "unmatched_test": 0, "unmatched_ref": 0, "min_iou": 1.0, "max_dscore": 0.0,
                 "median_dscore": 0.0, "frac_iou_ge_0.999": 1.0}
@@ -39,21 +48,29 @@ def compare(test, ref, conf_thr, min_iou=0.999, score_tol=1e-3, max_unmatched_fr
     assert (dscore < score_tol).all(), f"score drift {dscore.max():.3e} >= {score_tol}"
     un_t = np.setdiff1d(np.arange(len(test)), ti)
     un_r = np.setdiff1d(np.arange(len(ref)), rj)
-    # an unmatched detection must be a borderline keep/drop: near the confidence threshold, or involved in an NMS
-    # decision (it overlaps a same-class detection of the other set strongly enough to have been suppressed there)
-    def excused(d, other):
+
+    def excused(d, overlaps, other, other_unmatched):
+        """d: the unmatched record; overlaps: its same-class IoUs with every record of `other`"""
         if abs(float(d["confidence"]) - conf_thr) <= score_tol:
             return True
         if len(other) == 0:
             return False
-        one = np.array([d], dtype=other.dtype) if d.dtype == other.dtype else None
-        o = iou_matrix(one if one is not None else np.array([tuple(d[n] for n in other.dtype.names)], dtype=other.dtype), other)[0]
-        o = np.where(other["class_id"] == d["class_id"], o, 0.0)
-        return bool(o.max() > 0.3)
+        if (np.abs(overlaps - iou_thr) <= iou_margin).any():
+            return True
+        above = overlaps > iou_thr
+        if (above & other_unmatched).any():
+            return True
+        return bool((above & (np.abs(other["confidence"] - d["confidence"]) <= score_tol)).any())
+
+    ref_unmatched = ~used_ref
+    test_unmatched = np.ones(len(test), bool)
+    test_unmatched[ti] = False
     for i in un_t:
-        assert excused(test[i], ref), f"test detection {i} {test[i]} has no reference partner and is not borderline"
+        assert excused(test[i], m[i], ref, ref_unmatched), \
+            f"test detection {i} {test[i]} has no reference partner and no borderline decision explains it"
     for j in un_r:
-        assert excused(ref[j], test), f"reference detection {j} {ref[j]} was not reproduced and is not borderline"
+        assert excused(ref[j], m[:, j], test, test_unmatched), \
+            f"reference detection {j} {ref[j]} was not reproduced and no borderline decision explains it"
     total = max(len(ref), 1)
     assert (len(un_t) + len(un_r)) / total <= max_unmatched_frac, (len(un_t), len(un_r), total)
     ious = m[ti, rj] if len(pairs) else np.ones(1)

@@ -62,6 +62,69 @@ def test_two_rank_gloo_gather_restores_frame_order():
     assert ok
 
 
+def _ring_worker(rank, world, port, n_local, k, banks, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unina_yolo_dla_amd import gather
+    rt = gather.HostRuntime()
+    local = torch.zeros((banks, k, gather.SLOT_WORDS), dtype=torch.int32)
+    gathered = torch.zeros((banks, world, k, gather.SLOT_WORDS), dtype=torch.int32)
+    seen = {}
+
+    def on_gathered(first_local_frame, g):
+        # g: [world, k, SLOT_WORDS]; local frame j of rank r is global frame j * world + r
+        for r in range(world):
+            for s in range(k):
+                seen[(first_local_frame + s) * world + r] = gather.unpack_slot(g[r, s].numpy().copy()).tobytes()
+
+    ring = gather.SlotRing(rt, local, gathered, k, on_gathered=on_gathered)
+
+    def infer(i, stream_index, slot):
+        slot.copy_(torch.from_numpy(gather.pack_slot(_fake_dets(i * world + rank))))
+
+    streams = ["infer0", "infer1"]
+    half = (n_local // 2 // k) * k
+    gather.run_frames(half, 2, ring, infer, streams)                  # two calls: the ring continues across them
+    gather.run_frames(n_local - half, 2, ring, infer, streams, start=half)
+    ring.flush()
+    ok = len(seen) == n_local * world and all(v == _fake_dets(f).tobytes() for f, v in seen.items())
+    ok = ok and ring.gathers_issued == n_local // k
+    # who waited for what: the comm stream waits for frame events only; an inference stream waits for a collective only
+    # to reuse a bank, and then for the gather issued (banks - 1) * k frames before the frame it is about to enqueue --
+    # never for the gather of the bank just completed
+    infer_waits = [(st, tag, why) for st, tag, why in rt.log if st != "comm"]
+    comm_waits = [(st, tag, why) for st, tag, why in rt.log if st == "comm"]
+    ok = ok and all(tag[0] == "frame" and why == "gather input" for _st, tag, why in comm_waits)
+    ok = ok and len(comm_waits) == n_local
+    ok = ok and all(tag[0] == "gather" and why[0] == "bank reuse" for _st, tag, why in infer_waits)
+    ok = ok and len(infer_waits) == n_local - banks * k                # none while the ring fills for the first time
+    q.put((rank, ok, len(infer_waits), len(comm_waits)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_slot_ring_overlaps_the_gather():
+    """gather.SlotRing / run_frames (the loop bench.py runs per rank over RCCL) on two gloo ranks: 3 banks x 4 slots, 40
+    frames per rank on two 'inference streams'; every gathered slot is the right frame's, every gather was issued on the
+    comm stream behind its own bank's frames, and no inference stream waited on the collective of the bank it just
+    completed (only on bank reuse, (banks-1)*k frames later)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ring_worker, args=(r, 2, port, 40, 4, 3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _r, ok, _a, _b in res), res
+
+
 def test_slot_roundtrip_and_sharding(pkg):
     from unina_yolo_dla_amd import gather
     d = _fake_dets(3)

@@ -11,15 +11,22 @@ from detcmp import compare
 pytestmark = pytest.mark.gpu
 
 # ---- fp16 tolerances -------------------------------------------------------------------------------------
-# The fp16 engine stores folded weights and every activation in fp16 (fp32 accumulate). Each rounding adds
-# ~2e-4 relative noise; the P4 logits sit behind 45 convs = 90 roundings -> sqrt(90)*2e-4 = 1.9e-3 relative, i.e.
-# rms 3.8e-3 on logits of std 2.0 (measured: 3.85e-3). That is the FORMAT's noise, not a kernel error:
-# test_fp16_engine_matches_fp16_emulator pins the kernels to a bit-level emulation of this arithmetic far tighter.
-# North-star tolerance (IoU >= 0.999, |dscore| < 1e-3) is therefore asserted on the typical detection (median, and
-# >= 95 % of boxes), with hard bounds IoU >= 0.998 / |dscore| < 4e-3 on the worst one.
+# North star (BASELINE.json): every matched box IoU >= 0.999 and |dscore| < 1e-3 against the fp32 forward.
+# The fp32 engine (native fp32 MFMA) meets that outright on every detection (test_fp32_engine_meets_north_star_tolerance).
+# The fp16 engine CANNOT, and that is the storage format's floor, not a kernel property -- proven on the CPU by
+# tools/fp16_error_budget.py (committed run: profiles/r02/fp16_error_budget.txt): every fp16 rounding (folded weights,
+# activation stores) of every layer group contributes a few percent of the head-error variance, no group dominates,
+# and even with every layer but stem+stage1 kept in fp32 the worst of 4 711 detections still moves by 1.8e-3. With all
+# roundings on, a bit-level emulation of the arithmetic (tests/emulate.py) gives, over 10 frames / 4 711 detections:
+# max |dscore| 3.0e-3, p99 2.1e-3, min IoU 0.99858, 1.5 % of boxes below 0.999 -- the floor of ANY engine that stores
+# fp16 weights and activations for this graph. So the fp16 engine is held to:
+#   (a) the floor itself: its worst detection may not be worse than the emulation's on the same frames (+30 %)
+#       -> test_fp16_engine_tail_is_the_format_floor;
+#   (b) the north-star numbers on the typical detection: median |dscore| < 1e-3, >= 95 % of boxes at IoU >= 0.999;
+#   (c) hard bounds just above the measured floor on every detection: IoU >= 0.9983, |dscore| < 3.5e-3.
 HEAD_ATOL = 2.5e-2          # max |logit error| (cls std 2.0); measured 1.4e-2
 CLS_RMS, REG_RMS = 6e-3, 1.5e-3   # measured 3.9e-3 / 7.3e-4
-FP16_MIN_IOU, FP16_SCORE_TOL = 0.998, 4e-3
+FP16_MIN_IOU, FP16_SCORE_TOL = 0.9983, 3.5e-3
 
 
 def check_fp16_detections(got, want, conf_thr):
@@ -177,6 +184,34 @@ def test_infer_end_to_end_vs_oracle(pkg, eng640, oracle_mod, oracle_sd7, torch_c
         o = oracle_mod.forward(oracle_sd7, x)
         want, _ = oracle_mod.postprocess([o[n] for n in pkg.graph.OUTPUT_NAMES], 0.5, 0.45, q)
         check_fp16_detections(got, want, 0.5)
+
+
+def test_fp16_engine_tail_is_the_format_floor(pkg, sd7, eng640, oracle_mod, oracle_sd7, torch_cuda):
+    """The HIP engine's worst detection vs the worst detection of the bit-level fp16 emulation of the same op table
+    (torch CPU, tests/emulate.py), both against the fp32 oracle on the same four frames: the engine may not be further
+    from fp32 than the arithmetic it implements is. Together with tools/fp16_error_budget.py (which shows that no
+    subset of layers short of all of them removes the tail) this bounds the fp16 engine's miss of the north-star
+    tolerance formally: it IS the format's floor."""
+    from emulate import run_op_table
+    from unina_yolo_dla_amd import export
+    b = export.EngineBuilder(sd7)
+    worst = {"gpu": [0.0, 1.0], "emu": [0.0, 1.0]}
+    for seed in (1234, 1235, 1236, 1237):
+        x = pkg.rng.frame(seed, 640, 640)
+        o = oracle_mod.forward(oracle_sd7, x)
+        want, _ = oracle_mod.postprocess([o[n] for n in pkg.graph.OUTPUT_NAMES], 0.5, 0.45, 0.1)
+        emu, _ = run_op_table(b, x, fp16=True)
+        e_dets, _ = oracle_mod.postprocess([emu[n] for n in pkg.graph.OUTPUT_NAMES], 0.5, 0.45, 0.1)
+        g_dets = eng640.infer(torch_cuda.from_numpy(x).cuda(), 0.5, 0.45, 0.1)
+        for key, dets in (("gpu", g_dets), ("emu", e_dets)):
+            st = compare(dets, want, 0.5, min_iou=0.99, score_tol=1e-2)
+            worst[key][0] = max(worst[key][0], st["max_dscore"])
+            worst[key][1] = min(worst[key][1], st["min_iou"])
+    print("fp16 floor: engine max|ds| %.2e min IoU %.5f | emulation max|ds| %.2e min IoU %.5f" %
+          (worst["gpu"][0], worst["gpu"][1], worst["emu"][0], worst["emu"][1]))
+    assert worst["gpu"][0] <= 1.3 * worst["emu"][0] + 1e-4, worst
+    assert 1.0 - worst["gpu"][1] <= 1.3 * (1.0 - worst["emu"][1]) + 1e-4, worst
+    assert worst["emu"][0] > 1e-3                            # the emulation itself misses 1e-3: the floor is the format's
 
 
 def test_narrow_model_base_channels_16(pkg, oracle_mod, torch_cuda):

@@ -1,0 +1,89 @@
+"""The timed throughput path of bench.py, checked: several handles on separate streams, rotating result slots, no
+synchronisation between frames (unina_infer_async re-points the graph's stem / post-process nodes per frame while
+earlier launches of the same graph may still be queued); and the documented fallbacks of unina_infer's hand-off."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+def test_pipelined_frames_on_two_handles_match_serial_inference(pkg, sd7, torch_cuda, tmp_path):
+    """96 frames through 2 handles on 2 streams, 16 rotating result slots, thresholds changing every frame, no sync in
+    between: every slot must hold, byte for byte, what a serial unina_infer of that frame returns."""
+    from unina_yolo_dla_amd import export
+    from unina_yolo_dla_amd.engine import Engine, MAX_DETECTIONS
+    from unina_yolo_dla_amd import gather
+    torch = torch_cuda
+    path = str(tmp_path / "m.une")
+    export.export_engine(sd7, path)
+    engines = [Engine(path) for _ in range(2)]
+    try:
+        streams = [torch.cuda.Stream() for _ in engines]
+        frames = [torch.from_numpy(pkg.rng.frame(1234 + i, 640, 640)).cuda() for i in range(6)]
+        confs = (0.5, 0.45, 0.55, 0.6)
+        n_frames, n_slots = 96, 16
+        # serial reference, one frame at a time on handle 0
+        want = {}
+        for f in range(len(frames)):
+            for c in confs:
+                want[(f, c)] = engines[0].infer(frames[f], c, 0.45, 0.1).tobytes()
+        torch.cuda.synchronize()
+        slots = torch.zeros((n_frames // n_slots, n_slots, gather.SLOT_WORDS), dtype=torch.int32, device="cuda")
+        for i in range(n_frames):
+            k = i % 2
+            with torch.cuda.stream(streams[k]):
+                engines[k].infer_async(frames[i % len(frames)], confs[i % len(confs)], 0.45, 0.1,
+                                       out=slots[i // n_slots, i % n_slots], stream=streams[k])
+        torch.cuda.synchronize()
+        host = slots.cpu()
+        for i in range(n_frames):
+            got = Engine.unpack(host[i // n_slots, i % n_slots])
+            assert got.tobytes() == want[(i % len(frames), confs[i % len(confs)])], f"frame {i}"
+        assert MAX_DETECTIONS * 8 + 8 == gather.SLOT_WORDS
+    finally:
+        for e in engines:
+            e.close()
+
+
+@pytest.mark.parametrize("env", [{"UNINA_HOST_POLL": "0"}, {"UNINA_HOST_RESULT": "0"},
+                                 {"UNINA_HOST_POLL": "0", "UNINA_HOST_RESULT": "0"}])
+def test_host_handoff_fallbacks_are_byte_identical(env, tmp_path):
+    """unina_infer hands detections over through a pinned block + completion word; UNINA_HOST_POLL=0 (stream
+    synchronise instead of the spin) and UNINA_HOST_RESULT=0 (device buffer + D2H copy) are read once per process, so
+    each runs in a child process; the records must be the same bytes as the default path's."""
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import unina_yolo_dla_amd as u
+from unina_yolo_dla_amd.engine import Engine
+e = Engine.from_state_dict(u.synth.make_state_dict(7))
+out = []
+for seed in (1234, 1235, 1234):
+    x = torch.from_numpy(u.rng.frame(seed, 640, 640)).cuda()
+    for q in (0.1, 0.0):
+        out.append(e.infer(x, 0.5, 0.45, q).tobytes())
+e.close()
+open(sys.argv[1], "wb").write(b"".join(len(o).to_bytes(4, "little") + o for o in out))
+''' % ROOT
+    def run(extra, name):
+        out = str(tmp_path / name)
+        envp = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code, out], env=envp, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return open(out, "rb").read()
+    base = run({}, "base.bin")
+    assert len(base) > 6 * 4 + 32 * 100
+    assert run(env, "alt.bin") == base

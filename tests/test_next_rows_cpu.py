@@ -75,3 +75,35 @@ def test_preprocess_oracle_arithmetic(oracle_mod):
     out = oracle_mod.preprocess_nv12(y, uv)
     want = ((y.astype(np.float32) / np.float32(255))[None] - mean[:, None, None]) / std[:, None, None]
     np.testing.assert_array_equal(out, want)
+
+
+def test_evaluate_entry_point_on_cpu(pkg, oracle_mod, oracle_sd7, tmp_path):
+    """unina_yolo_dla_amd.evaluate.evaluate (eval.py:18-138 + train.py:299-520) end to end with the ORACLE as the
+    detector (no GPU): predictions.json schema, per-image grouping, small-object counts, conformal quantile."""
+    import json
+    from evalset import OracleDetector, make_dataset
+    from unina_yolo_dla_amd import evaluate as ev
+    size = 128
+    det = OracleDetector(oracle_mod, oracle_sd7, pkg.graph.OUTPUT_NAMES)
+    root = str(tmp_path / "ds")
+    n_labels = make_dataset(root, pkg, det, size, (1234, 1235), conf=0.3)
+    out = str(tmp_path / "run")
+    res = ev.evaluate(det, root, imgsz=size, conf=0.3, iou=0.45, conformal_q=0.0, out_dir=out, conformal_alpha=0.1)
+    recs = json.load(open(os.path.join(out, "predictions.json")))
+    assert res["images"] == 2 and len(recs) == len(res["predictions"]) > 4
+    assert set(recs[0]) == {"image_id", "category_id", "bbox", "score"} and recs[0]["image_id"] == "frame1234"   # eval.py:58-61
+    assert all(len(r["bbox"]) == 4 and r["bbox"][2] > 0 for r in recs)
+    so = res["small_object"]
+    assert so["small_object_tp"] > 0 and so["small_object_fn"] >= 2          # the jittered labels match; the planted small GTs do not
+    # same numbers through the lower-level helper (eval.py:110-131 loop)
+    dets = [det(np.load(f), 0.3, 0.45, 0.0) for f in ev.list_frames(root)]
+    labels = [ev.read_labels(ev.label_path(f)) for f in ev.list_frames(root)]
+    assert sum(len(l) for l in labels) == n_labels
+    direct = pkg.metrics.evaluate_small_objects(dets, labels, size, size)
+    assert (direct["small_object_tp"], direct["small_object_fp"], direct["small_object_fn"]) == \
+        (so["small_object_tp"], so["small_object_fp"], so["small_object_fn"])
+    c = res["conformal"]
+    assert 0.0 < c["q_hat"] < 0.5 and c["num_calibration_samples"] > 4
+    assert json.load(open(os.path.join(out, "conformal_params.json")))["q_hat"] == c["q_hat"]
+    with pytest.raises(FileNotFoundError):
+        ev.evaluate(det, str(tmp_path / "empty"))

@@ -306,6 +306,7 @@ size_t post_workspace_bytes();
 void post_bind_workspace(PostParams* p, void* ws);   // ws: post_workspace_bytes() of device memory, zeroed once
 constexpr int kPostBlock = 1024;
 int post_num_blocks(const int gw[3], const int gh[3]);
+hipError_t post_init();   // per device: raise the dynamic-LDS limit of the post-process kernels
 hipError_t postprocess_launch(const PostParams& p, hipStream_t stream);
 int postprocess_desc(const PostParams& p, LaunchDesc out[2]);   // number of launches (1 or 2), or -1 on error
 

@@ -652,7 +652,6 @@ __global__ __launch_bounds__(kTileThreads) void nms_tiles_kernel(const PostParam
   signal_done(p, tid);
 }
 
-namespace { hipError_t post_init(); }
 
 int post_num_blocks(const int gw[3], const int gh[3]) {
   const int cells = gw[0] * gh[0] + gw[1] * gh[1] + gw[2] * gh[2];
@@ -676,11 +675,6 @@ void post_bind_workspace(PostParams* p, void* ws) {
 int postprocess_desc(const PostParams& p, LaunchDesc out[2]) {
   const int nb = post_num_blocks(p.gw, p.gh);
   if (nb < 1 || nb > kPostBlock) return -1;
-  static bool attr_set = false;  // raise the dynamic-LDS limit once per process
-  if (!attr_set) {
-    if (post_init() != hipSuccess) return -1;
-    attr_set = true;
-  }
   out[0].func = reinterpret_cast<const void*>(&postprocess_kernel);
   out[0].grid = dim3(nb);
   out[0].block = dim3(kPostBlock);
@@ -774,6 +768,11 @@ __global__ __launch_bounds__(kPostBlock) void compact_valid_kernel(const GpuDete
   if (tid == 0) *num_selected = tot;
 }
 
+
+}  // namespace
+
+// hipFuncSetAttribute applies to the CURRENT device: called by unina_load_engine after hipSetDevice (one handle per GPU)
+// and by init_postprocess_resources.
 hipError_t post_init() {
   const void* fns[] = {reinterpret_cast<const void*>(postprocess_kernel), reinterpret_cast<const void*>(decode_head_append_kernel),
                        reinterpret_cast<const void*>(nms_inplace_kernel), reinterpret_cast<const void*>(compact_valid_kernel)};
@@ -784,7 +783,6 @@ hipError_t post_init() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(nms_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem2));
 }
 
-}  // namespace
 }  // namespace unina
 
 using unina::g_ws;

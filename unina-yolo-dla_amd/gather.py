@@ -55,3 +55,141 @@ def interleave(gathered) -> list:
     """[world, k, SLOT_WORDS] -> slots in global frame order (frame i was on rank i % world)."""
     world, k = gathered.shape[0], gathered.shape[1]
     return [gathered[i % world, i // world] for i in range(world * k)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The per-GPU frame loop with the gather OFF the critical path (SURVEY.md section 8e: dedicated comm stream, K frames per
+# collective, overlapped with the next frames' inference). bench.py (RCCL) and tests/test_distributed_cpu.py (gloo) run
+# the same code; only the runtime underneath differs.
+
+class CudaRuntime:
+    """Streams / events of the GPU box (torch.cuda; backend "nccl" == RCCL over xGMI)."""
+
+    def __init__(self, device):
+        import torch
+        self.torch, self.device = torch, device
+        self.comm = torch.cuda.Stream(device=device)
+
+    def record(self, stream, tag):
+        ev = self.torch.cuda.Event()
+        ev.record(stream)
+        return ev
+
+    def wait(self, stream, ev, why):
+        stream.wait_event(ev)
+
+    def all_gather(self, out, local, group, after):
+        """Issue the collective on the comm stream once `after` (events) have fired; returns its completion event."""
+        import torch.distributed as dist
+        for ev in after:
+            self.comm.wait_event(ev)
+        with self.torch.cuda.stream(self.comm):
+            dist.all_gather_into_tensor(out.view(-1), local.reshape(-1), group=group)
+            done = self.torch.cuda.Event()
+            done.record(self.comm)
+        return done
+
+    def host_sync(self, ev):
+        ev.synchronize()
+
+
+class HostRuntime:
+    """CPU stand-in (gloo): 'streams' are names, work runs where it is issued, the collective is asynchronous
+    (async_op=True) and every wait is LOGGED as (waiting stream, what it waited for) so that a test can assert which
+    stream ever waited on a collective."""
+
+    class Ev:
+        def __init__(self, tag, work=None):
+            self.tag, self.work = tag, work
+
+    def __init__(self):
+        self.comm = "comm"
+        self.log = []
+
+    def record(self, stream, tag):
+        return HostRuntime.Ev(tag)
+
+    def wait(self, stream, ev, why):
+        self.log.append((stream, ev.tag, why))
+        if ev.work is not None:
+            ev.work.wait()
+            ev.work = None
+
+    def all_gather(self, out, local, group, after):
+        import torch.distributed as dist
+        for ev in after:
+            self.wait(self.comm, ev, "gather input")
+        work = dist.all_gather_into_tensor(out.view(-1), local.reshape(-1), group=group, async_op=True)
+        return HostRuntime.Ev(("gather",), work)
+
+    def host_sync(self, ev):
+        if ev.work is not None:
+            ev.work.wait()
+            ev.work = None
+
+
+class SlotRing:
+    """`banks` x `k` detection slots per rank. Frame i is written into bank (i // k) % banks, slot i % k, by whichever
+    inference stream runs it. When the last frame of a bank has been enqueued, the bank's all-gather is issued on the
+    runtime's COMM stream behind the completion events of exactly those k frames; inference goes straight on into the
+    next bank. The only time an inference stream waits for a collective is when it is about to overwrite a slot of a
+    bank whose previous gather (issued (banks-1)*k frames earlier) has not finished: with banks >= 2 that wait is
+    normally already satisfied."""
+
+    def __init__(self, runtime, local, gathered, k, group=None, on_gathered=None):
+        """local: [banks, k, SLOT_WORDS] int32 tensor; gathered: [banks, world, k, SLOT_WORDS]."""
+        assert local.shape[0] >= 2 and local.shape[1] == k and gathered.shape[0] == local.shape[0]
+        self.rt, self.local, self.gathered, self.k, self.group = runtime, local, gathered, k, group
+        self.banks = local.shape[0]
+        self.on_gathered = on_gathered
+        self.frame_events = [[] for _ in range(self.banks)]
+        self.gather_done = [None] * self.banks
+        self.pending = [None] * self.banks          # (first frame index of the bank) awaiting consumption
+        self.gathers_issued = 0
+
+    def slot(self, i, stream):
+        """Slot tensor for frame i (rank-local index); `stream` will write it."""
+        b, s = (i // self.k) % self.banks, i % self.k
+        ev = self.gather_done[b]
+        if ev is not None:                              # the bank's previous gather still reads these slots
+            self.rt.wait(stream, ev, ("bank reuse", b))
+        return self.local[b, s]
+
+    def commit(self, i, stream):
+        """Frame i has been enqueued on `stream`. Issues the bank's gather when the bank is complete."""
+        b, s = (i // self.k) % self.banks, i % self.k
+        self.frame_events[b].append(self.rt.record(stream, ("frame", i)))
+        if s == self.k - 1:
+            self._consume(b)
+            ev = self.rt.all_gather(self.gathered[b], self.local[b], self.group, self.frame_events[b])
+            ev.tag = ("gather", b, i - self.k + 1)
+            self.gather_done[b] = ev
+            self.pending[b] = i - self.k + 1
+            self.frame_events[b] = []
+            self.gathers_issued += 1
+
+    def _consume(self, b):
+        """Hand a finished bank to the consumer (host side) before the bank is gathered into again."""
+        if self.pending[b] is not None:
+            self.rt.host_sync(self.gather_done[b])
+            if self.on_gathered is not None:
+                self.on_gathered(self.pending[b], self.gathered[b])
+            self.pending[b] = None
+
+    def flush(self):
+        """Complete every outstanding gather and hand it over (end of the stream of frames)."""
+        order = sorted((f, b) for b, f in enumerate(self.pending) if f is not None)
+        for _f, b in order:
+            self._consume(b)
+
+
+def run_frames(n_frames, n_streams, ring, infer, streams, start=0):
+    """The loop of one rank: frame i on stream i % n_streams, result into the ring, gathers overlapped.
+    infer(i, stream_index, slot_tensor) enqueues frame i (unina_infer_async on the GPU box). `start`: index of the first
+    frame (a multiple of the ring's k), so that consecutive calls continue the same ring."""
+    assert start % ring.k == 0
+    for i in range(start, start + n_frames):
+        k = i % n_streams
+        slot = ring.slot(i, streams[k])
+        infer(i, k, slot)
+        ring.commit(i, streams[k])
