@@ -107,12 +107,35 @@ class StateDict:
             pass
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually run on: the affinity mask, cut down to the cgroup CPU quota. os.cpu_count() is
+    the HOST's count: on a GPU box whose container has a 16-CPU share it says 128+, and an OpenMP team that large only
+    time-slices (round 1's "64 threads" figure was 64 threads on such a share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                quota, period = int(f.read()), int(g.read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def forward(sd: StateDict, x: np.ndarray, num_classes: int = 4, base_channels: int = 32, lite_p2: bool = False,
             keep_all: bool = False, nthreads: int = 0, variant: str = "A") -> Dict[str, np.ndarray]:
     """x: [1,3,H,W] or [3,H,W] fp32. Returns {name: [C,H,W] fp32}; the six heads are always present.
     variant "A" = model.py's graph, "B" = qat.py's (state_dict with qat.py key names)."""
     L = lib()
     x = np.ascontiguousarray(x, dtype=np.float32).reshape(3, x.shape[-2], x.shape[-1])
+    if nthreads <= 0:
+        nthreads = min(usable_cpus(), 32)
     if variant == "B":
         run = L.uo_forward_qat(sd.h, x.ctypes.data, x.shape[1], x.shape[2], num_classes, base_channels, int(keep_all), nthreads)
     else:

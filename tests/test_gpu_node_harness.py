@@ -30,7 +30,7 @@ def env(pkg, sd7, tmp_path_factory):
     return dict(torch=torch, engine=engine, exe=exe, une=path, frame=frame, fpath=fpath, geom=(sw, sh, pitch), tmp=tmp)
 
 
-def run_harness(env, mode, conf=0.3, iou=0.45, q=0.1):
+def run_harness(env, mode, conf=0.6, iou=0.45, q=0.1):
     sw, sh, pitch = env["geom"]
     out = str(env["tmp"] / f"out_{mode}.bin")
     r = subprocess.run([env["exe"], env["une"], env["fpath"], str(sw), str(sh), str(pitch), mode, out, str(conf), str(iou), str(q)],
@@ -43,7 +43,7 @@ def run_harness(env, mode, conf=0.3, iou=0.45, q=0.1):
     return recs
 
 
-def ctypes_two_step(env, conf=0.3, iou=0.45, q=0.1):
+def ctypes_two_step(env, conf=0.6, iou=0.45, q=0.1):
     """preprocess_bgra_resize + unina_infer through ctypes (Option B)."""
     torch, engine = env["torch"], env["engine"]
     sw, sh, pitch = env["geom"]
@@ -77,16 +77,20 @@ def ctypes_two_step(env, conf=0.3, iou=0.45, q=0.1):
                 assert L.run_gpu_nms(dets.data_ptr(), nd, iou, s) == 0
                 assert L.copy_valid_detections_to_host(dets.data_ptr(), host.ctypes.data, nd, C.byref(valid), s) == 0
             stepwise = host[:valid.value].copy()
+            ncand = n.value
         finally:
             L.cleanup_postprocess_resources()
-        return fused, stepwise
+        return fused, stepwise, ncand
     finally:
         e.close()
 
 
 def test_node_harness_matches_ctypes_byte_for_byte(env):
-    fused, stepwise = ctypes_two_step(env)
-    assert len(fused) > 20
+    fused, stepwise, ncand = ctypes_two_step(env)
+    # (beyond MAX_DETECTIONS candidates the two forms differ BY DESIGN: the node's 1024-record buffer makes
+    # decode_yolo_head drop later candidates in enumeration order, like the reference's `if (det_idx < MAX_DETECTIONS)`,
+    # gpu_postprocess.cu:178-197, while unina_infer keeps the 1024 highest-confidence ones)
+    assert 20 < len(fused) and ncand < 1024, (len(fused), ncand)
     a = run_harness(env, "A")
     b = run_harness(env, "B")
     c = run_harness(env, "C")
