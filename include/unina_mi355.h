@@ -183,14 +183,21 @@ int unina_debug_fusable_groups(const char *path);
 int unina_debug_read_buffer(unina_engine_t *e, const char *name, float *host_out, size_t capacity_floats,
                             int *c, int *h, int *w);
 
-/* Debug: wall_clock64 stamps (100 MHz) of the phases of the last unina_infer's post-process kernel; only written
- * when the environment has UNINA_POST_STAMPS=1. out8[0..6]: decode done, hand-off done, gather done, sort done,
- * masks done, scan done, output done. */
-int unina_debug_post_stamps(unina_engine_t *e, long long *out8);
+/* Debug: wall_clock64 stamps (100 MHz) of the phases of the last unina_infer's post-process launches; only written
+ * when the environment has UNINA_POST_STAMPS=1. out16 (16 values): [7] launch 1 starts (workgroup 0), [0] its decode is
+ * done, [1] last arriver found, [2] candidates gathered (launch 1 ends), [3] launch 2 starts, [4] its last arriver
+ * found (all pair tiles done), [8] ranks / masks loaded, [9] per-class row lists built, [5] greedy scan done, [6] output
+ * written. (The older launch forms use [0..6] as decode, hand-off, gather, sort, masks, scan, output.) */
+int unina_debug_post_stamps(unina_engine_t *e, long long *out16);
 
 /* Debug: one launch of conv op `op_index` with in-kernel s_memtime stamps of a mid-grid workgroup:
  * out5 = start, prologue issued, first operands usable, K loop done, stores drained (shader-clock ticks). */
 int unina_debug_conv_stamps(unina_engine_t *e, int op_index, long long *out5, hipStream_t stream);
+
+/* Debug: the same for the DUAL conv launch led by op `op_index` (two independent convs as one grid, e.g. the P3 | P4 head
+ * layers): out16[0..7] = stamps of conv A's mid workgroup, out16[8..15] = conv B's (each: start, loads issued, patch
+ * landed, K loop done, stores issued, 2 x 100 MHz reference). UNINA_ERR_ARG if the op does not lead such a launch. */
+int unina_debug_dual_stamps(unina_engine_t *e, int op_index, long long *out16, hipStream_t stream);
 
 /* Library/build identification: "unina_mi355 <version> gfx950". */
 const char *unina_version(void);

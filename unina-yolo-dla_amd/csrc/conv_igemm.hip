@@ -63,6 +63,14 @@ __device__ __forceinline__ void stamp(const ConvParams& p, int k) {
   }
 }
 
+// Same for a body that runs as workgroup `bid` of `nwg` inside a larger grid (dual launches): the mid workgroup of ITS conv.
+__device__ __forceinline__ void stamp_b(const ConvParams& p, int k, int bid, int nwg) {
+  if (p.stamps && bid == (nwg >> 1) && threadIdx.x == 0) {
+    p.stamps[k] = __builtin_amdgcn_s_memtime();
+    if (k == 0 || k == 4) p.stamps[5 + (k >> 2)] = wall_clock64();
+  }
+}
+
 // Element-type traits. A 1-KiB fragment block is always 16 rows x 4 chunks of 16 bytes:
 //   fp16: chunk = 8 k  -> block = 32 k, one v_mfma_f32_16x16x32_f16 per (A block, B block)
 //   fp32: chunk = 4 k  -> block = 16 k, four v_mfma_f32_16x16x4_f32 (exact fp32 products and accumulation);
@@ -700,7 +708,10 @@ __device__ __forceinline__ void stem_patch(unsigned char* smem, unsigned char* w
 
 // WN = 16-channel subtiles per wave (each activation fragment then feeds WN MFMAs: halves the LDS reads per MFMA at 2).
 // T = half_t, or signed char (INT8 engines: int8 patch image, 64-k weight blocks, v_mfma_i32_16x16x64_i8).
-template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, bool STEM = false, int WN = 1, typename T = half_t>
+// STAMPS (debug instantiations only: a branch around the loads would change the schedule of the product kernels): phase
+// stamps of the conv's mid workgroup -- 0 start, 1 patch DMA + first weight blocks issued, 2 patch landed (barrier passed),
+// 3 K loop done, 4 stores issued.
+template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, bool STEM = false, int WN = 1, typename T = half_t, bool STAMPS = false>
 __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, int nwg, const StemParams* sp = nullptr) {
   typedef Elem<T> E;
   typedef typename E::frag frag;
@@ -712,6 +723,7 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
   constexpr int NS = BN / 16 / WN, WVM = NW / NS, MS = (BM + 15) / 16, WM_T = (MS + WVM - 1) / WVM;   // NS = waves along the channels
   static_assert((BN / 16) % WN == 0 && NW % NS == 0 && WM_T >= 1 && KB * WN >= D, "tile");
 
+  if constexpr (STAMPS) stamp_b(p, 0, bid, nwg);
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wid / NS, wn = wid % NS;
@@ -752,8 +764,10 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
   }
   EpiConsts<WN> ec;
   load_epi_consts<WN>(sg, nb0 + wn * (WN * 16), lq, ec);
+  if constexpr (STAMPS) stamp_b(p, 1, bid, nwg);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
   lds_barrier();
+  if constexpr (STAMPS) stamp_b(p, 2, bid, nwg);
 
   int row0[WM_T];
 #pragma unroll
@@ -790,12 +804,14 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
       for (int i = 0; i < WM_T; ++i) acc[j][i] = E::mma(a[j], b[kb & 1][i], acc[j][i]);
   });
 
+  if constexpr (STAMPS) stamp_b(p, 3, bid, nwg);
   conv_epilogue<T, BM, BN, WM_T, WN>(p, sg, acc, ec, wm, wn, nb0, l15, lq,
                                          [&](int pl) {
                                            const int oy = ty0 + pl / TW, ox = tx0 + pl % TW;
                                            return (pl < BM && oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
                                          },
                                          conv_smem, NT);
+  if constexpr (STAMPS) stamp_b(p, 4, bid, nwg);
 }
 
 template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, int WN = 1, typename T = half_t>
@@ -835,6 +851,11 @@ __global__ __launch_bounds__(512, 4) void conv_dual_head3x3_i8(const ConvParams 
 __global__ __launch_bounds__(512) void conv_dual_head3x3_big(const ConvParams pa, const ConvParams pb, int na) {
   if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 16, 1>(pa, (int)blockIdx.x, na);
   else conv3x3_regq_body<8, 16, 64, 256, 8, 16, 1>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
+}
+// debug twin of conv_dual_head3x3_big with in-kernel phase stamps (unina_debug_dual_stamps)
+__global__ __launch_bounds__(512) void conv_dual_head3x3_big_stamped(const ConvParams pa, const ConvParams pb, int na) {
+  if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 16, 1, false, 1, half_t, true>(pa, (int)blockIdx.x, na);
+  else conv3x3_regq_body<8, 16, 64, 256, 8, 16, 1, false, 1, half_t, true>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
 }
 __global__ __launch_bounds__(512) void conv_dual_head3x3_big_i8(const ConvParams pa, const ConvParams pb, int na) {
   if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 16, 1, false, 1, signed char>(pa, (int)blockIdx.x, na);
@@ -1230,7 +1251,7 @@ constexpr int kDualKinds = 6;
 }  // namespace
 
 int conv_dual_match(const ConvParams& a, const ConvParams& b) {
-  if (a.stamps || b.stamps) return -1;
+  if (a.stamps || b.stamps) return -1;   // (stamped launches go through conv_dual_launch with an explicit kind)
   // 16x16 | 8x16 pixel tiles (one workgroup per CU): default for fp16 (39.5 vs 41.4 us per frame for the two pairs,
   // +2.5 % frames/s), opt-in for int8 (measured slower: 0.229 vs 0.2245 ms). UNINA_DUAL_BIG=0 / 1 overrides.
   const char* bigenv = getenv("UNINA_DUAL_BIG");
@@ -1263,7 +1284,12 @@ hipError_t conv_dual_launch(int kind, const ConvParams& pa_in, const ConvParams&
   const int na = (int)(ga.x * ga.y), nb = (int)(gb.x * gb.y);
   const size_t sa = smem_for(pa, kCfg[pa.dtype][k.cfg_a]), sb = smem_for(pb, kCfg[pb.dtype][k.cfg_b]);
   if (grid_out) *grid_out = na + nb;
-  hipLaunchKernelGGL(k.fn, dim3(na + nb, 1, 1), dim3(k.threads, 1, 1), max_sz(sa, sb), stream, pa, pb, na);
+  auto fn = k.fn;
+  if (pa.stamps || pb.stamps) {   // debug: the stamped twin (only the default fp16 pair has one)
+    if (kind != 4) return hipErrorInvalidValue;
+    fn = conv_dual_head3x3_big_stamped;
+  }
+  hipLaunchKernelGGL(fn, dim3(na + nb, 1, 1), dim3(k.threads, 1, 1), max_sz(sa, sb), stream, pa, pb, na);
   return hipGetLastError();
 }
 

@@ -67,7 +67,7 @@ struct DeviceResult {  // what the fused post-process writes; one D2H brings cou
   unsigned int seq;    // host block only: the sequence number the post-process stores last (unina_infer's completion word)
   int pad[5];
   GpuDetection det[MAX_DETECTIONS];
-  long long pad_stamps[8];  // debug phase stamps of the post-process kernel (UNINA_POST_STAMPS=1)
+  long long pad_stamps[16]; // debug phase stamps of the post-process kernel (UNINA_POST_STAMPS=1) / of a conv or a dual conv launch
 };
 
 }  // namespace
@@ -117,6 +117,9 @@ struct unina_engine {
   hipGraphExec_t fexec = nullptr;
   hipGraphNode_t stem_node = nullptr, post_node = nullptr, post_node2 = nullptr;
   bool post_split = true;            // post-process as two launches (UNINA_POST_SPLIT=0: everything in one workgroup)
+  int post_mode = 2;                 // 2: sort-free two-launch form (default); 1: two launches with the bitonic sort (UNINA_POST_V1=1); 0: one launch
+  bool fold_heads = true;            // full-frame graph: the heads' output convs run inside the decode launch (UNINA_POST_FOLD=0: off)
+  int fold_op[3] = {-1, -1, -1};     // per head: the output-conv op the decode launch absorbs (-1: the head is read from its planes)
   int stem_op = -1;
   StemParams f_stem;
   PostParams f_post;
@@ -246,6 +249,29 @@ void op_regions(const unina_engine* e, size_t i, std::vector<Region>* reads, std
 // (Re)computes kernel parameters from the current buffer addresses. Element types are properties of the BUFFERS
 // (fp16 / fp32 / int8 NHWC): a conv runs in the type of its source buffer and converts to the type of each
 // destination buffer in its epilogue, so fp16, fp32 and mixed int8/fp16 engines share one planner.
+// Which heads' output convs (model.py:292,299: Conv2d(C, nc | 4, 1) with bias, the `.2` layers) can run inside the decode
+// launch of the post-process (postprocess.hip, fold): a plain fp16 1x1 conv op of two slices that write the head's cls
+// and reg planes, at most 16 output channels each. A head whose output conv already lives in a fused launch (the P2
+// head kernel) is read from its planes instead.
+void find_fold_ops(unina_engine* e) {
+  for (int h = 0; h < 3; ++h) e->fold_op[h] = -1;
+  if (!e->fold_heads || e->post_mode != 2) return;
+  for (size_t i = 0; i < e->ops.size(); ++i) {
+    const PlannedOp& op = e->ops[i];
+    if (op.d.kind != kOpConv || (e->fuse && op.fuse_role)) continue;
+    const ConvParams& c = op.cp;
+    if (c.dtype != kF16 || c.ksize != 1 || c.stride != 1 || c.relu || c.res || c.nseg != 2 || (c.Cin & 31)) continue;
+    for (int h = 0; h < 3; ++h) {
+      const void* pc = e->bufs[e->out_buf[2 * h]].ptr;
+      const void* pr = e->bufs[e->out_buf[2 * h + 1]].ptr;
+      if (!pc || !pr || c.seg[0].dst_planar != pc || c.seg[1].dst_planar != pr) continue;
+      if (c.seg[0].n_count > 16 || c.seg[1].n_count > 16 || c.seg[0].mult || c.seg[1].mult) continue;
+      if (c.M != (int)(e->bufs[e->out_buf[2 * h]].d.w * e->bufs[e->out_buf[2 * h]].d.h)) continue;
+      e->fold_op[h] = (int)i;
+    }
+  }
+}
+
 int plan(unina_engine* e) {
   const char* blob = static_cast<const char*>(e->d_blob);
   for (size_t i = 0; i < e->ops.size(); ++i) {
@@ -681,6 +707,7 @@ int plan(unina_engine* e) {
       }
     }
   }
+  find_fold_ops(e);
   e->plan_dirty = false;
   drop_graph(e);
   return UNINA_OK;
@@ -1171,6 +1198,16 @@ int capture_full(unina_engine* e, const PostParams& pp) {
   hipError_t err = hipSuccess;
   int rc = UNINA_OK;
   for (size_t j = 0; j < e->ops.size() && err == hipSuccess; ++j) {
+    if (pp.mode == 2) {   // the heads' output convs that the decode launch computes itself are left out of the graph
+      auto used = [&](int k) {
+        for (int h = 0; h < 3; ++h)
+          if (e->fold_op[h] == k && pp.h1[h] != nullptr) return true;
+        return false;
+      };
+      const PlannedOp& oj = e->ops[j];
+      const bool dual_leader = oj.dual_with >= 0 && !(e->fuse && oj.fuse_role);
+      if (used((int)j) && (!dual_leader || used(oj.dual_with))) continue;
+    }
     err = launch_op(e, j, st);
     if (err != hipSuccess) {
       rc = fail(e, UNINA_ERR_HIP, "op %zu (%s): %s", j, e->ops[j].d.name, hipGetErrorString(err));
@@ -1340,7 +1377,7 @@ float half_bits_to_float(uint16_t h) {
 }
 
 int fill_post_params(unina_engine* e, PostParams* pp, float conf, float iou, float q, GpuDetection* d_out, int* d_count,
-                     int* d_cand_count) {
+                     int* d_cand_count, bool fold = false) {
   memset(pp, 0, sizeof *pp);
   for (int i = 0; i < 3; ++i) {
     const Buffer& c = e->bufs[e->out_buf[2 * i]];
@@ -1358,7 +1395,27 @@ int fill_post_params(unina_engine* e, PostParams* pp, float conf, float iou, flo
   pp->cand = e->d_cand;
   pp->block_count = e->d_block_count;
   pp->ticket = e->d_ticket;
-  if (e->post_split) post_bind_workspace(pp, e->d_post_ws);
+  pp->mode = e->post_split ? e->post_mode : 0;
+  if (pp->mode) post_bind_workspace(pp, e->d_post_ws);
+  if (pp->mode == 2) {
+    for (int h = 0; h < 3 && fold; ++h) {
+      if (e->fold_op[h] < 0) continue;
+      const ConvParams& c = e->ops[e->fold_op[h]].cp;
+      pp->h1[h] = c.src;
+      pp->h1_ld[h] = c.src_ld;
+      pp->h1_c[h] = c.Cin;
+      for (int k = 0; k < 2; ++k) {
+        pp->h1_coff[h][k] = c.seg[k].src_coff;
+        pp->w2[h][k] = static_cast<const unsigned char*>(c.seg[k].w);
+        pp->b2[h][k] = c.seg[k].bias;
+      }
+    }
+    if (!post_plan_blocks(pp)) {     // does not fit the block table: everything in one launch
+      pp->mode = 0;
+      pp->ws_box = nullptr;
+      for (int h = 0; h < 3; ++h) pp->h1[h] = nullptr;
+    }
+  }
   pp->out = d_out;
   pp->out_count = d_count;
   pp->out_candidates = d_cand_count;
@@ -1504,8 +1561,11 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   }
   e->post_blocks = post_num_blocks(gw, gh);
   if (e->post_blocks > kPostBlock) return bail(UNINA_ERR_UNSUPPORTED, "input too large for the post-process workspace");
-  LOADCHK(hipMalloc(&e->d_cand, sizeof(GpuDetection) * (size_t)e->post_blocks * kPostBlock));
-  LOADCHK(hipMalloc(&e->d_block_count, sizeof(int) * (size_t)e->post_blocks));
+  {  // candidate segments: post_blocks x 1024 records (modes 0 / 1) or up to 1024 workgroups x 256 (mode 2)
+    const size_t recs = (size_t)e->post_blocks * kPostBlock > (size_t)1024 * kPost2Block ? (size_t)e->post_blocks * kPostBlock : (size_t)1024 * kPost2Block;
+    LOADCHK(hipMalloc(&e->d_cand, sizeof(GpuDetection) * recs));
+    LOADCHK(hipMalloc(&e->d_block_count, sizeof(int) * (size_t)(e->post_blocks > 1024 ? e->post_blocks : 1024)));
+  }
   LOADCHK(hipMalloc(&e->d_ticket, sizeof(unsigned int)));
   LOADCHK(hipMemset(e->d_ticket, 0, sizeof(unsigned int)));
   LOADCHK(hipMalloc(&e->d_post_ws, post_workspace_bytes()));
@@ -1526,6 +1586,8 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   if (const char* ns = getenv("UNINA_STREAMS")) e->n_streams = atoi(ns) > 0 ? atoi(ns) : 1;
   if (const char* fg = getenv("UNINA_FULL_GRAPH")) e->full_graph = fg[0] != '0';
   if (const char* ps = getenv("UNINA_POST_SPLIT")) e->post_split = ps[0] != '0';
+  if (const char* pv = getenv("UNINA_POST_V1")) e->post_mode = pv[0] == '1' ? 1 : 2;
+  if (const char* pf = getenv("UNINA_POST_FOLD")) e->fold_heads = pf[0] != '0';
   e->plan_dirty = true;
   *out = e;
   return UNINA_OK;
@@ -1626,7 +1688,7 @@ int unina_infer_async(unina_engine_t* e, const float* d_images, float conf, floa
       if (rc != UNINA_OK) return rc;
     }
     PostParams pp;
-    fill_post_params(e, &pp, conf, iou, q, d_out, d_out_count, &e->d_result->candidates);
+    fill_post_params(e, &pp, conf, iou, q, d_out, d_out_count, &e->d_result->candidates, /*fold=*/true);
     return launch_full(e, pp, stream);
   }
   int rc = unina_enqueue(e, stream);
@@ -1729,7 +1791,7 @@ int unina_debug_post_stamps(unina_engine_t* e, long long* out8) {
   if (!e || !out8) return UNINA_ERR_ARG;
   HIPCHK(e, hipSetDevice(e->device));
   HIPCHK(e, hipDeviceSynchronize());
-  HIPCHK(e, hipMemcpy(out8, e->d_result->pad_stamps, sizeof(long long) * 8, hipMemcpyDeviceToHost));
+  HIPCHK(e, hipMemcpy(out8, e->d_result->pad_stamps, sizeof(long long) * 16, hipMemcpyDeviceToHost));
   return UNINA_OK;
 }
 
@@ -1750,6 +1812,28 @@ int unina_debug_conv_stamps(unina_engine_t* e, int op_index, long long* out5, hi
   HIPCHK(e, conv_launch(p, e->ops[op_index].cl, stream));
   HIPCHK(e, hipStreamSynchronize(stream));
   HIPCHK(e, hipMemcpy(out5, p.stamps, sizeof(long long) * 8, hipMemcpyDeviceToHost));  // 5 shader-clock stamps + 2 at 100 MHz + entry
+  return UNINA_OK;
+}
+
+// One launch of the DUAL conv launch led by op `op_index` (fusion on: e.g. the P3 | P4 head layers) with in-kernel stamps of
+// the mid workgroup of each of its two convs: out16[0..7] conv A, out16[8..15] conv B, each as unina_debug_conv_stamps.
+int unina_debug_dual_stamps(unina_engine_t* e, int op_index, long long* out16, hipStream_t stream) {
+  if (!e || !out16 || op_index < 0 || op_index >= (int)e->ops.size()) return UNINA_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (e->plan_dirty) {
+    int rc = plan(e);
+    if (rc != UNINA_OK) return rc;
+  }
+  const PlannedOp& op = e->ops[op_index];
+  if (op.d.kind != kOpConv || op.fuse_role || op.dual_with < 0 || op.dual_absorbed)
+    return fail(e, UNINA_ERR_ARG, "op %d does not lead a dual conv launch", op_index);
+  ConvParams pa = op.cp, pb = e->ops[op.dual_with].cp;
+  pa.stamps = reinterpret_cast<long long*>(e->d_result->pad_stamps);
+  pb.stamps = pa.stamps + 8;
+  HIPCHK(e, hipMemsetAsync(pa.stamps, 0, sizeof(long long) * 16, stream));
+  HIPCHK(e, conv_dual_launch(op.dual_kind, pa, pb, stream));
+  HIPCHK(e, hipStreamSynchronize(stream));
+  HIPCHK(e, hipMemcpy(out16, pa.stamps, sizeof(long long) * 16, hipMemcpyDeviceToHost));
   return UNINA_OK;
 }
 

@@ -301,10 +301,31 @@ struct PostParams {
   unsigned long long* ws_mask;    // upper-triangular 64x64-bit suppression tiles
   unsigned long long* ws_tilenz;  // per tile: rows with a non-empty mask
   unsigned int* ticket2;     // arrival counter of launch 2 (zero at rest)
+  // ---- sort-free form (mode 2, the default; postprocess.hip "v2"): launch 1 = decode on many 256-thread workgroups, the
+  // last arriver gathers the candidates in ENUMERATION order; launch 2 = one workgroup per 64x64 tile of the candidate
+  // pairs computes the directional suppression bits (both directions) AND every candidate's rank (number of candidates
+  // with a larger (confidence, ~position) key: a stable sort order without sorting), its last arriver runs the greedy scan
+  // in rank order (one wave per class residue) and writes the compacted output. Same results as the other forms.
+  int mode;                  // 0: one launch; 1: two launches with a bitonic sort (v1); 2: sort-free (v2)
+  int* ws_rank;              // [MAX_DETECTIONS] rank of each candidate (zeroed by launch 1)
+  unsigned long long* ws_full;    // [MAX_DETECTIONS][16] suppression bits, row = suppressor, bit = suppressed (enumeration positions)
+  unsigned long long* ws_rownz;   // [16] rows with a non-empty mask (zeroed by launch 1)
+  // fold: the head's output convs (model.py:292,299: Conv2d 1x1 + bias on the hidden tensor) computed INSIDE launch 1 with
+  // the same MFMA / K order / bias add as the conv kernels (bit-identical logits), straight into the decode -- the fp32
+  // planes of such a head are neither written nor read. h1[h] == nullptr: head h is read from its planes cls[h] / reg[h].
+  const void* h1[3];         // hidden tensor of head h: fp16 NHWC
+  int h1_ld[3], h1_c[3];     // channels per pixel of that buffer; input channels of each output conv (multiple of 32)
+  int h1_coff[3][2];         // channel offset of the cls / reg branch's input
+  const unsigned char* w2[3][2];  // packed 1-KiB fragment blocks [1][C/32] (16 rows) of the cls / reg output conv
+  const float* b2[3][2];     // [16] biases
+  int bstart[4];             // launch 1 of mode 2: first workgroup of each head, total (post_plan_blocks)
+  int cpb[3];                // cells per workgroup of each head: 256 (planes, or 4 pixel subtiles per wave) or 64 (1 per wave)
 };
 size_t post_workspace_bytes();
 void post_bind_workspace(PostParams* p, void* ws);   // ws: post_workspace_bytes() of device memory, zeroed once
+bool post_plan_blocks(PostParams* p);                // mode 2: fills bstart / cpb from gw, gh, h1; false if the grid would exceed 1024 workgroups
 constexpr int kPostBlock = 1024;
+constexpr int kPost2Block = 256;                     // threads per workgroup of the mode-2 kernels (= candidate segment size)
 int post_num_blocks(const int gw[3], const int gh[3]);
 hipError_t post_init();   // per device: raise the dynamic-LDS limit of the post-process kernels
 hipError_t postprocess_launch(const PostParams& p, hipStream_t stream);

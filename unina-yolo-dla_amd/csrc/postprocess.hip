@@ -27,6 +27,7 @@
 // with wave ballots.
 // Built with -ffp-contract=off: the box arithmetic must round exactly like the reference's scalar code.
 #include "kernels.h"
+#include "mfma_common.h"
 
 #pragma clang fp contract(off)
 
@@ -77,15 +78,15 @@ __device__ __forceinline__ int block_rank(bool flag, Smem& s, int* total) {
   return off + rank;
 }
 
-// one cell of one head -> (pass, record)
-__device__ __forceinline__ bool decode_cell(const float* __restrict__ cls, const float* __restrict__ reg, int gw, int gh,
-                                            int stride, int num_classes, float conf_thr, float q, int idx,
-                                            GpuDetection* d) {
-  const int hw = gw * gh;
+// one cell of one head -> (pass, record). cls_at(c) / reg_at(k) deliver the cell's raw head values (from the fp32 planes,
+// or from the registers / LDS of the launch that has just computed them): ONE arithmetic sequence for every form.
+template <typename FC, typename FR>
+__device__ __forceinline__ bool decode_core(FC cls_at, FR reg_at, int gw, int stride, int num_classes, float conf_thr, float q,
+                                            int idx, GpuDetection* d) {
   float max_conf = 0.0f;
   int best = -1;
   for (int c = 0; c < num_classes; ++c) {
-    const float conf = sigmoidf(cls[(size_t)c * hw + idx]);
+    const float conf = sigmoidf(cls_at(c));
     if (conf > max_conf) {
       max_conf = conf;
       best = c;
@@ -95,8 +96,8 @@ __device__ __forceinline__ bool decode_cell(const float* __restrict__ cls, const
   const int y = idx / gw, x = idx - y * gw;
   const float fs = (float)stride;
   const float xc = ((float)x + 0.5f) * fs, yc = ((float)y + 0.5f) * fs;
-  const float l = reg[idx] * fs, t = reg[(size_t)hw + idx] * fs;
-  const float r = reg[(size_t)2 * hw + idx] * fs, b = reg[(size_t)3 * hw + idx] * fs;
+  const float l = reg_at(0) * fs, t = reg_at(1) * fs;
+  const float r = reg_at(2) * fs, b = reg_at(3) * fs;
   d->x1 = xc - l;
   d->y1 = yc - t;
   d->x2 = xc + r;
@@ -116,16 +117,24 @@ __device__ __forceinline__ bool decode_cell(const float* __restrict__ cls, const
   return true;
 }
 
+__device__ __forceinline__ bool decode_cell(const float* __restrict__ cls, const float* __restrict__ reg, int gw, int gh,
+                                            int stride, int num_classes, float conf_thr, float q, int idx,
+                                            GpuDetection* d) {
+  const int hw = gw * gh;
+  return decode_core([&](int c) { return cls[(size_t)c * hw + idx]; }, [&](int k) { return reg[(size_t)k * hw + idx]; }, gw,
+                     stride, num_classes, conf_thr, q, idx, d);
+}
+
 // Publishes this block's global stores and draws an arrival ticket; returns true in exactly one block (the last
 // to arrive), with every other block's stores visible to it (agent-scope release / acquire).
-__device__ __forceinline__ bool arrive_and_check_last(unsigned int* ticket, int* is_last /*LDS*/) {
+__device__ __forceinline__ bool arrive_and_check_last(unsigned int* ticket, int* is_last /*LDS*/, int arrivals = 0 /*0: the whole grid*/) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *is_last = (t == gridDim.x - 1) ? 1 : 0;
+    *is_last = (t == (arrivals ? (unsigned)arrivals : gridDim.x) - 1u) ? 1 : 0;
   }
   __syncthreads();
   if (!*is_last) return false;
@@ -653,13 +662,531 @@ __global__ __launch_bounds__(kTileThreads) void nms_tiles_kernel(const PostParam
 }
 
 
+// ================================================================================================ v2: sort-free, folded
+// Launch 1 (post_decode_kernel, 256-thread workgroups, a few hundred of them): every workgroup owns a run of consecutive
+// cells of ONE head. A head is read from its fp32 planes, or -- fold -- its output convs are computed here: wave = 16-pixel
+// subtile, B fragments (16 bytes of the NHWC hidden tensor per lane) and A fragments (the exporter's packed 1-KiB blocks)
+// straight from global memory into v_mfma_f32_16x16x32_f16, k blocks in ascending order from a zero accumulator, `acc + bias`
+// in fp32: the operations, operands and order of conv_glds / conv_epilogue, so the logits are the per-op table's bit for
+// bit; they go through LDS to the thread that decodes the cell. Survivors are appended, in order, to the workgroup's
+// segment, the count to a table -- and that is all: no ticket, no gather, no sort (the one-workgroup gather + bitonic
+// sort behind an arrival ticket were 9 of the older form's 31 us).
+// Launch 2 (post_nms_kernel, 512 threads): one workgroup per 64x64 tile of candidate pairs (I <= J). Each scans the count
+// table for itself (the enumeration order P2 -> P3 -> P4, row-major, is the order of the segments), fetches its 64 rows and
+// 64 columns by binary search (top-1024 by radix select when more cells passed), and besides the overlap test compares
+// the (confidence, ~position) keys of every pair, so a tile contributes (a) the DIRECTIONAL suppression bits of both
+// orientations -- rows of tile (I,J) per lane, rows of tile (J,I) as wave ballots -- into a full n x n bit matrix
+// indexed by enumeration position, and (b) to every candidate's RANK = number of candidates with a larger key,
+// accumulated with integer atomics: the stable sort order falls out of the pair loop that the NMS needs anyway.
+// The last arriver (one ticket per TILE, not per grid slot) inverts the ranks into a permutation, and because a row only
+// ever marks candidates of strictly lower confidence (= processed later) and of its own class, the greedy scan splits by
+// class: wave v walks the candidates of class = v (mod 4) in rank order, skipping rows that mark nothing, 16 rows'
+// masks fetched at a time. Output = unmarked candidates in rank order, every thread scattering its own two records.
+// Measured inside a frame at ~490 candidates (profiles/r02): 20 us from the start of launch 1 to the completion word,
+// against 31 us for the sorted two-launch form plus 8 us for the conv launch of the P3 | P4 output convs it absorbed.
+namespace {
+
+constexpr int kT2 = kPost2Block;
+constexpr int kW2 = kT2 / 64;
+
+struct SmemD {                     // launch 1
+  float stage[32][kT2];            // fold: [output channel: 0..15 cls, 16..31 reg][cell of the workgroup]
+  int scan[1024 + 8];
+  int wave_cnt[kW2];
+  int hist[256];
+  int is_last;
+  int misc[4];
+};
+
+constexpr int kTN = 512;             // threads per workgroup of launch 2
+constexpr int kWN = kTN / 64;        // 8 waves: a 64 x 64 pair tile = 64 rows (lanes) x 8 columns per wave
+constexpr int kColsPerWave = 64 / kWN;
+struct SmemN {                     // launch 2
+  float4 rbox[64], cbox[64];
+  float2 rcc[64], ccc[64];
+  unsigned char piece[64][kWN];
+  unsigned char rcnt[64][kWN];
+  unsigned long long mask[kMaxDet * kWords];   // last workgroup: row i, word w at [i * nw + w]
+  unsigned short perm[kMaxDet];
+  unsigned char cls4[kMaxDet];
+  unsigned short list[4][kMaxDet];
+  unsigned long long removed[4][kWords];
+  unsigned long long rownz[kWords];
+  int scan[1024 + 8];                // exclusive prefix of launch 1's per-workgroup candidate counts
+  int hist[256];
+  int misc[4];
+  int wave_cnt[kWN];
+  int is_last;
+};
+
+// block_rank for the kTN-thread workgroups of launch 2
+__device__ __forceinline__ int block_rank_n(bool flag, int* wave_cnt /*LDS, kWN*/, int* total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const unsigned long long b = __ballot(flag);
+  const int rank = __popcll(b & ((1ull << lane) - 1ull));
+  __syncthreads();
+  if (lane == 0) wave_cnt[wid] = __popcll(b);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kWN; ++w) {
+    const int c = wave_cnt[w];
+    if (w < wid) off += c;
+    tot += c;
+  }
+  *total = tot;
+  return off + rank;
+}
+
+// block_rank for a 256-thread workgroup
+__device__ __forceinline__ int block_rank2(bool flag, int* wave_cnt /*LDS, kW2*/, int* total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const unsigned long long b = __ballot(flag);
+  const int rank = __popcll(b & ((1ull << lane) - 1ull));
+  __syncthreads();
+  if (lane == 0) wave_cnt[wid] = __popcll(b);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kW2; ++w) {
+    const int c = wave_cnt[w];
+    if (w < wid) off += c;
+    tot += c;
+  }
+  *total = tot;
+  return off + rank;
+}
+
+__device__ __forceinline__ int scan_block_counts2(const int* block_count, int nblocks, int* scan /*LDS, nblocks + 1*/) {
+  const int tid = threadIdx.x;
+  // every count in ONE round trip (a serial walk over 64-entry chunks paid an L2 latency per chunk), then a scan in LDS
+  int v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = tid + q * kT2;
+    v[q] = i < nblocks ? __hip_atomic_load(block_count + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = tid + q * kT2;
+    if (i < nblocks) scan[i] = v[q];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    int carry = 0;
+    for (int base = 0; base < nblocks; base += 64) {
+      const int i = base + tid;
+      const int c = i < nblocks ? scan[i] : 0;
+      int incl = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (tid >= off) incl += t;
+      }
+      if (i < nblocks) scan[i] = carry + incl - c;
+      carry += __shfl(incl, 63);
+    }
+    if (tid == 0) scan[nblocks] = carry;
+  }
+  __syncthreads();
+  return scan[nblocks];
+}
+
+__device__ __forceinline__ const GpuDetection* cand_at2(const GpuDetection* cand, const int* scan, int nblocks, int e) {
+  int lo = 0, hi = nblocks - 1;  // largest b with scan[b] <= e
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (scan[mid] <= e) lo = mid; else hi = mid - 1;
+  }
+  return cand + (size_t)lo * kT2 + (e - scan[lo]);
+}
+
+__device__ __forceinline__ void put_ws(const PostParams& p, int pos, const GpuDetection* c) {
+  p.ws_box[pos] = make_float4(c->x1, c->y1, c->x2, c->y2);
+  p.ws_cc[pos] = make_float2(c->confidence, __int_as_float(c->class_id));
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kPost2Block) void post_decode_kernel(const PostParams p) {
+  SmemD& s = *reinterpret_cast<SmemD*>(post_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.x;
+  const int h = b < p.bstart[1] ? 0 : (b < p.bstart[2] ? 1 : 2);
+  const int cpb = p.cpb[h];
+  const int cell0 = (b - p.bstart[h]) * cpb;
+  const int gw = p.gw[h], ncell = gw * p.gh[h];
+  const int idx = cell0 + tid;
+  if (p.stamps && tid == 0 && b == 0) p.stamps[7] = wall_clock64();
+  bool pass = false;
+  GpuDetection d;
+  if (p.h1[h] == nullptr) {
+    if (idx < ncell) pass = decode_cell(p.cls[h], p.reg[h], gw, p.gh[h], p.stride[h], p.num_classes, p.conf_thr, p.conformal_q, idx, &d);
+  } else {
+    // ---- fold: the two output convs of the head on this workgroup's pixels (see the header comment) ----
+    const int nsub = cpb >> 6;                       // pixel subtiles per wave: 1 or 4
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int kblocks = p.h1_c[h] >> 5, ld = p.h1_ld[h];
+    const _Float16* h1 = static_cast<const _Float16*>(p.h1[h]);
+    const int slot = (4 * l15 + (lq ^ dev::swz_g(l15))) * 16;   // this lane's 16 bytes of any packed weight block
+    for (int si = 0; si < nsub; ++si) {
+      const int sub = wv * nsub + si;
+      int pix = cell0 + sub * 16 + l15;
+      pix = pix < ncell ? pix : ncell - 1;           // tail subtiles: any valid pixel (never decoded)
+      const _Float16* x0 = h1 + (size_t)pix * ld + 8 * lq;
+      dev::floatx4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      // every operand of up to 8 k blocks of BOTH branches is requested before the first MFMA waits for one: the hidden
+      // tensor was written a launch ago by other CUs, each load is a trip to another XCD's side of the chip
+      for (int kb0 = 0; kb0 < kblocks; kb0 += 8) {
+        dev::half8 av[2][8], bv[2][8];
+#pragma unroll
+        for (int br = 0; br < 2; ++br)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int kb = kb0 + k < kblocks ? kb0 + k : kblocks - 1;   // (past the end: a repeat, not used)
+            av[br][k] = *reinterpret_cast<const dev::half8*>(p.w2[h][br] + slot + (size_t)kb * 1024);
+            bv[br][k] = *reinterpret_cast<const dev::half8*>(x0 + p.h1_coff[h][br] + kb * 32);
+          }
+#pragma unroll
+        for (int br = 0; br < 2; ++br)
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (kb0 + k < kblocks) acc[br] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[br][k], bv[br][k], acc[br], 0, 0, 0);
+      }
+#pragma unroll
+      for (int br = 0; br < 2; ++br) {
+        const dev::floatx4 bias = *reinterpret_cast<const dev::floatx4*>(p.b2[h][br] + 4 * lq);
+        const dev::floatx4 v = acc[br] + bias;       // conv_epilogue: v = acc + bias, no activation (model.py:292,299)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.stage[br * 16 + 4 * lq + r][sub * 16 + l15] = v[r];
+      }
+    }
+    __syncthreads();
+    if (tid < cpb && idx < ncell)
+      pass = decode_core([&](int c) { return s.stage[c][tid]; }, [&](int k) { return s.stage[16 + k][tid]; }, gw, p.stride[h],
+                         p.num_classes, p.conf_thr, p.conformal_q, idx, &d);
+  }
+  {
+    int total;
+    const int pos = block_rank2(pass, s.wave_cnt, &total);
+    if (pass) p.cand[(size_t)b * kT2 + pos] = d;
+    if (tid == 0) p.block_count[b] = total;
+  }
+  if (p.stamps && tid == 0 && b == 0) p.stamps[0] = wall_clock64();
+}
+
+__global__ __launch_bounds__(kTN) void post_nms_kernel(const PostParams p) {
+  SmemN& s = *reinterpret_cast<SmemN*>(post_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int t = blockIdx.x;
+  if (p.stamps && tid == 0 && t == 0) p.stamps[3] = wall_clock64();
+  // every workgroup works out the candidate list for itself: exclusive scan of launch 1's per-workgroup counts
+  const int nblocks = p.bstart[3];
+  const int total = scan_block_counts2(p.block_count, nblocks, s.scan);
+  if (p.stamps && tid == 0 && t == 0) p.stamps[1] = wall_clock64();
+  const int n = total < kMaxDet ? total : kMaxDet;
+  const int nw = (n + 63) >> 6;
+  const int ntiles = nw * (nw + 1) / 2;
+  if (t >= (ntiles > 0 ? ntiles : 1)) return;   // (the grid is sized for 1024 candidates; with none, workgroup 0 writes the empty result)
+  if (ntiles > 0) {
+    int c = 0, rem = t;  // tile t -> (row chunk c, column chunk w >= c)
+    while (rem >= nw - c) {
+      rem -= nw - c;
+      ++c;
+    }
+    const int w = c + rem;
+    if (tid < 128) {   // rows 64c.. (tid < 64), columns 64w.. : dummies (class -1, empty box) past the end
+      const int k = tid & 63;
+      if (tid < 64) {
+        s.rbox[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s.rcc[k] = make_float2(0.f, __int_as_float(-1));
+      } else {
+        s.cbox[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s.ccc[k] = make_float2(0.f, __int_as_float(-1));
+      }
+    }
+    if (total <= kMaxDet) {
+      if (tid < 128) {
+        const int k = tid & 63, e = (tid < 64 ? c : w) * 64 + k;
+        if (e < n) {
+          const GpuDetection* cd = cand_at2(p.cand, s.scan, nblocks, e);
+          const float4 bx = make_float4(cd->x1, cd->y1, cd->x2, cd->y2);
+          const float2 cf = make_float2(cd->confidence, __int_as_float(cd->class_id));
+          if (tid < 64) { s.rbox[k] = bx; s.rcc[k] = cf; } else { s.cbox[k] = bx; s.ccc[k] = cf; }
+        }
+      }
+    } else {
+      // overflow: the kMaxDet largest confidences, ties by enumeration order, kept in enumeration order (radix select on
+      // the bit patterns: confidences are positive floats, so the patterns order like the values). Every workgroup runs
+      // the selection for itself and keeps the selected candidates that fall into its rows / columns.
+      unsigned int prefix = 0, pmask = 0;
+      int want = kMaxDet;
+      for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) s.hist[tid] = 0;
+        __syncthreads();
+        for (int e = tid; e < total; e += kTN) {
+          const unsigned int key = __float_as_uint(cand_at2(p.cand, s.scan, nblocks, e)->confidence);
+          if ((key & pmask) == prefix) atomicAdd(&s.hist[(key >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          int acc = 0, bb = 255;
+          for (; bb > 0; --bb) {
+            if (acc + s.hist[bb] >= want) break;
+            acc += s.hist[bb];
+          }
+          s.misc[0] = bb;
+          s.misc[1] = want - acc;
+        }
+        __syncthreads();
+        prefix |= (unsigned int)s.misc[0] << shift;
+        pmask |= 255u << shift;
+        want = s.misc[1];
+        __syncthreads();
+      }
+      const unsigned int T = prefix;  // bits of the kMaxDet-th largest confidence; take `want` of its ties
+      int base_sel = 0, base_eq = 0;
+      for (int e0 = 0; e0 < total; e0 += kTN) {
+        const int e = e0 + tid;
+        const GpuDetection* cd = e < total ? cand_at2(p.cand, s.scan, nblocks, e) : nullptr;
+        const unsigned int key = cd ? __float_as_uint(cd->confidence) : 0u;
+        const bool eq = cd && key == T;
+        int tot_eq, tot_sel;
+        const int rank_eq = block_rank_n(eq, s.wave_cnt, &tot_eq);
+        const bool sel = cd && (key > T || (eq && base_eq + rank_eq < want));
+        const int pos = base_sel + block_rank_n(sel, s.wave_cnt, &tot_sel);
+        if (sel) {
+          const float4 bx = make_float4(cd->x1, cd->y1, cd->x2, cd->y2);
+          const float2 cf = make_float2(cd->confidence, __int_as_float(cd->class_id));
+          if ((pos >> 6) == c) { s.rbox[pos & 63] = bx; s.rcc[pos & 63] = cf; }
+          if ((pos >> 6) == w) { s.cbox[pos & 63] = bx; s.ccc[pos & 63] = cf; }
+        }
+        base_sel += tot_sel;
+        base_eq += tot_eq;
+      }
+    }
+    __syncthreads();
+    if (p.stamps && tid == 0 && t == 0) p.stamps[2] = wall_clock64();
+    if (c == w && tid < 64) {   // the diagonal tile publishes its chunk of the candidate list (output stage)
+      p.ws_box[c * 64 + tid] = s.rbox[tid];
+      p.ws_cc[c * 64 + tid] = s.rcc[tid];
+    }
+    const int gi = c * 64 + lane;
+    const float4 a = s.rbox[lane];
+    const float2 ac = s.rcc[lane];
+    const float area_a = (a.z - a.x) * (a.w - a.y);
+    unsigned int rowbits = 0u;
+    int rowcnt = 0, colcnt = 0;
+    unsigned long long colword = 0ull;
+#pragma unroll
+    for (int u = 0; u < kColsPerWave; ++u) {
+      const int col = wv * kColsPerWave + u;
+      const int gj = w * 64 + col;
+      const float4 bb = s.cbox[col];
+      const float2 bc = s.ccc[col];
+      // key_j > key_i with key = (confidence, ~position): the stable descending order
+      const bool j_first = bc.x > ac.x || (bc.x == ac.x && gj < gi);
+      const bool i_first = gi != gj && !j_first;
+      // the pair test of `suppresses` (same arithmetic; the IoU is symmetric bit for bit), once for both orientations
+      const float ix1 = fmaxf(a.x, bb.x), iy1 = fmaxf(a.y, bb.y);
+      const float ix2 = fminf(a.z, bb.z), iy2 = fminf(a.w, bb.w);
+      bool over = gi != gj && __float_as_int(bc.y) == __float_as_int(ac.y) && !(ix1 >= ix2 || iy1 >= iy2);
+      if (over) {
+        const float inter = (ix2 - ix1) * (iy2 - iy1);
+        const float area_b = (bb.z - bb.x) * (bb.w - bb.y);
+        over = inter / (area_a + area_b - inter + 1e-6f) > p.iou_thr;
+      }
+      if (over && ac.x > bc.x) rowbits |= 1u << u;                       // i suppresses j (strictly higher confidence)
+      rowcnt += j_first ? 1 : 0;
+      const unsigned long long cw = __ballot(over && bc.x > ac.x);      // j suppresses i: row j of tile (w, c), bit = lane
+      const int cc = __popcll(__ballot(i_first));
+      if (lane == u) {
+        colword = cw;
+        colcnt = cc;
+      }
+    }
+    s.piece[lane][wv] = (unsigned char)rowbits;
+    s.rcnt[lane][wv] = (unsigned char)rowcnt;
+    const unsigned long long colnz = __ballot(lane < kColsPerWave && colword != 0ull);
+    if (w != c) {   // (the diagonal tile visits every ordered pair itself)
+      if (lane < kColsPerWave) {
+        const int gj = w * 64 + wv * kColsPerWave + lane;
+        p.ws_full[(size_t)gj * kWords + c] = colword;
+        atomicAdd(&p.ws_rank[gj], colcnt);
+      }
+      if (lane == 0 && colnz) atomicOr(&p.ws_rownz[w], colnz << (kColsPerWave * wv));
+    }
+    __syncthreads();
+    if (tid < 64) {
+      unsigned long long word = 0ull;
+      int cnt = 0;
+#pragma unroll
+      for (int v = 0; v < kWN; ++v) {
+        word |= (unsigned long long)s.piece[tid][v] << (kColsPerWave * v);
+        cnt += s.rcnt[tid][v];
+      }
+      p.ws_full[(size_t)gi * kWords + w] = word;
+      atomicAdd(&p.ws_rank[gi], cnt);
+      const unsigned long long nz = __ballot(word != 0ull);
+      if (tid == 0 && nz) atomicOr(&p.ws_rownz[c], nz);
+    }
+    if (!arrive_and_check_last(p.ticket2, &s.is_last, ntiles)) return;
+  }
+  if (p.stamps && tid == 0) p.stamps[4] = wall_clock64();
+
+  // ---- last arriver: ranks -> permutation, masks -> LDS, greedy scan per class residue, output ----
+  int rk[2];        // this thread's two candidates (enumeration positions tid, tid + kTN): rank, (confidence, class), box
+  float2 cc2[2];
+  float4 bx2[2];
+  {
+    // every load of this phase is requested before the first one is waited for (each is a trip to L2 / another XCD)
+    constexpr int B = 8;
+    const int total = n * nw;       // rows 0..n) x nw words
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + q * kTN;
+      rk[q] = e < n ? __hip_atomic_load(p.ws_rank + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      cc2[q] = e < n ? p.ws_cc[e] : make_float2(0.f, 0.f);
+      bx2[q] = e < n ? p.ws_box[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    unsigned long long rz = tid < kWords ? __hip_atomic_load(p.ws_rownz + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    for (int k0 = tid; k0 < total; k0 += kTN * B) {
+      unsigned long long v[B];
+#pragma unroll
+      for (int q = 0; q < B; ++q) {
+        const int k = k0 + q * kTN;
+        const int row = k / nw, wd = k - row * nw;
+        v[q] = k < total ? p.ws_full[(size_t)row * kWords + wd] : 0ull;
+      }
+#pragma unroll
+      for (int q = 0; q < B; ++q) {
+        const int k = k0 + q * kTN;
+        if (k < total) s.mask[k] = v[q];
+      }
+    }
+    if (tid < kWords) s.rownz[tid] = rz;
+    __syncthreads();
+    // entry r of the rank-ordered list: candidate position | class residue << 10 | "its row marks something" << 12
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + q * kTN;
+      if (e < n && (unsigned)rk[q] < (unsigned)n) {   // (ranks are a permutation of 0..n-1: keys are distinct)
+        const unsigned nz = (unsigned)((s.rownz[e >> 6] >> (e & 63)) & 1ull);
+        s.perm[rk[q]] = (unsigned short)(e | ((__float_as_int(cc2[q].y) & 3) << 10) | (nz << 12));
+      }
+    }
+  }
+  __syncthreads();
+  if (p.stamps && tid == 0) p.stamps[8] = wall_clock64();
+  unsigned long long removed_reg = 0ull;                // wave v < 4, lane q < nw: word q of the wave's suppressed set
+  if (wv < 4) {
+    // this wave's rows, in rank order: class = wv (mod 4), mask not empty
+    int m = 0;
+    for (int r0 = 0; r0 < n; r0 += 64) {
+      const int r = r0 + lane;
+      const int ent = r < n ? (int)s.perm[r] : 0;
+      const bool take = r < n && (ent >> 12) && ((ent >> 10) & 3) == wv;
+      const unsigned long long bal = __ballot(take);
+      if (take) s.list[wv][m + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(ent & 1023);
+      m += __popcll(bal);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the list was written by this wave itself
+    if (p.stamps && tid == 0) p.stamps[9] = wall_clock64();
+    if (p.stamps && lane == 0) p.stamps[10 + wv] = m;
+    auto word_of = [&](int q) {
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)removed_reg, q);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(removed_reg >> 32), q);
+      return ((unsigned long long)hi << 32) | lo;
+    };
+    for (int k0 = 0; k0 < m; k0 += 64) {
+      // 64 list entries in a register (lane L: entry k0 + L); per group of 16: the 16 mask rows are fetched together, then
+      // the 16 decisions run from registers -- branch-free, so that no LDS latency sits in the dependent chain (with a
+      // conditional refill inside the loop the compiler waited lgkmcnt(0) per row: ~200 cycles a row)
+      const int cnt = m - k0 < 64 ? m - k0 : 64;
+      const int mine = k0 + lane < m ? (int)s.list[wv][k0 + lane] : 0;
+      for (int kb = 0; kb < cnt; kb += 16) {
+        unsigned long long pre[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int iq = __builtin_amdgcn_readlane(mine, (kb + q) & 63);     // (past the end: entry 0 of the register, unused)
+          pre[q] = lane < nw ? s.mask[iq * nw + lane] : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int i = __builtin_amdgcn_readlane(mine, (kb + q) & 63);
+          const unsigned long long cur = word_of(i >> 6);
+          const bool act = kb + q < cnt && !((cur >> (i & 63)) & 1ull);     // (a suppressed row suppresses nothing)
+          removed_reg |= act ? pre[q] : 0ull;
+        }
+      }
+    }
+    if (lane < kWords) s.removed[wv][lane] = removed_reg;
+    if (p.stamps && lane == 0) p.stamps[10 + wv] |= (long long)(wall_clock64() & 0xFFFFFFFFll) << 20;
+  }
+  __syncthreads();
+  if (tid < kWords) s.removed[0][tid] |= s.removed[1][tid] | s.removed[2][tid] | s.removed[3][tid];
+  __syncthreads();
+  if (p.stamps && tid == 0) p.stamps[5] = wall_clock64();
+  // output position of a kept candidate = number of kept candidates of lower rank: prefix over the rank order, then every
+  // thread scatters ITS OWN records (enumeration order, already in registers) -- no second trip to memory
+  int base = 0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = tid + q * kTN;
+    if (q * kTN >= n) break;
+    bool kept = false;
+    if (r < n) {
+      const int i = s.perm[r] & 1023;
+      kept = !((s.removed[0][i >> 6] >> (i & 63)) & 1ull);
+    }
+    const unsigned long long bal = __ballot(kept);
+    __syncthreads();
+    if (lane == 0) s.wave_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int v = 0; v < kWN; ++v) {
+      const int cwv = s.wave_cnt[v];
+      if (v < wv) off += cwv;
+      tot += cwv;
+    }
+    if (r < n) s.list[0][r] = (unsigned short)(base + off + __popcll(bal & ((1ull << lane) - 1ull)));   // (the lists are done with)
+    base += tot;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = tid + q * kTN;
+    if (e < n && (unsigned)rk[q] < (unsigned)n && !((s.removed[0][e >> 6] >> (e & 63)) & 1ull)) {
+      GpuDetection d;
+      d.x1 = bx2[q].x; d.y1 = bx2[q].y; d.x2 = bx2[q].z; d.y2 = bx2[q].w;
+      d.confidence = cc2[q].x;
+      d.class_id = __float_as_int(cc2[q].y);
+      d.valid = 1;
+      d._pad = 0;
+      p.out[s.list[0][rk[q]]] = d;
+    }
+  }
+  // the rank / row accumulators go back to zero for the next frame (they are zero at rest, like the ticket)
+  for (int e = tid; e < nw * 64; e += kTN) p.ws_rank[e] = 0;
+  if (tid < kWords) p.ws_rownz[tid] = 0ull;
+  if (tid == 0) {
+    *p.out_count = base;
+    if (p.out_candidates) *p.out_candidates = total;
+    __hip_atomic_store(p.ticket2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    if (p.stamps) p.stamps[6] = wall_clock64();
+  }
+  signal_done(p, tid);
+}
+
 int post_num_blocks(const int gw[3], const int gh[3]) {
   const int cells = gw[0] * gh[0] + gw[1] * gh[1] + gw[2] * gh[2];
   return (cells + kPostBlock - 1) / kPostBlock;
 }
 
 size_t post_workspace_bytes() {
-  return sizeof(float4) * kMaxDet + sizeof(float2) * kMaxDet + sizeof(unsigned long long) * (kTriWords + kMaxTiles) + 256;
+  return sizeof(float4) * kMaxDet + sizeof(float2) * kMaxDet + sizeof(unsigned long long) * (kTriWords + kMaxTiles) + 256 +
+         sizeof(int) * kMaxDet + sizeof(unsigned long long) * ((size_t)kMaxDet * kWords + kWords);
 }
 
 void post_bind_workspace(PostParams* p, void* ws) {
@@ -670,9 +1197,43 @@ void post_bind_workspace(PostParams* p, void* ws) {
   p->ws_tilenz = reinterpret_cast<unsigned long long*>(c); c += sizeof(unsigned long long) * kMaxTiles;
   p->ws_n = reinterpret_cast<int*>(c);
   p->ticket2 = reinterpret_cast<unsigned int*>(c + 64);
+  c += 256;
+  p->ws_full = reinterpret_cast<unsigned long long*>(c); c += sizeof(unsigned long long) * (size_t)kMaxDet * kWords;
+  p->ws_rownz = reinterpret_cast<unsigned long long*>(c); c += sizeof(unsigned long long) * kWords;
+  p->ws_rank = reinterpret_cast<int*>(c);
+}
+
+// mode 2: workgroups per head. A head read from planes: 256 cells per workgroup. A folded head: 64 cells (one 16-pixel
+// subtile per wave: its hidden tensor -- 64 px x 2C x 2 bytes per workgroup -- is then spread over many CUs), or 256 when
+// the grid would not fit the 1024-entry block table.
+bool post_plan_blocks(PostParams* p) {
+  for (int per = 64; per <= 256; per *= 4) {
+    int tot = 0;
+    for (int h = 0; h < 3; ++h) {
+      const int cells = p->gw[h] * p->gh[h];
+      p->cpb[h] = p->h1[h] ? per : kT2;
+      p->bstart[h] = tot;
+      tot += (cells + p->cpb[h] - 1) / p->cpb[h];
+    }
+    p->bstart[3] = tot;
+    if (tot >= 1 && tot <= 1024) return true;
+  }
+  return false;
 }
 
 int postprocess_desc(const PostParams& p, LaunchDesc out[2]) {
+  if (p.mode == 2) {
+    if (p.bstart[3] < 1 || p.bstart[3] > 1024 || !p.ws_full) return -1;
+    out[0].func = reinterpret_cast<const void*>(&post_decode_kernel);
+    out[0].grid = dim3(p.bstart[3]);
+    out[0].block = dim3(kT2);
+    out[0].shmem = (unsigned)sizeof(SmemD);
+    out[1].func = reinterpret_cast<const void*>(&post_nms_kernel);
+    out[1].grid = dim3(kMaxTiles);   // n is only known on the device: tiles past the triangle just draw their ticket
+    out[1].block = dim3(kTN);
+    out[1].shmem = (unsigned)sizeof(SmemN);
+    return 2;
+  }
   const int nb = post_num_blocks(p.gw, p.gh);
   if (nb < 1 || nb > kPostBlock) return -1;
   out[0].func = reinterpret_cast<const void*>(&postprocess_kernel);
@@ -780,7 +1341,11 @@ hipError_t post_init() {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPostSmemBytes);
     if (e != hipSuccess) return e;
   }
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(nms_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem2));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem2));
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(post_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemD));
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(post_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemN));
 }
 
 }  // namespace unina
