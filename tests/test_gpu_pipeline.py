@@ -87,3 +87,39 @@ open(sys.argv[1], "wb").write(b"".join(len(o).to_bytes(4, "little") + o for o in
     base = run({}, "base.bin")
     assert len(base) > 6 * 4 + 32 * 100
     assert run(env, "alt.bin") == base
+
+
+def test_tiled_stem_is_bit_identical_to_the_per_pixel_form(tmp_path):
+    """backbone.stem (model.py:175) as the tiled kernel (16-byte loads of the footprint into LDS, one thread per pixel and
+    all channels, LDS-staged NHWC stores) vs the one-thread-per-pixel form (UNINA_STEM_V1=1): the same fma chain per
+    channel, so the stem tensor must agree bit for bit -- tensor input, camera frame of the network's size and a resized
+    camera frame (pre-process computed inside the stem), at 640x640 and at a size with partial tiles."""
+    code = r'''
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, %r)
+import unina_yolo_dla_amd as u
+from unina_yolo_dla_amd.engine import Engine
+out = []
+for (h, w) in ((640, 640), (96, 160)):
+    g = u.graph.Graph(in_h=h, in_w=w)
+    e = Engine.from_state_dict(u.synth.make_state_dict(7), g)
+    e.set_fusion(False)
+    x = torch.from_numpy(u.rng.frame(1234, h, w)).cuda()
+    e.forward(x)
+    out.append(hashlib.sha256(e.read_buffer("backbone.stem").tobytes()).hexdigest())
+    rng = np.random.default_rng(5)
+    for (ch, cw) in ((h, w), (h + 40, w + 72)):
+        cam = torch.from_numpy(rng.integers(0, 256, (ch, cw * 4), dtype=np.uint8)).cuda()
+        d = e.infer_bgra(cam, cw, ch, cw * 4, None, 0.3, 0.45, 0.1)
+        out.append(hashlib.sha256(e.read_buffer("backbone.stem").tobytes()).hexdigest() + str(len(d)))
+    e.close()
+open(sys.argv[1], "w").write("\n".join(out))
+''' % ROOT
+    def run(extra, name):
+        out = str(tmp_path / name)
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return open(out).read()
+    tiled = run({}, "tiled.txt")
+    assert len(tiled.split()) == 6
+    assert run({"UNINA_STEM_V1": "1"}, "v1.txt") == tiled

@@ -1543,6 +1543,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   LOADCHK(pair_init());
   LOADCHK(block_dual_init());
   LOADCHK(post_init());
+  LOADCHK(stem_init());
   LOADCHK(hipMalloc(&e->d_zeros, 256));
   LOADCHK(hipMemset(e->d_zeros, 0, 256));
   LOADCHK(hipMalloc(&e->d_arena, arena ? arena : 256));

@@ -237,6 +237,7 @@ struct LaunchDesc {
   unsigned shmem;
 };
 hipError_t stem_desc(const StemParams& p, LaunchDesc* out);
+hipError_t stem_init();   // per device: dynamic-LDS limit of the tiled stem kernels
 // backbone.stem + the 3x3/s2 conv that follows it as ONE launch (conv_igemm.hip: stem_conv3x3s2_kernel)
 struct ConvParams;
 bool stemconv_supported(const StemParams& sp, const ConvParams& cp);

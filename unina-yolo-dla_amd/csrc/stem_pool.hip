@@ -4,6 +4,9 @@
 //   upsample2x_kernel  : Upsample(scale_factor=2, nearest)  (model.py:145-147), standalone form
 #include "kernels.h"
 
+#include <cstdint>
+#include <cstdlib>
+
 namespace unina {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -119,10 +122,184 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
   }
 }
 
+// ---- tiled form (the default) ----------------------------------------------------------------------------------
+// The one-thread-per-pixel form above issues 27 stride-2 dword loads per thread, twice (both channel halves): 173 000
+// wave-level load instructions per 640^2 frame, each a 512-byte span of which half is used, and fetches its 27 x CO/2
+// weights with scalar loads that the compiler cannot keep in flight (54 s_load_dwordx16, each behind an
+// s_waitcnt lgkmcnt(0)): 13.4 us at 640^2 for 11.5 MB (0.86 TB/s). Here a 128-thread workgroup owns 2 x 64 output pixels (800 workgroups at 640^2: three per CU, so that one's loads overlap another's arithmetic):
+//   1. its input footprint (3 planes x 5 rows x 132 columns fp32, 8 KB) comes in as aligned 16-byte loads along W --
+//      ~5 000 wave-level loads per frame, every byte used -- into LDS, next to the weights ([27][CO] + bias, 3.5 KB); a
+//      camera frame is pre-processed once per footprint pixel instead of once per tap that touches it;
+//   2. thread = TWO output pixels (the tile's two rows, one column) x one HALF of the channels: the same sequential fma chain
+//      per channel (k = (c, kh, kw) = 0..26 from the bias, v_pk_fma_f32 on channel pairs), inputs from LDS, weights as LDS
+//      broadcast reads shared by the two pixels and read one tap ahead;
+//   3. the tile's NHWC rows are staged in LDS and leave as contiguous 16-byte-per-lane stores (full lines).
+constexpr int kStemNT = 128;   // threads per workgroup
+constexpr int kStemTH = 2, kStemTW = 64, kStemPR = 2 * kStemTH + 1, kStemPW = 2 * kStemTW + 4;   // patch rows / columns
+template <typename T, int CO>
+struct StemTile {
+  static constexpr int NPATCH = 3 * kStemPR * kStemPW;                // floats
+  static constexpr int NW = 27 * CO + CO;                             // weights [27][CO] then bias [CO]
+  static constexpr int ROWB = CO * (int)sizeof(T) + 16;               // padded staging row (bytes) of one output pixel
+  static constexpr int STAGE = kStemTH * kStemTW * ROWB;              // the staging tile reuses the patch + weight area
+  static constexpr int IN_BYTES = (NPATCH + NW) * 4;
+  static constexpr unsigned SMEM = (unsigned)(STAGE > IN_BYTES ? STAGE : IN_BYTES);
+};
+template <typename T, int CO>
+__global__ __launch_bounds__(kStemNT) void stem_tile_kernel(const StemParams p) {
+  typedef StemTile<T, CO> ST;
+  extern __shared__ __align__(16) unsigned char stem_smem[];
+  float* patch = reinterpret_cast<float*>(stem_smem);          // [3][kStemPR][kStemPW]
+  float* wl = patch + ST::NPATCH;                               // [27][CO], then bias [CO]
+  const int tid = threadIdx.x;
+  const int tiles_x = (p.Wo + kStemTW - 1) / kStemTW;
+  const int ty0 = ((int)blockIdx.x / tiles_x) * kStemTH, tx0 = ((int)blockIdx.x % tiles_x) * kStemTW;
+  const int iy0 = 2 * ty0 - 1, ix0 = 2 * tx0 - 4;               // image coordinates of patch (row 0, column 0)
+  for (int i = tid; i < 27 * CO / 4; i += kStemNT) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(p.wt)[i];
+  if (tid < CO) wl[27 * CO + tid] = p.bias[tid];
+  if (p.src_kind == 0) {
+    const size_t plane = (size_t)p.H * p.W;
+    constexpr int NV = 3 * kStemPR * (kStemPW / 4);
+    for (int v = tid; v < NV; v += kStemNT) {
+      const int c = v / (kStemPR * (kStemPW / 4)), rem = v - c * (kStemPR * (kStemPW / 4));
+      const int r = rem / (kStemPW / 4), q = rem - r * (kStemPW / 4);
+      const int iy = iy0 + r, ix = ix0 + 4 * q;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (iy >= 0 && iy < p.H) {
+        const float* row = p.src + c * plane + (size_t)iy * p.W;
+        if (ix >= 0 && ix + 3 < p.W) {
+          val = *reinterpret_cast<const float4*>(row + ix);    // W % 4 == 0 and a 16-byte aligned tensor: aligned
+        } else {
+          if (ix >= 0 && ix < p.W) val.x = row[ix];
+          if (ix + 1 >= 0 && ix + 1 < p.W) val.y = row[ix + 1];
+          if (ix + 2 >= 0 && ix + 2 < p.W) val.z = row[ix + 2];
+          if (ix + 3 >= 0 && ix + 3 < p.W) val.w = row[ix + 3];
+        }
+      }
+      *reinterpret_cast<float4*>(patch + (c * kStemPR + r) * kStemPW + 4 * q) = val;
+    }
+  } else {
+    // camera frame: every footprint pixel is pre-processed once, as preprocess.hip would have written it
+    for (int e = tid; e < kStemPR * kStemPW; e += kStemNT) {
+      const int r = e / kStemPW, j = e - r * kStemPW;
+      const int iy = iy0 + r, ix = ix0 + j;
+      float rgb[3] = {0.f, 0.f, 0.f};
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) camera_pixel(p, iy, ix, rgb);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) patch[(c * kStemPR + r) * kStemPW + j] = rgb[c];
+    }
+  }
+  __syncthreads();
+  // a WAVE = the tile's two rows x 64 columns x ONE half of the output channels: 1 600 waves at 640^2, so that
+  // most SIMDs interleave two (a single wave issues a VALU instruction every 4 cycles, two waves every 2)
+  constexpr int CH = CO / 2;
+  const int tx = tid & 63, c0 = (tid >> 6) * CH;   // (tile rows 0 and 1)
+  float x[2][27];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const float* row = patch + (c * kStemPR + 2 * h + kh) * kStemPW + 2 * tx + 3;
+        x[h][(c * 3 + kh) * 3 + 0] = row[0];
+        const floatx2 v12 = *reinterpret_cast<const floatx2*>(row + 1);   // (8-byte aligned: 2 * tx + 4)
+        x[h][(c * 3 + kh) * 3 + 1] = v12[0];
+        x[h][(c * 3 + kh) * 3 + 2] = v12[1];
+      }
+  // (v_pk_fma_f32 on channel pairs; a scalar v_fma_f32 build of this loop measured 10.3 us against 9.5 us)
+  floatx2 acc[2][CH / 2];
+#pragma unroll
+  for (int r = 0; r < CH / 2; ++r) {
+    acc[0][r] = *reinterpret_cast<const floatx2*>(wl + 27 * CO + c0 + 2 * r);
+    acc[1][r] = acc[0][r];
+  }
+  // the weights of tap k + 1 are read (LDS broadcast: the same address in every lane) while tap k is computed: left to
+  // itself the compiler issues two reads, waits for them, uses them -- one exposed LDS latency per 8 FMAs, and with one
+  // or two waves per SIMD nothing else covers it (measured: 13.5 us, slower than the per-pixel form)
+  float4 wbuf[2][CH / 4];
+#pragma unroll
+  for (int j = 0; j < CH / 4; ++j) wbuf[0][j] = *reinterpret_cast<const float4*>(wl + c0 + 4 * j);
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    if (k + 1 < 27) {
+#pragma unroll
+      for (int j = 0; j < CH / 4; ++j) wbuf[(k + 1) & 1][j] = *reinterpret_cast<const float4*>(wl + (k + 1) * CO + c0 + 4 * j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const floatx2 x0 = {x[0][k], x[0][k]}, x1 = {x[1][k], x[1][k]};
+#pragma unroll
+    for (int j = 0; j < CH / 4; ++j) {
+      const float4 w4 = wbuf[k & 1][j];
+      acc[0][2 * j] = __builtin_elementwise_fma(x0, floatx2{w4.x, w4.y}, acc[0][2 * j]);
+      acc[0][2 * j + 1] = __builtin_elementwise_fma(x0, floatx2{w4.z, w4.w}, acc[0][2 * j + 1]);
+      acc[1][2 * j] = __builtin_elementwise_fma(x1, floatx2{w4.x, w4.y}, acc[1][2 * j]);
+      acc[1][2 * j + 1] = __builtin_elementwise_fma(x1, floatx2{w4.z, w4.w}, acc[1][2 * j + 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();                                              // every thread has read its inputs: the input area is free
+  constexpr int V = 16 / (int)sizeof(T);                        // elements per 16-byte chunk
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < CH; r += V) {
+      vec_t hv;
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const float a = acc[h][(r + q) >> 1][(r + q) & 1];
+        hv[q] = (T)(a > 0.f ? a : 0.f);
+      }
+      *reinterpret_cast<vec_t*>(stem_smem + (h * kStemTW + tx) * ST::ROWB + (c0 + r) * (int)sizeof(T)) = hv;
+    }
+  __syncthreads();
+  constexpr int CPP = CO * (int)sizeof(T) / 16;                 // 16-byte chunks per pixel
+  typedef float vec16 __attribute__((ext_vector_type(4)));
+  unsigned char* dst = static_cast<unsigned char*>(p.dst);
+#pragma unroll
+  for (int i = 0; i < CPP; ++i) {
+    const int chunk = i * kStemNT + tid;
+    const int pl = chunk / CPP, part = chunk - pl * CPP;        // tile pixel (row-major), chunk of its channels
+    const int oy = ty0 + (pl >> 6), ox = tx0 + (pl & 63);
+    if (oy < p.Ho && ox < p.Wo)
+      *reinterpret_cast<vec16*>(dst + ((size_t)(oy * p.Wo + ox) * p.dst_ld) * sizeof(T) + part * 16) =
+          *reinterpret_cast<const vec16*>(stem_smem + pl * ST::ROWB + part * 16);
+  }
+}
+
+template <typename T, int CO>
+constexpr unsigned stem_tile_smem() { return StemTile<T, CO>::SMEM; }
+
+// per device: the fp32 / wide instantiations stage more than the default 64 KB of dynamic LDS
+hipError_t stem_init() {
+  struct { const void* fn; unsigned smem; } ks[] = {
+      {reinterpret_cast<const void*>(&stem_tile_kernel<half_t, 32>), stem_tile_smem<half_t, 32>()},
+      {reinterpret_cast<const void*>(&stem_tile_kernel<half_t, 64>), stem_tile_smem<half_t, 64>()},
+      {reinterpret_cast<const void*>(&stem_tile_kernel<float, 32>), stem_tile_smem<float, 32>()},
+      {reinterpret_cast<const void*>(&stem_tile_kernel<float, 64>), stem_tile_smem<float, 64>()}};
+  for (const auto& k : ks) {
+    hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.smem);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 hipError_t stem_desc(const StemParams& p, LaunchDesc* out) {
-  out->grid = dim3((p.Ho * p.Wo + 127) / 128);        // 128 pixels x two channel halves per 256-thread workgroup
   if (!p.wt) return hipErrorInvalidValue;
   out->block = dim3(256);
+  static const bool legacy = getenv("UNINA_STEM_V1") && getenv("UNINA_STEM_V1")[0] == '1';   // the one-thread-per-pixel form
+  if (!legacy && (p.W & 3) == 0 && ((uintptr_t)p.src & 15) == 0 && p.dst_ld == p.Co) {
+    out->block = dim3(kStemNT);
+    out->grid = dim3(((p.Ho + kStemTH - 1) / kStemTH) * ((p.Wo + kStemTW - 1) / kStemTW));
+    if (p.Co == 32 && p.dtype == kF16) { out->func = reinterpret_cast<const void*>(&stem_tile_kernel<half_t, 32>); out->shmem = stem_tile_smem<half_t, 32>(); }
+    else if (p.Co == 64 && p.dtype == kF16) { out->func = reinterpret_cast<const void*>(&stem_tile_kernel<half_t, 64>); out->shmem = stem_tile_smem<half_t, 64>(); }
+    else if (p.Co == 32 && p.dtype == kF32) { out->func = reinterpret_cast<const void*>(&stem_tile_kernel<float, 32>); out->shmem = stem_tile_smem<float, 32>(); }
+    else if (p.Co == 64 && p.dtype == kF32) { out->func = reinterpret_cast<const void*>(&stem_tile_kernel<float, 64>); out->shmem = stem_tile_smem<float, 64>(); }
+    else return hipErrorInvalidValue;
+    return hipSuccess;
+  }
+  out->grid = dim3((p.Ho * p.Wo + 127) / 128);        // 128 pixels x two channel halves per 256-thread workgroup
   out->shmem = 0;
   if (p.Co == 32 && p.dtype == kF16) out->func = reinterpret_cast<const void*>(&stem_conv_kernel<half_t, 32>);
   else if (p.Co == 64 && p.dtype == kF16) out->func = reinterpret_cast<const void*>(&stem_conv_kernel<half_t, 64>);
