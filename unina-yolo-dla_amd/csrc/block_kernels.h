@@ -84,6 +84,30 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
   constexpr Img X = make_img(0, CX / E::CH);                               // (CX == CIN without a pre-conv)
   constexpr Img XR = make_img(0, (CREST ? CREST : E::KBLK) / E::CH);       // the HBM part next to a pre-conv's output
   constexpr int PH = 2 * (TH + 2 * NB - 1) + 3, PW = 2 * (R0W - 1) + 3;   // footprint of R0 under a 3x3 / stride-2 conv
+#if UNINA_BLOCK_PATCH_REGS
+  // patch (and constants) through registers, requested BEFORE the weight queue: the commits below then wait only for
+  // them (counted vmcnt) and the D weight blocks stay in flight across the barrier
+  PatchRegs<PH, PW, (CPRE ? CPRE : E::KBLK), NT, E> pr_pre;
+  PatchRegs<TH + 2 * NB, R0W, (CREST ? CREST : E::KBLK), NT, E> pr_rest;
+  PatchRegs<TH + 2 * NB, R0W, CIN, NT, E> pr_x;
+  if constexpr (PRE) {
+    patch_issue<PH, PW, (CPRE ? CPRE : E::KBLK), NT, E>(pr_pre, p.src, p.src_ld, p.preH, p.preW, 2 * (ty0 - NB) - 1, 2 * (tx0 - NB) - 1, wid, lane);
+    if constexpr (CREST > 0)
+      patch_issue<TH + 2 * NB, R0W, (CREST ? CREST : E::KBLK), NT, E>(pr_rest, p.src2, p.src2_ld, p.H, p.W, ty0 - NB, tx0 - NB, wid, lane);
+  } else {
+    patch_issue<TH + 2 * NB, R0W, CIN, NT, E>(pr_x, p.src, p.src_ld, p.H, p.W, ty0 - NB, tx0 - NB, wid, lane);
+  }
+  consts_issue<NT>(cregs, p.bias, p.n_bias);
+  static_for<0, D>([&](auto gc) { wq_fetch<ST, D, decltype(gc)::value>(q, wbase, wid); });
+  if constexpr (PRE) {
+    patch_commit<PH, PW, (CPRE ? CPRE : E::KBLK), NT, E>(pr_pre, smem + p.off_p, wid, lane);
+    if constexpr (CREST > 0) patch_commit<TH + 2 * NB, R0W, (CREST ? CREST : E::KBLK), NT, E>(pr_rest, smem + p.off_xr, wid, lane);
+  } else {
+    patch_commit<TH + 2 * NB, R0W, CIN, NT, E>(pr_x, smem + p.off_x, wid, lane);
+  }
+  consts_commit<NT>(cregs, bias_lds, p.n_bias);
+  lds_barrier();
+#else
   if constexpr (PRE) {
     load_patch<PH, PW, (CPRE ? CPRE : E::KBLK), NT, E>(smem + p.off_p, p.src, p.src_ld, p.preH, p.preW, 2 * (ty0 - NB) - 1,
                                                      2 * (tx0 - NB) - 1, p.zeros, wid, lane);
@@ -98,6 +122,8 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed (LDS-DMA is not tracked by the compiler)
   consts_commit<NT>(cregs, bias_lds, p.n_bias);
   lds_barrier();
+
+#endif
 
   const Img Xi = Img{p.off_x, X.nch, X.sh, X.mask};
   const Img XRi = Img{p.off_xr, XR.nch, XR.sh, XR.mask};
@@ -355,12 +381,23 @@ __device__ __forceinline__ void head_fused_body(const HeadParams& p, int bid, un
   float* bias_lds = reinterpret_cast<float*>(smem + p.off_bias);
   floatx4 cregs[kConstVecs];
   constexpr Img X = make_img(0, C / 8);
+#if UNINA_BLOCK_PATCH_REGS
+  PatchRegs<R0H, R0W, C, NT> pr_x;
+  patch_issue<R0H, R0W, C, NT>(pr_x, p.src, p.src_ld, p.H, p.W, ty0 - 2, tx0 - 2, wid, lane);
+  consts_issue<NT>(cregs, p.bias, p.n_bias);
+  static_for<0, D>([&](auto gc) { wq_fetch<ST, D, decltype(gc)::value>(q, wbase, wid); });
+  patch_commit<R0H, R0W, C, NT>(pr_x, smem + p.off_x, wid, lane);
+  consts_commit<NT>(cregs, bias_lds, p.n_bias);
+  lds_barrier();
+#else
   load_patch<R0H, R0W, C, NT>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0 - 2, tx0 - 2, p.zeros, wid, lane);
   static_for<0, D>([&](auto gc) { wq_fetch<ST, D, decltype(gc)::value>(q, wbase, wid); });
   consts_issue<NT>(cregs, p.bias, p.n_bias);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
   consts_commit<NT>(cregs, bias_lds, p.n_bias);
   lds_barrier();
+
+#endif
 
   const Img Xi = Img{p.off_x, X.nch, X.sh, X.mask};
   const Img H0 = make_img(p.off_h0, 2 * C / 8);

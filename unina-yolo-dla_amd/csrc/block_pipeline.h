@@ -279,5 +279,75 @@ __device__ __forceinline__ void load_patch(unsigned char* lds_img, const void* s
   }
 }
 
+#ifndef UNINA_BLOCK_PATCH_REGS
+#define UNINA_BLOCK_PATCH_REGS 0   // block kernels / conv_pair: input patch through registers (1) or LDS-DMA (0, the default: same-box
+                                   // A/B at 2 frames in flight: 8 270-8 470 frames/s with LDS-DMA against 8 130-8 200 through registers;
+                                   // the register-queue 3x3 kernels (conv_igemm.hip) go the other way: 8 240-8 360 against 8 130-8 170)
+#endif
+// The same patch through REGISTERS: plain 16-byte global loads (all requested back to back: ~16 cycles of issue each, against
+// the 60-185 cycles an LDS-DMA piece costs the issuing wave), then ds_write_b128 once they have landed -- the compiler's
+// counted s_waitcnt vmcnt leaves whatever was requested after them (the weight queue) in flight. Same LDS image.
+template <int RH, int RW, int CIN, int NT, typename E = EltH>
+struct PatchRegs {
+  static constexpr int nchx = CIN / E::CH, nslots = RH * RW * nchx, ITER = (nslots + NT - 1) / NT;
+  floatx4 v[ITER];
+};
+// Index arithmetic kept short: 32-bit offsets, the chunk index is the same in every iteration (NT is a multiple of the
+// chunks per pixel), and no branch -- a pixel outside the image is loaded from a clamped address and zeroed by a select
+// (with a branch per load and 64-bit pointer arithmetic this prologue was ~770 instructions per wave: 2.5 us before the
+// first weight block was requested).
+template <int RH, int RW, int CIN, int NT, typename E = EltH>
+__device__ __forceinline__ void patch_issue_nobranch(PatchRegs<RH, RW, CIN, NT, E>& pr, const void* src_, int src_ld, int H, int W, int y0,
+                                            int x0, int wid, int lane) {
+  typedef PatchRegs<RH, RW, CIN, NT, E> PR;
+  constexpr Img X = make_img(0, CIN / E::CH);
+  static_assert(NT % PR::nchx == 0, "the chunk index must not depend on the iteration");
+  const unsigned char* src = static_cast<const unsigned char*>(src_);
+  const int ls = wid * 64 + lane;
+  const int cs = ls % PR::nchx, r0 = ls / PR::nchx;
+  const int pitch = src_ld * E::ESZ;                    // bytes per pixel
+#pragma unroll
+  for (int it = 0; it < PR::ITER; ++it) {
+    const int r = r0 + it * (NT / PR::nchx);
+    const int ry = r / RW, rx = r - ry * RW;
+    const int iy = y0 + ry, ix = x0 + rx;
+    const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && r < RH * RW;
+    const int iyc = iy < 0 ? 0 : (iy < H ? iy : H - 1), ixc = ix < 0 ? 0 : (ix < W ? ix : W - 1);
+    const unsigned off = (unsigned)((iyc * W + ixc) * pitch + ((cs ^ X.key(r)) << 4));
+    const floatx4 v = *reinterpret_cast<const floatx4*>(src + off);
+    pr.v[it] = inside ? v : floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+// The form in use: a branch around each load (out-of-image pixels are not fetched). Same-box A/B (tools/ab_run.sh, regq head
+// pairs): LDS-DMA 19.8 us, this 18.9 us, the branch-free clamped form above 20.5 us per pair.
+template <int RH, int RW, int CIN, int NT, typename E = EltH>
+__device__ __forceinline__ void patch_issue(PatchRegs<RH, RW, CIN, NT, E>& pr, const void* src_, int src_ld, int H, int W, int y0,
+                                              int x0, int wid, int lane) {
+  typedef PatchRegs<RH, RW, CIN, NT, E> PR;
+  constexpr Img X = make_img(0, CIN / E::CH);
+  const unsigned char* src = static_cast<const unsigned char*>(src_);
+#pragma unroll
+  for (int it = 0; it < PR::ITER; ++it) {
+    const int s = it * NT + wid * 64 + lane;
+    pr.v[it] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (s < PR::nslots) {
+      const int r = s / PR::nchx, cs = s - r * PR::nchx;
+      const int ry = r / RW, rx = r - ry * RW;
+      const int iy = y0 + ry, ix = x0 + rx;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        pr.v[it] = *reinterpret_cast<const floatx4*>(src + ((size_t)(iy * W + ix) * src_ld) * E::ESZ + ((cs ^ X.key(r)) << 4));
+    }
+  }
+}
+template <int RH, int RW, int CIN, int NT, typename E = EltH>
+__device__ __forceinline__ void patch_commit(const PatchRegs<RH, RW, CIN, NT, E>& pr, unsigned char* lds_img, int wid, int lane) {
+  typedef PatchRegs<RH, RW, CIN, NT, E> PR;
+#pragma unroll
+  for (int it = 0; it < PR::ITER; ++it) {
+    const int s = it * NT + wid * 64 + lane;
+    if (s < PR::nslots) *reinterpret_cast<floatx4*>(lds_img + s * 16) = pr.v[it];
+  }
+}
+
 }  // namespace dev
 }  // namespace unina

@@ -708,6 +708,10 @@ __device__ __forceinline__ void stem_patch(unsigned char* smem, unsigned char* w
 
 // WN = 16-channel subtiles per wave (each activation fragment then feeds WN MFMAs: halves the LDS reads per MFMA at 2).
 // T = half_t, or signed char (INT8 engines: int8 patch image, 64-k weight blocks, v_mfma_i32_16x16x64_i8).
+#ifndef UNINA_PATCH_VIA_REGS
+#define UNINA_PATCH_VIA_REGS 1
+#endif
+constexpr bool kPatchViaRegs = UNINA_PATCH_VIA_REGS != 0;   // input patch: 16-byte loads to registers + ds_write (1) or LDS-DMA (0)
 // STAMPS (debug instantiations only: a branch around the loads would change the schedule of the product kernels): phase
 // stamps of the conv's mid workgroup -- 0 start, 1 patch DMA + first weight blocks issued, 2 patch landed (barrier passed),
 // 3 K loop done, 4 stores issued.
@@ -757,6 +761,15 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
     static_for<0, D>(fetch);   // weights first: they are in flight while the stem patch is computed
     constexpr int PATCH = ((R0H * R0W * CIN * 2 + 1023) / 1024) * 1024;
     stem_patch<R0H, R0W, CIN, NT>(conv_smem, conv_smem + PATCH, *sp, S * ty0 - 1, S * tx0 - 1);
+  } else if constexpr (kPatchViaRegs) {
+    PatchRegs<R0H, R0W, CIN, NT, PE> pr;
+    if constexpr (UNINA_PATCH_VIA_REGS == 2)
+      patch_issue_nobranch<R0H, R0W, CIN, NT, PE>(pr, static_cast<const T*>(p.src) + sg.src_coff, p.src_ld, p.H, p.W, S * ty0 - 1, S * tx0 - 1, wid, lane);
+    else
+      patch_issue<R0H, R0W, CIN, NT, PE>(pr, static_cast<const T*>(p.src) + sg.src_coff, p.src_ld, p.H, p.W, S * ty0 - 1, S * tx0 - 1, wid, lane);
+    static_for<0, D>(fetch);
+    if constexpr (STAMPS) stamp_b(p, 1, bid, nwg);
+    patch_commit<R0H, R0W, CIN, NT, PE>(pr, conv_smem, wid, lane);
   } else {
     load_patch<R0H, R0W, CIN, NT, PE>(conv_smem, static_cast<const T*>(p.src) + sg.src_coff, p.src_ld, p.H, p.W, S * ty0 - 1,
                                       S * tx0 - 1, p.zeros, wid, lane);
@@ -764,8 +777,8 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
   }
   EpiConsts<WN> ec;
   load_epi_consts<WN>(sg, nb0 + wn * (WN * 16), lq, ec);
-  if constexpr (STAMPS) stamp_b(p, 1, bid, nwg);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
+  if constexpr (STAMPS && (STEM || !kPatchViaRegs)) stamp_b(p, 1, bid, nwg);
+  if constexpr (STEM || !kPatchViaRegs) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
   lds_barrier();
   if constexpr (STAMPS) stamp_b(p, 2, bid, nwg);
 
@@ -851,6 +864,19 @@ __global__ __launch_bounds__(512, 4) void conv_dual_head3x3_i8(const ConvParams 
 __global__ __launch_bounds__(512) void conv_dual_head3x3_big(const ConvParams pa, const ConvParams pb, int na) {
   if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 16, 1>(pa, (int)blockIdx.x, na);
   else conv3x3_regq_body<8, 16, 64, 256, 8, 16, 1>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
+}
+// The same tiles on FOUR waves (2 along the channels x 2 along the pixels, two channel subtiles per wave): every activation
+// fragment read from LDS feeds two MFMAs, so the LDS array -- which the 8-wave form saturates at exactly the MFMA rate, one
+// ds_read_b128 per MFMA -- runs at half load; the L2 -> register weight traffic per workgroup is unchanged (4 waves x 2
+// subtiles instead of 8 x 1).
+__global__ __launch_bounds__(256) void conv_dual_head3x3_big4(const ConvParams pa, const ConvParams pb, int na) {
+  if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 4, 16, 1, false, 2>(pa, (int)blockIdx.x, na);
+  else conv3x3_regq_body<8, 16, 64, 256, 4, 16, 1, false, 2>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
+}
+// experiment: the 8-wave form with a 32-deep weight queue (twice the weight bytes in flight per CU)
+__global__ __launch_bounds__(512) void conv_dual_head3x3_big_d32(const ConvParams pa, const ConvParams pb, int na) {
+  if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 32, 1>(pa, (int)blockIdx.x, na);
+  else conv3x3_regq_body<8, 16, 64, 256, 8, 32, 1>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
 }
 // debug twin of conv_dual_head3x3_big with in-kernel phase stamps (unina_debug_dual_stamps)
 __global__ __launch_bounds__(512) void conv_dual_head3x3_big_stamped(const ConvParams pa, const ConvParams pb, int na) {
@@ -1093,6 +1119,8 @@ hipError_t conv_init() {
   for (const void* f : {reinterpret_cast<const void*>(conv_dual_head3x3), reinterpret_cast<const void*>(conv_dual_head1x1),
                         reinterpret_cast<const void*>(conv_dual_head3x3_w2), reinterpret_cast<const void*>(conv_dual_head3x3_i8),
                         reinterpret_cast<const void*>(conv_dual_head3x3_big), reinterpret_cast<const void*>(conv_dual_head3x3_big_i8),
+                        reinterpret_cast<const void*>(conv_dual_head3x3_big4), reinterpret_cast<const void*>(conv_dual_head3x3_big_stamped),
+                        reinterpret_cast<const void*>(conv_dual_head3x3_big_d32),
                         reinterpret_cast<const void*>(stem_conv3x3s2_kernel)}) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (e != hipSuccess) return e;
@@ -1246,8 +1274,10 @@ const DualKind kDual[] = {
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3_i8<regq i8,8x16,64,128 | regq i8,8x8,64,256>", conv_dual_head3x3_i8},
     {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big<regq 16x16,64,128 | regq 8x16,64,256>", conv_dual_head3x3_big},
     {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big_i8<regq i8,16x16,64,128 | regq i8,8x16,64,256>", conv_dual_head3x3_big_i8},
+    {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 256, "conv_dual_head3x3_big4<regq 16x16,64,128,4w,wn2 | regq 8x16,64,256,4w,wn2>", conv_dual_head3x3_big4},
+    {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big_d32<regq 16x16,64,128,d32 | regq 8x16,64,256,d32>", conv_dual_head3x3_big_d32},
 };
-constexpr int kDualKinds = 6;
+constexpr int kDualKinds = 8;
 }  // namespace
 
 int conv_dual_match(const ConvParams& a, const ConvParams& b) {
@@ -1262,7 +1292,8 @@ int conv_dual_match(const ConvParams& a, const ConvParams& b) {
   }
   if (a.dtype != kF16 || b.dtype != kF16) return -1;
   static const bool w2 = getenv("UNINA_DUAL_W2") && getenv("UNINA_DUAL_W2")[0] == '1';
-  if (big && a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[4].cfg_a) && conv_config_valid(b, kDual[4].cfg_b)) return 4;
+  static const int variant = getenv("UNINA_DUAL_4W") ? atoi(getenv("UNINA_DUAL_4W")) : 0;   // 1: four waves, wn 2; 2: queue depth 32
+  if (big && a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[4].cfg_a) && conv_config_valid(b, kDual[4].cfg_b)) return variant == 1 ? 6 : (variant == 2 ? 7 : 4);
   if (w2 && a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[2].cfg_a) && conv_config_valid(b, kDual[2].cfg_b)) return 2;
   if (a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[0].cfg_a) && conv_config_valid(b, kDual[0].cfg_b)) return 0;
   auto tiny = [](const ConvParams& p) {

@@ -66,6 +66,18 @@ __global__ __launch_bounds__(NW * 64) void conv_pair_kernel(const PairParams p) 
   constexpr Img X = make_img(0, C0 / E::CH);
   constexpr int CXP = C0 / 4, NCX = CXP / E::CH;            // POOL: channels / chunks of x
   constexpr int RH = TH + 12, RW = TW + 12;                 // POOL: tile + 6-pixel halo
+#if UNINA_BLOCK_PATCH_REGS
+  PatchRegs<RH, RW, CXP, NT, E> pr_r;
+  PatchRegs<TH, TW, C0, NT, E> pr_x;
+  if constexpr (POOL) patch_issue<RH, RW, CXP, NT, E>(pr_r, p.src, p.src_ld, p.H, p.W, ty0 - 6, tx0 - 6, wid, lane);
+  else patch_issue<TH, TW, C0, NT, E>(pr_x, p.src, p.src_ld, p.H, p.W, ty0, tx0, wid, lane);
+  consts_issue<NT>(cregs, p.bias, p.n_bias);
+  static_for<0, D>([&](auto gc) { wq_fetch<ST, D, decltype(gc)::value>(q, wbase, wid); });
+  if constexpr (POOL) patch_commit<RH, RW, CXP, NT, E>(pr_r, smem + p.off_r, wid, lane);
+  else patch_commit<TH, TW, C0, NT, E>(pr_x, smem + p.off_x, wid, lane);
+  consts_commit<NT>(cregs, cst, p.n_bias);
+  lds_barrier();
+#else
   if constexpr (POOL)
     load_patch<RH, RW, CXP, NT, E>(smem + p.off_r, p.src, p.src_ld, p.H, p.W, ty0 - 6, tx0 - 6, p.zeros, wid, lane);
   else
@@ -75,6 +87,8 @@ __global__ __launch_bounds__(NW * 64) void conv_pair_kernel(const PairParams p) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
   consts_commit<NT>(cregs, cst, p.n_bias);
   lds_barrier();
+
+#endif
 
   const Img Xi = Img{p.off_x, X.nch, X.sh, X.mask};
   if constexpr (POOL) {
