@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--precision", choices=["fp16", "fp32", "int8"], default="fp16",
                     help="fp16 = BASELINE configs[1] (headline); fp32 = native fp32-MFMA mode that meets the strict tolerance")
     ap.add_argument("--calib-frames", type=int, default=64)
+    ap.add_argument("--calibrator", choices=["max", "percentile", "entropy", "mse"], default="mse", help="INT8 activation range selection")
     ap.add_argument("--variant", choices=["A", "B"], default="A",
                     help="A = model.py's graph (BASELINE configs); B = qat.py's topology (stride-32 stage, third FPN level)")
     ap.add_argument("--streams", type=int, default=0, help="parallel graph paths per engine (0 = library default)")
@@ -95,9 +96,10 @@ def main():
     os.close(fd)
     prec = {"fp32": export.FP32, "int8": export.INT8}.get(args.precision, export.FP16)
     amax = None
-    if prec == export.INT8:   # BASELINE configs[2]: own calibrator over 64 synthetic frames (seeds 5000..5063)
+    if prec == export.INT8:   # BASELINE configs[2]: |x| histograms over 64 synthetic frames (seeds 5000..5063), range = the
+        # mse-optimal threshold (the best of max / percentile / entropy / mse in profiles/r02/int8_drift_table.txt)
         from unina_yolo_dla_amd.engine import calibrate_amax
-        amax = calibrate_amax(sd, g, (u.rng.frame(5000 + i, S, S) for i in range(args.calib_frames)), device=local)
+        amax = calibrate_amax(sd, g, (u.rng.frame(5000 + i, S, S) for i in range(args.calib_frames)), device=local, method=args.calibrator)
     export.export_engine(sd, path, g, prec, amax)
     engines = [Engine(path, device=local) for _ in range(IN_FLIGHT)]
     os.unlink(path)

@@ -403,7 +403,8 @@ def test_int8_engine_matches_integer_emulation_and_reports_drift(pkg, sd7, oracl
     """(1) exactness: the HIP int8 path (v_mfma_i32_16x16x64_i8, fp32 per-channel multiplier, round-half-even
     requantisation) against the torch-CPU integer emulation of the same op table at 128x128, op by op on the engine's
     own inputs (teacher-forced) -- int8 codes must agree but for rare round-to-nearest ties; (2) calibrated drift vs the fp32 oracle at
-    640x640 (the reference pins no quantised result: parity unpinned)."""
+    640x640 with the histogram + mse calibrator (the reference pins no quantised result and pytorch-quantization is absent:
+    PARITY UNPINNED; the per-calibrator drift table is profiles/r02/int8_drift_table.txt)."""
     from emulate import run_op_table, engine_buffers, per_op_mismatch
     from unina_yolo_dla_amd import export
     from unina_yolo_dla_amd.engine import Engine, calibrate_amax
@@ -439,9 +440,11 @@ def test_int8_engine_matches_integer_emulation_and_reports_drift(pkg, sd7, oracl
             assert e_engine < 1.25 * e_quant + 1e-3, (n, e_engine, e_quant)
     finally:
         e.close()
-    # ---- drift at the benchmark size ----
+    # ---- drift at the benchmark size (PARITY UNPINNED: the reference pins no quantised result and its quantisation
+    # library is absent; bounds = the measured drift of the chosen calibrator, profiles/r02/int8_drift_table.txt:
+    # histogram + mse, 97.6 % matched, median IoU 0.9934, median |dscore| 0.0067, head rms 3.4 % of std -- plus a margin) ----
     frames = [pkg.rng.frame(5000 + i, 640, 640) for i in range(8)]
-    amax = calibrate_amax(sd7, None, frames)
+    amax = calibrate_amax(sd7, None, frames, method="mse")
     e = Engine.from_state_dict(sd7, precision=export.INT8, amax=amax)
     try:
         x = pkg.rng.frame(1234, 640, 640)
@@ -451,7 +454,7 @@ def test_int8_engine_matches_integer_emulation_and_reports_drift(pkg, sd7, oracl
         want, _ = oracle_mod.postprocess([o[n] for n in pkg.graph.OUTPUT_NAMES], 0.5, 0.45, 0.1)
         for n in pkg.graph.OUTPUT_NAMES:
             err = float(np.sqrt(((heads[n] - o[n]) ** 2).mean()))
-            assert err < 0.12 * max(float(o[n].std()), 0.3), (n, err)
+            assert err < 0.08 * max(float(o[n].std()), 0.3), (n, err)
         from detcmp import iou_matrix
         m = iou_matrix(got, want)
         m = np.where(got["class_id"][:, None] == want["class_id"][None, :], m, 0.0)
@@ -460,7 +463,8 @@ def test_int8_engine_matches_integer_emulation_and_reports_drift(pkg, sd7, oracl
         print("INT8 drift: dets", len(got), "vs", len(want), "matched", int(matched.sum()),
               "median IoU %.4f" % np.median(m.max(1)[matched]),
               "median |dscore| %.4f" % np.median(np.abs(got["confidence"] - want["confidence"][j])[matched]))
-        assert matched.sum() >= 0.75 * len(want) and np.median(m.max(1)[matched]) > 0.9
+        assert matched.sum() >= 0.94 * len(want) and np.median(m.max(1)[matched]) > 0.985
+        assert np.median(np.abs(got["confidence"] - want["confidence"][j])[matched]) < 0.012
     finally:
         e.close()
 

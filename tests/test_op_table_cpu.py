@@ -98,3 +98,32 @@ def test_int8_pass_structure_and_drift(pkg, sd7, oracle_mod, oracle_sd7):
         assert err < 0.12 * max(float(ref[n].std()), 0.3), (n, err)                 # measured ~5 % of the logit std
     with np.testing.assert_raises(ValueError):
         export.EngineBuilder(sd7, g, export.INT8)                                    # no calibration -> refuse
+
+
+def test_histogram_calibrator_range_selections(pkg):
+    """export.HistogramCalibrator (the build's restatement of the reference's QuantDescriptor(calib_method="histogram"),
+    qat.py:91-126; parity unpinned): the histogram grows by whole bins, an outlier is clipped by entropy / mse /
+    percentile but not by max, and calibrate() returns one range per buffer for every method."""
+    from unina_yolo_dla_amd import export
+    rng = np.random.default_rng(0)
+    a = np.maximum(rng.normal(0, 1, (32, 40, 40)).astype(np.float32), 0)
+    b = a * 1.5
+    a[0, 0, 0] = 40.0
+    c = export.HistogramCalibrator()
+    c.collect(a)
+    n0 = len(c.hist)
+    c.collect(b)
+    assert len(c.hist) == n0 and c.hist.sum() == a.size + b.size           # (b stays below the outlier: no growth)
+    c.collect(np.array([55.0], dtype=np.float32))
+    assert len(c.hist) > n0 and c.edges[-1] >= 55.0                        # grown by whole bins
+    assert abs((c.edges[1] - c.edges[0]) - 40.0 / 2048) < 1e-6
+    ent, mse, p9999 = c.amax("entropy"), c.amax("mse"), c.amax("percentile", 99.99)
+    assert 3.0 < p9999 < 8.0 and 3.0 < ent < 12.0 and 3.0 < mse <= c.edges[-1]   # the bulk is N(0,1.5) clipped at 0: max ~ 6-7
+    # (mse keeps far outliers when their squared clipping error outweighs the finer step for everything else)
+    frames = [{"x": a, "y": b}, {"x": b, "y": a}]
+    for method in ("max", "entropy", "mse", "percentile"):
+        am = export.calibrate(frames, method=method)
+        assert set(am) == {"x", "y"} and all(v > 0 for v in am.values())
+    assert export.calibrate(frames)["x"] == 40.0
+    both = export.calibrate_all(frames, {"m": ("max", None), "e": ("entropy", None)})
+    assert both["m"]["x"] == 40.0 and both["e"]["x"] < 40.0

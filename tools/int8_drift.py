@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""INT8 calibrated drift per calibrator (BASELINE configs[2]; parity unpinned: the reference pins no quantised result and its
+quantisation library is absent): for every range selection -- max, percentiles, histogram + entropy (what
+the reference configures, qat.py:91-126), histogram + mse -- an INT8 engine is built from the SAME calibration pass
+(--calib frames, seeds 5000..) and run on --frames evaluation frames (seeds 1234..); its detections and head tensors are
+compared with the fp32 oracle's. Output: a table (stdout) -> profiles/rNN/int8_drift_table.txt."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+import unina_yolo_dla_amd as u
+from unina_yolo_dla_amd import export
+from unina_yolo_dla_amd.engine import Engine, calibrate_amax
+from oracle import oracle
+from detcmp import iou_matrix
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--calib", type=int, default=16)
+ap.add_argument("--frames", type=int, default=8)
+ap.add_argument("--size", type=int, default=640)
+a = ap.parse_args()
+S = a.size
+g = u.graph.Graph(in_h=S, in_w=S)
+sd = u.synth.make_state_dict(7, g)
+osd = oracle.StateDict(sd)
+NAMES = u.graph.OUTPUT_NAMES
+SPECS = {"max": ("max", None), "percentile 99.9": ("percentile", 99.9), "percentile 99.99": ("percentile", 99.99),
+         "percentile 99.999": ("percentile", 99.999), "histogram+entropy": ("entropy", None), "histogram+mse": ("mse", None)}
+amaxes = calibrate_amax(sd, g, (u.rng.frame(5000 + i, S, S) for i in range(a.calib)), specs=SPECS)
+
+frames = [u.rng.frame(1234 + i, S, S) for i in range(a.frames)]
+refs = []
+for x in frames:
+    o = oracle.forward(osd, x)
+    d, _ = oracle.postprocess([o[n] for n in NAMES], 0.5, 0.45, 0.1)
+    refs.append((o, d))
+
+def evaluate(e):
+    agg = dict(ndet=0, nref=0, matched=0, ious=[], ds=[], rms=[])
+    for x, (o, want) in zip(frames, refs):
+        xd = torch.from_numpy(x).cuda()
+        heads = e.forward(xd)
+        got = e.infer(xd, 0.5, 0.45, 0.1)
+        agg["rms"].append(np.mean([np.sqrt(((heads[n] - o[n]) ** 2).mean()) / max(float(o[n].std()), 1e-6) for n in NAMES]))
+        m = iou_matrix(got, want)
+        m = np.where(got["class_id"][:, None] == want["class_id"][None, :], m, 0.0)
+        j = m.argmax(1)
+        ok = m.max(1) > 0.5
+        agg["ndet"] += len(got); agg["nref"] += len(want); agg["matched"] += int(ok.sum())
+        agg["ious"] += list(m.max(1)[ok]); agg["ds"] += list(np.abs(got["confidence"] - want["confidence"][j])[ok])
+    i, d = np.array(agg["ious"]), np.array(agg["ds"])
+    return (agg["ndet"], agg["nref"], agg["matched"], 100.0 * agg["matched"] / agg["nref"], float(np.median(i)), float(np.percentile(i, 5)), float(i.min()),
+            float(np.median(d)), float(np.percentile(d, 95)), float(d.max()), 100.0 * float(np.mean(agg["rms"])))
+
+print(f"INT8 drift vs the fp32 oracle, {S}x{S}, {a.calib} calibration frames (seeds 5000..), {a.frames} evaluation frames (seeds 1234..), conf 0.5 / iou 0.45 / q 0.1")
+print("matched = same class and IoU > 0.5 with an oracle detection; head rms = rms error of the six head tensors / their std")
+print(f"{'calibrator':20s}{'dets':>7s}{'oracle':>8s}{'matched':>9s}{'%':>7s}{'IoU med':>9s}{'IoU p5':>8s}{'IoU min':>9s}{'|ds| med':>10s}{'|ds| p95':>10s}{'|ds| max':>10s}{'head rms %':>12s}")
+def row(label, r):
+    print(f"{label:20s}{r[0]:7d}{r[1]:8d}{r[2]:9d}{r[3]:7.1f}{r[4]:9.4f}{r[5]:8.4f}{r[6]:9.4f}{r[7]:10.4f}{r[8]:10.4f}{r[9]:10.4f}{r[10]:12.2f}")
+e = Engine.from_state_dict(sd, g)
+row("(fp16 engine)", evaluate(e))
+e.close()
+for label, amax in amaxes.items():
+    e = Engine.from_state_dict(sd, g, precision=export.INT8, amax=amax)
+    row(label, evaluate(e))
+    e.close()
+osd.close()

@@ -366,10 +366,12 @@ class Engine:
 
 
 def calibrate_amax(sd: Dict[str, np.ndarray], graph: Optional[Graph], frames, device: int = 0,
-                   percentile: Optional[float] = None) -> Dict[str, float]:
+                   percentile: Optional[float] = None, method: Optional[str] = None, specs=None):
     """INT8 calibration on the GPU (the role of qat.py:171-220 `calibrate_model`, 30 batches in train.py:809): runs the
     fp16 engine over `frames` (iterable of [1,3,H,W] fp32 ndarrays) and records, per activation buffer, the
-    (percentile of the) absolute maximum. Feed the result to from_state_dict(..., precision=INT8, amax=...)."""
+    (percentile of the) absolute maximum, or -- `method` = "entropy" | "mse" | "percentile" -- the range a |x| histogram over
+    all frames selects (export.HistogramCalibrator: the reference's QuantDescriptor(calib_method="histogram"), qat.py:91-126).
+    Feed the result to from_state_dict(..., precision=INT8, amax=...)."""
     torch = _torch()
     b = _export.EngineBuilder(sd, graph)
     names = [n for (n, _h, _w, _c, dtype, _f, _s) in b.buffers if dtype == _export.BUF_F16]
@@ -380,6 +382,8 @@ def calibrate_amax(sd: Dict[str, np.ndarray], graph: Optional[Graph], frames, de
             for x in frames:
                 eng.forward(torch.from_numpy(np.ascontiguousarray(x)).cuda(device))
                 yield {n: eng.read_buffer(n) for n in names}
-        return _export.calibrate(per_frame(), percentile)
+        if specs is not None:                      # several range selections from one pass (tools/int8_drift.py)
+            return _export.calibrate_all(per_frame(), specs)
+        return _export.calibrate(per_frame(), percentile, method)
     finally:
         eng.close()

@@ -551,19 +551,137 @@ class EngineBuilder:
             f.write(self.tobytes())
 
 
-def calibrate(named_buffers_per_frame, percentile: Optional[float] = None) -> Dict[str, float]:
+class HistogramCalibrator:
+    """Per-tensor |x| histogram + range selection, the role of pytorch-quantization's ``HistogramCalibrator`` that the
+    reference configures for activations AND weights (qat.py:91-126: ``QuantDescriptor(num_bits=8, calib_method="histogram",
+    axis=None)``; its docstring calls it "Histogram (Entropy) calibration"). That library is not available here and the
+    reference holds no calibrated value, so this is the build's OWN restatement of the published algorithm (parity
+    unpinned): 2048 bins of |x| whose range grows by whole bins when a later batch exceeds it; then one of
+      * ``entropy``    -- the threshold (from bin 128 on) whose 128-level re-quantised distribution has the smallest
+                          KL divergence from the clipped original (the TensorRT-style entropy calibration);
+      * ``mse``        -- the threshold whose int8 fake-quantisation of the bin centres has the smallest count-weighted
+                          squared error;
+      * ``percentile`` -- the |x| below which `percentile` percent of the values lie."""
+
+    def __init__(self, num_bins: int = 2048):
+        self.num_bins = num_bins
+        self.hist: Optional[np.ndarray] = None
+        self.edges: Optional[np.ndarray] = None
+
+    def collect(self, x: np.ndarray) -> None:
+        a = np.abs(np.asarray(x, dtype=np.float32)).reshape(-1)
+        amax = float(a.max()) if a.size else 0.0
+        if self.hist is None:
+            amax = max(amax, 1e-8)
+            self.hist, self.edges = np.histogram(a, bins=self.num_bins, range=(0.0, amax))
+            self.hist = self.hist.astype(np.float64)
+            return
+        if amax > self.edges[-1]:                      # grow the range by whole bins of the same width
+            width = self.edges[1] - self.edges[0]
+            extra = int(np.ceil((amax - self.edges[-1]) / width))
+            self.edges = np.concatenate([self.edges, self.edges[-1] + width * np.arange(1, extra + 1)])
+            self.hist = np.concatenate([self.hist, np.zeros(extra)])
+        h, _ = np.histogram(a, bins=self.edges)
+        self.hist += h
+
+    # -- range selection ------------------------------------------------------------------------------
+    def amax(self, method: str = "entropy", percentile: float = 99.99, start_bin: int = 128, stride: int = 1) -> float:
+        if self.hist is None:
+            raise ValueError("no data collected")
+        if method == "percentile":
+            cdf = np.cumsum(self.hist) / self.hist.sum()
+            idx = int(np.searchsorted(cdf, percentile / 100.0))
+            return float(self.edges[min(idx + 1, len(self.edges) - 1)])
+        if method == "mse":
+            return self._mse(start_bin, stride)
+        if method == "entropy":
+            return self._entropy(start_bin, stride)
+        raise ValueError(f"unknown calibration method {method!r}")
+
+    def _mse(self, start_bin: int, stride: int) -> float:
+        centers = (self.edges[1:] + self.edges[:-1]) / 2
+        counts = self.hist
+        best, arg = None, len(centers) - 1
+        for i in range(min(start_bin, len(centers) - 1), len(centers), stride):
+            amax = centers[i]
+            q = np.clip(np.rint(centers * (127.0 / amax)), -127, 127) * (amax / 127.0)
+            mse = float((((q - centers) ** 2) * counts).mean())
+            if best is None or mse < best:
+                best, arg = mse, i
+        return float(centers[arg])
+
+    def _entropy(self, start_bin: int, stride: int) -> float:
+        bins = self.hist.copy()
+        bins[0] = bins[1]
+        nbins = 128                                                  # 1 << (num_bits - 1): positive int8 levels
+        stop = len(bins)
+        if stop <= start_bin:
+            return float(self.edges[-1])
+        csum = np.concatenate([[0.0], np.cumsum(bins)])
+        total = csum[-1]
+        best, arg = None, stop
+        for i in range(start_bin, stop + 1, stride):
+            # reference: the first i bins with everything beyond folded into the last one
+            ref = bins[:i].copy()
+            ref[-1] += total - csum[i]
+            # candidate: the first i bins merged into 128 levels; a level's mass is spread evenly over its NON-EMPTY bins
+            level = (np.arange(i) * nbins) // i
+            nz = bins[:i] > 0
+            mass = np.bincount(level, weights=bins[:i], minlength=nbins)
+            cnt = np.bincount(level, weights=nz.astype(np.float64), minlength=nbins)
+            per = np.divide(mass, cnt, out=np.zeros(nbins), where=cnt > 0)
+            cand = np.where(nz, per[level], 0.0)
+            p = ref / ref.sum()
+            qsum = cand.sum()
+            if qsum <= 0:
+                continue
+            q = cand / qsum
+            m = p > 0
+            if np.any(m & (q <= 0)):
+                continue                                             # infinite divergence
+            kl = float(np.sum(p[m] * np.log(p[m] / q[m])))
+            if best is None or kl <= best:                           # ties: the LAST (largest) threshold, as the library's argmin over the reversed list
+                best, arg = kl, i
+        return float(self.edges[arg])
+
+
+def calibrate(named_buffers_per_frame, percentile: Optional[float] = None, method: Optional[str] = None) -> Dict[str, float]:
     """The build's own activation calibrator (the reference's lives in NVIDIA pytorch-quantization, qat.py:129-220,
     which is not available: parity unpinned). Input: an iterable of {buffer name: ndarray} (one dict per
     calibration frame, e.g. Engine.read_buffer() of an fp16/fp32 engine, or tests/emulate.py on CPU). Output:
-    {buffer name: amax}; amax = max |x| over all frames, or, with `percentile` (e.g. 99.99), the max over frames of
-    that percentile of |x| (a histogram-style clip of outliers)."""
-    amax: Dict[str, float] = {}
+    {buffer name: amax}.
+      method None / "max" : max |x| over all frames (with `percentile`: the max over frames of that per-frame percentile --
+                            round 1's calibrator);
+      "entropy" | "mse" | "percentile" : per-buffer |x| histogram over ALL frames (HistogramCalibrator above -- what the
+                            reference configures, qat.py:91-126), then that range selection (`percentile` defaults to 99.99)."""
+    if method in (None, "max"):
+        amax: Dict[str, float] = {}
+        for named in named_buffers_per_frame:
+            for name, arr in named.items():
+                a = np.abs(np.asarray(arr, dtype=np.float32))
+                v = float(a.max()) if percentile is None else float(np.percentile(a, percentile))
+                amax[name] = max(amax.get(name, 0.0), v)
+        return amax
+    cals: Dict[str, HistogramCalibrator] = {}
     for named in named_buffers_per_frame:
         for name, arr in named.items():
-            a = np.abs(np.asarray(arr, dtype=np.float32))
-            v = float(a.max()) if percentile is None else float(np.percentile(a, percentile))
-            amax[name] = max(amax.get(name, 0.0), v)
-    return amax
+            cals.setdefault(name, HistogramCalibrator()).collect(arr)
+    return {name: c.amax(method, 99.99 if percentile is None else percentile) for name, c in cals.items()}
+
+
+def calibrate_all(named_buffers_per_frame, specs) -> Dict[str, Dict[str, float]]:
+    """One pass over the calibration frames, several range selections: specs = {label: (method, percentile | None)}.
+    Returns {label: {buffer name: amax}} (tools/int8_drift.py compares them)."""
+    cals: Dict[str, HistogramCalibrator] = {}
+    mx: Dict[str, float] = {}
+    for named in named_buffers_per_frame:
+        for name, arr in named.items():
+            cals.setdefault(name, HistogramCalibrator()).collect(arr)
+            mx[name] = max(mx.get(name, 0.0), float(np.abs(np.asarray(arr)).max()))
+    out = {}
+    for label, (method, pct) in specs.items():
+        out[label] = dict(mx) if method == "max" else {n: c.amax(method, 99.99 if pct is None else pct) for n, c in cals.items()}
+    return out
 
 
 def export_engine(sd: Dict[str, np.ndarray], path: str, graph: Optional[Graph] = None,
