@@ -154,6 +154,12 @@ int unina_get_op_info(const unina_engine_t *e, int index, unina_op_info *info);
  * inside a fused block's launch). Used by bench.py's roofline leg. */
 int unina_profile_ops(unina_engine_t *e, int iters, float *ms_per_op, hipStream_t stream);
 
+/* The same for the post-process launches of a frame (each repetition replays the whole forward first): ms2[0] = decode
+ * launch (including the head output convs folded into it; ops the frame leaves out because of that report 0 in
+ * unina_profile_ops), ms2[1] = pair tiles + greedy scan + output launch (0 if the post-process is one launch). */
+int unina_profile_post(unina_engine_t *e, int iters, float conf_threshold, float iou_threshold, float conformal_q, float *ms2,
+                       hipStream_t stream);
+
 /* Tile-configuration control of the implicit-GEMM conv kernel (autotuning, tests). cfg = -1 restores the heuristic.
  * Returns UNINA_ERR_UNSUPPORTED if the configuration does not fit the op's shape. */
 int unina_conv_config_count(void);

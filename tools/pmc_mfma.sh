@@ -7,7 +7,7 @@ REPO=$(pwd)
 export TMPDIR=/tmp; cd /tmp
 rocprofv3 -L > "$REPO/gpurun_out/counters_list.txt" 2>&1
 python3 "$REPO/bench.py" --steps 50 --warmup 10 --no-cpu-baseline --latency-frames 5 --tune-cache /tmp/tune.json > /dev/null 2>&1
-for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES" "SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
   tag=$(echo $pass | cut -d' ' -f1)
   rm -rf "$REPO/gpurun_out/pmc_mfma_$tag"
   timeout -k 10 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$REPO/gpurun_out/pmc_mfma_$tag" -o pmc -- \

@@ -22,5 +22,8 @@ for k, cs in sorted(res.items()):
     busy, cu = o.get("SQ_VALU_MFMA_BUSY_CYCLES"), o.get("SQ_BUSY_CU_CYCLES")
     if busy is not None and cu:
         o["mfma_util_of_busy_cu_cycles"] = busy / (4.0 * cu)
+    gui = o.get("GRBM_GUI_ACTIVE")
+    if busy is not None and gui:                       # rocprofv3's MfmaUtil: MFMA-busy cycles / (GPU-active cycles x 1024 SIMDs)
+        o["mfma_util"] = busy / (gui * 1024.0)
     out[k] = o
 json.dump(out, sys.stdout, indent=1)

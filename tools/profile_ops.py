@@ -40,6 +40,8 @@ for i, o in enumerate(ops):
     print(f"{i:2d} {us:7.2f} {o['flops'] / ms_ / 1e9:6.1f} {o['bytes'] / ms_ / 1e6:6.0f} {o['grid']:5d}  "
           f"{o['m']:6d} {o['n']:4d} {o['k']:5d}  {o['kernel']:34s} {o['name'][:60]}")
 print(f"sum of ops: {tot * 1e3:.1f} us  ({g.macs() * 2 / tot / 1e9:.1f} TFLOP/s over the forward)")
+pd, pn = e.profile_post(a.iters)
+print(f"post-process: decode launch (+ folded head output convs) {pd * 1e3:.2f} us, pair tiles + scan + output {pn * 1e3:.2f} us")
 
 if a.sweep:
     cfgs = e.conv_configs()

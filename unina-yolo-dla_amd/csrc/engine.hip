@@ -372,9 +372,13 @@ int plan(unina_engine* e) {
       info.m = p.Ho * p.Wo; info.n = p.Co; info.k = 27;
       info.flops = 2.0 * info.m * info.n * 27;
       info.bytes = 4.0 * 3 * p.H * p.W + (double)dtype_size(odt) * info.m * p.Co;
-      snprintf(info.kernel, sizeof info.kernel, "stem_conv_kernel<%s,%d>", odt == kF32 ? "f32" : "f16", p.Co);
-      info.grid = (2 * info.m + 255) / 256;
-      info.block = 256;
+      {
+        LaunchDesc sl;
+        const bool tiled = stem_desc(p, &sl) == hipSuccess && sl.block.x == 128;
+        snprintf(info.kernel, sizeof info.kernel, "%s<%s,%d>", tiled ? "stem_tile_kernel" : "stem_conv_kernel", odt == kF32 ? "f32" : "f16", p.Co);
+        info.grid = tiled ? (int)sl.grid.x : (2 * info.m + 255) / 256;
+        info.block = tiled ? 128 : 256;
+      }
     } else if (d.kind == kOpSppfPool) {
       PoolParams& p = op.pp;
       const int dt = act_dtype_of(src.d.dtype);
@@ -1968,8 +1972,17 @@ int unina_profile_ops(unina_engine_t* e, int iters, float* ms_per_op, hipStream_
   hipEvent_t a, b;
   HIPCHK(e, hipEventCreate(&a));
   HIPCHK(e, hipEventCreate(&b));
+  PostParams pp;   // which head output convs the frame's decode launch computes itself (they are not launched in a frame)
+  fill_post_params(e, &pp, 0.5f, 0.45f, 0.1f, e->d_result->det, &e->d_result->count, &e->d_result->candidates, e->full_graph && e->use_graph);
+  auto folded = [&](int k) {
+    for (int h = 0; h < 3; ++h)
+      if (pp.mode == 2 && e->fold_op[h] == k && pp.h1[h] != nullptr) return true;
+    return false;
+  };
   for (size_t i = 0; i < e->ops.size(); ++i) {
-    if ((e->fuse && e->ops[i].fuse_role == 2) || e->ops[i].dual_absorbed) {
+    const PlannedOp& op = e->ops[i];
+    const bool dual_leader = op.dual_with >= 0 && !(e->fuse && op.fuse_role);
+    if ((e->fuse && op.fuse_role == 2) || op.dual_absorbed || (folded((int)i) && (!dual_leader || folded(op.dual_with)))) {
       ms_per_op[i] = 0.f;
       continue;
     }
@@ -1978,6 +1991,47 @@ int unina_profile_ops(unina_engine_t* e, int iters, float* ms_per_op, hipStream_
   }
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
+  return UNINA_OK;
+}
+
+// The post-process launches of a frame, timed like unina_profile_ops (HIP events on `stream`, each repetition replays the
+// whole forward first): ms2[0] = decode launch (with the folded head output convs), ms2[1] = pair tiles + scan + output
+// (0 when the post-process is one launch). Thresholds as given.
+int unina_profile_post(unina_engine_t* e, int iters, float conf, float iou, float q, float* ms2, hipStream_t stream) {
+  if (!e || !ms2 || iters < 1) return UNINA_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->bufs[e->images_buf].ptr && !e->camera_active) return fail(e, UNINA_ERR_STATE, "tensor 'images' is not bound");
+  if (e->plan_dirty) {
+    int rc = plan(e);
+    if (rc != UNINA_OK) return rc;
+  }
+  PostParams pp;
+  fill_post_params(e, &pp, conf, iou, q, e->d_result->det, &e->d_result->count, &e->d_result->candidates, true);
+  pp.done_flag = nullptr;
+  LaunchDesc d[2];
+  const int npost = postprocess_desc(pp, d);
+  if (npost < 1) return fail(e, UNINA_ERR_STATE, "post-process launch shape");
+  hipEvent_t ev[3];
+  for (auto& x : ev) HIPCHK(e, hipEventCreate(&x));
+  ms2[0] = ms2[1] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+    int rc = launch_all(e, stream);
+    if (rc != UNINA_OK) return rc;
+    for (int k = 0; k < npost; ++k) {
+      PostParams copy = pp;
+      void* args[] = {&copy};
+      HIPCHK(e, hipEventRecord(ev[k], stream));
+      HIPCHK(e, hipLaunchKernel(d[k].func, d[k].grid, d[k].block, args, d[k].shmem, stream));
+    }
+    HIPCHK(e, hipEventRecord(ev[npost], stream));
+    HIPCHK(e, hipEventSynchronize(ev[npost]));
+    for (int k = 0; k < npost; ++k) {
+      float ms = 0.f;
+      HIPCHK(e, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+      ms2[k] += ms / (float)iters;
+    }
+  }
+  for (auto& x : ev) (void)hipEventDestroy(x);
   return UNINA_OK;
 }
 

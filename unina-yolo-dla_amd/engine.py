@@ -47,7 +47,7 @@ _lib: Optional[C.CDLL] = None
 ABI_SYMBOLS = [
     "unina_load_engine", "unina_unload_engine", "unina_engine_input_dims", "unina_set_tensor_address",
     "unina_tensor_address", "unina_enqueue", "unina_infer", "unina_infer_bgra", "unina_infer_async", "unina_postprocess_async",
-    "unina_last_error", "unina_op_count", "unina_get_op_info", "unina_profile_ops", "unina_debug_read_buffer",
+    "unina_last_error", "unina_op_count", "unina_get_op_info", "unina_profile_ops", "unina_profile_post", "unina_debug_read_buffer",
     "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune", "unina_debug_post_stamps", "unina_debug_conv_stamps", "unina_debug_dual_stamps",
     "unina_set_fusion", "unina_fusion_groups", "unina_debug_fusable_groups",
     "create_norm_params_imagenet", "create_norm_params", "preprocess_bgra_resize", "preprocess_bgra", "preprocess_nv12",
@@ -83,6 +83,7 @@ def load_library() -> C.CDLL:
     L.unina_op_count.argtypes = [vp]
     L.unina_get_op_info.argtypes = [vp, ci, C.POINTER(OpInfo)]
     L.unina_profile_ops.argtypes = [vp, ci, C.POINTER(cf), vp]
+    L.unina_profile_post.argtypes = [vp, ci, cf, cf, cf, C.POINTER(cf), vp]
     L.unina_debug_read_buffer.argtypes = [vp, C.c_char_p, vp, C.c_size_t, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     L.unina_version.restype = C.c_char_p
     L.unina_conv_config_name.restype = C.c_char_p
@@ -287,6 +288,12 @@ class Engine:
         for i, d in enumerate(infos):
             d["ms"] = float(ms[i])
         return infos
+
+    def profile_post(self, iters: int = 20, conf_thr: float = 0.5, iou_thr: float = 0.45, conformal_q: float = 0.1, stream=None):
+        """(ms of the decode launch, ms of the pair-tile / scan / output launch) inside the frame sequence."""
+        ms = (C.c_float * 2)()
+        self._check(self.L.unina_profile_post(self.h, iters, conf_thr, iou_thr, conformal_q, ms, _stream_ptr(stream)))
+        return float(ms[0]), float(ms[1])
 
     def autotune(self, images=None, iters: int = 10, stream=None, cache: Optional[str] = None) -> None:
         """Pick the fastest tile configuration per conv op by timing on this GPU (results are unchanged).
