@@ -31,7 +31,8 @@ def test_norm_params_and_allocators(env):
     L.destroy_preprocess_stream(s)
 
 
-@pytest.mark.parametrize("src,dst", [((720, 1280), (640, 640)), ((480, 640), (640, 640)), ((64, 96), (64, 96))])
+@pytest.mark.parametrize("src,dst", [((720, 1280), (640, 640)), ((480, 640), (640, 640)), ((64, 96), (64, 96)),
+                                     ((50, 70), (33, 45))])   # (row tails: widths that are not multiples of the 4-pixel quads)
 def test_bgra_resize_and_plain_match_oracle(env, oracle_mod, src, dst):
     torch, L, engine = env
     rng = np.random.default_rng(11)
@@ -54,10 +55,10 @@ def test_bgra_resize_and_plain_match_oracle(env, oracle_mod, src, dst):
     assert L.preprocess_bgra(d_in.data_ptr(), out2.data_ptr(), sw, sh, sw * 4 - 4, norm, stream) != 0   # pitch too small
 
 
-def test_nv12_matches_oracle(env, oracle_mod):
+@pytest.mark.parametrize("h,w,pitch", [(360, 640, 768), (50, 70, 74)])   # (the second: row tails and an unaligned pitch)
+def test_nv12_matches_oracle(env, oracle_mod, h, w, pitch):
     torch, L, engine = env
     rng = np.random.default_rng(12)
-    h, w, pitch = 360, 640, 768
     y = rng.integers(0, 256, (h, pitch), dtype=np.uint8)
     uv = rng.integers(0, 256, (h // 2, pitch), dtype=np.uint8)
     dy, duv = torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda()
