@@ -873,6 +873,12 @@ __global__ __launch_bounds__(256) void conv_dual_head3x3_big4(const ConvParams p
   if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 4, 16, 1, false, 2>(pa, (int)blockIdx.x, na);
   else conv3x3_regq_body<8, 16, 64, 256, 4, 16, 1, false, 2>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
 }
+// experiment: 8 waves, two channel subtiles per wave for the P3 conv (2 x 4 waves: half the LDS reads per MFMA, twice the
+// weight fetches per workgroup), the P4 conv unchanged
+__global__ __launch_bounds__(512) void conv_dual_head3x3_big_w2a(const ConvParams pa, const ConvParams pb, int na) {
+  if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 16, 1, false, 2>(pa, (int)blockIdx.x, na);
+  else conv3x3_regq_body<8, 16, 64, 256, 8, 16, 1>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
+}
 // experiment: the 8-wave form with a 32-deep weight queue (twice the weight bytes in flight per CU)
 __global__ __launch_bounds__(512) void conv_dual_head3x3_big_d32(const ConvParams pa, const ConvParams pb, int na) {
   if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 32, 1>(pa, (int)blockIdx.x, na);
@@ -1120,7 +1126,7 @@ hipError_t conv_init() {
                         reinterpret_cast<const void*>(conv_dual_head3x3_w2), reinterpret_cast<const void*>(conv_dual_head3x3_i8),
                         reinterpret_cast<const void*>(conv_dual_head3x3_big), reinterpret_cast<const void*>(conv_dual_head3x3_big_i8),
                         reinterpret_cast<const void*>(conv_dual_head3x3_big4), reinterpret_cast<const void*>(conv_dual_head3x3_big_stamped),
-                        reinterpret_cast<const void*>(conv_dual_head3x3_big_d32),
+                        reinterpret_cast<const void*>(conv_dual_head3x3_big_d32), reinterpret_cast<const void*>(conv_dual_head3x3_big_w2a),
                         reinterpret_cast<const void*>(stem_conv3x3s2_kernel)}) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (e != hipSuccess) return e;
@@ -1276,8 +1282,9 @@ const DualKind kDual[] = {
     {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big_i8<regq i8,16x16,64,128 | regq i8,8x16,64,256>", conv_dual_head3x3_big_i8},
     {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 256, "conv_dual_head3x3_big4<regq 16x16,64,128,4w,wn2 | regq 8x16,64,256,4w,wn2>", conv_dual_head3x3_big4},
     {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big_d32<regq 16x16,64,128,d32 | regq 8x16,64,256,d32>", conv_dual_head3x3_big_d32},
+    {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big_w2a<regq 16x16,64,128,wn2 | regq 8x16,64,256>", conv_dual_head3x3_big_w2a},
 };
-constexpr int kDualKinds = 8;
+constexpr int kDualKinds = 9;
 }  // namespace
 
 int conv_dual_match(const ConvParams& a, const ConvParams& b) {
@@ -1293,7 +1300,7 @@ int conv_dual_match(const ConvParams& a, const ConvParams& b) {
   if (a.dtype != kF16 || b.dtype != kF16) return -1;
   static const bool w2 = getenv("UNINA_DUAL_W2") && getenv("UNINA_DUAL_W2")[0] == '1';
   static const int variant = getenv("UNINA_DUAL_4W") ? atoi(getenv("UNINA_DUAL_4W")) : 0;   // 1: four waves, wn 2; 2: queue depth 32
-  if (big && a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[4].cfg_a) && conv_config_valid(b, kDual[4].cfg_b)) return variant == 1 ? 6 : (variant == 2 ? 7 : 4);
+  if (big && a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[4].cfg_a) && conv_config_valid(b, kDual[4].cfg_b)) return variant == 1 ? 6 : (variant == 2 ? 7 : (variant == 3 ? 8 : 4));
   if (w2 && a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[2].cfg_a) && conv_config_valid(b, kDual[2].cfg_b)) return 2;
   if (a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[0].cfg_a) && conv_config_valid(b, kDual[0].cfg_b)) return 0;
   auto tiny = [](const ConvParams& p) {
