@@ -139,15 +139,12 @@ def main():
 
     def fence():
         if ring is not None:
-            ring.flush()
+            nxt = ring.flush()            # (a partly filled bank is gathered as it stands: exactly --steps frames are timed)
+            if nxt is not None:
+                next_frame[0] = nxt
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-
-    if world > 1 and (args.steps % GATHER_EVERY or args.warmup % GATHER_EVERY):
-        # the ring gathers whole banks: round both up so that every rank issues the same number of collectives
-        args.warmup = -(-args.warmup // GATHER_EVERY) * GATHER_EVERY
-        args.steps = -(-args.steps // GATHER_EVERY) * GATHER_EVERY
 
     def timed_block():
         fence()

@@ -87,7 +87,7 @@ def _ring_worker(rank, world, port, n_local, k, banks, q):
     half = (n_local // 2 // k) * k
     gather.run_frames(half, 2, ring, infer, streams)                  # two calls: the ring continues across them
     gather.run_frames(n_local - half, 2, ring, infer, streams, start=half)
-    ring.flush()
+    assert ring.flush() is None                          # n_local is a multiple of k: no partial bank
     ok = len(seen) == n_local * world and all(v == _fake_dets(f).tobytes() for f, v in seen.items())
     ok = ok and ring.gathers_issued == n_local // k
     # who waited for what: the comm stream waits for frame events only; an inference stream waits for a collective only
@@ -99,6 +99,14 @@ def _ring_worker(rank, world, port, n_local, k, banks, q):
     ok = ok and len(comm_waits) == n_local
     ok = ok and all(tag[0] == "gather" and why[0] == "bank reuse" for _st, tag, why in infer_waits)
     ok = ok and len(infer_waits) == n_local - banks * k                # none while the ring fills for the first time
+    # a run that is NOT a multiple of k: the partial bank is gathered by flush(), the next run continues at a bank boundary
+    seen.clear()
+    start = n_local
+    gather.run_frames(k + 2, 2, ring, infer, streams, start=start)
+    nxt = ring.flush()
+    ok = ok and nxt == start + 2 * k
+    got = {f: v for f, v in seen.items() if start * world <= f < (start + k + 2) * world}
+    ok = ok and len(got) == (k + 2) * world and all(v == _fake_dets(f).tobytes() for f, v in got.items())
     q.put((rank, ok, len(infer_waits), len(comm_waits)))
     dist.barrier()
     dist.destroy_process_group()

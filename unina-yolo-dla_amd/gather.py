@@ -146,6 +146,7 @@ class SlotRing:
         self.gather_done = [None] * self.banks
         self.pending = [None] * self.banks          # (first frame index of the bank) awaiting consumption
         self.gathers_issued = 0
+        self._last_commit = -1
 
     def slot(self, i, stream):
         """Slot tensor for frame i (rank-local index); `stream` will write it."""
@@ -158,6 +159,7 @@ class SlotRing:
     def commit(self, i, stream):
         """Frame i has been enqueued on `stream`. Issues the bank's gather when the bank is complete."""
         b, s = (i // self.k) % self.banks, i % self.k
+        self._last_commit = i
         self.frame_events[b].append(self.rt.record(stream, ("frame", i)))
         if s == self.k - 1:
             self._consume(b)
@@ -177,10 +179,26 @@ class SlotRing:
             self.pending[b] = None
 
     def flush(self):
-        """Complete every outstanding gather and hand it over (end of the stream of frames)."""
+        """Complete every outstanding gather and hand it over (end of a stream of frames). A bank that is only partly
+        filled (the frame count was not a multiple of k) is gathered as it stands -- every rank has the same number of
+        frames, so every rank takes part; the slots past the last frame hold older frames and are the consumer's to ignore.
+        Returns the index the next frame must continue at (the start of the next bank)."""
+        nxt = None
+        for b in range(self.banks):
+            if self.frame_events[b]:
+                first = self._last_commit - len(self.frame_events[b]) + 1
+                self._consume(b)
+                ev = self.rt.all_gather(self.gathered[b], self.local[b], self.group, self.frame_events[b])
+                ev.tag = ("gather", b, first)
+                self.gather_done[b] = ev
+                self.pending[b] = first
+                self.frame_events[b] = []
+                self.gathers_issued += 1
+                nxt = (self._last_commit // self.k + 1) * self.k
         order = sorted((f, b) for b, f in enumerate(self.pending) if f is not None)
         for _f, b in order:
             self._consume(b)
+        return nxt
 
 
 def run_frames(n_frames, n_streams, ring, infer, streams, start=0):
