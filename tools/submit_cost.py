@@ -1,5 +1,5 @@
 import sys, time, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import unina_yolo_dla_amd as u
 from unina_yolo_dla_amd.engine import Engine
 g = u.graph.Graph()

@@ -284,6 +284,9 @@ __device__ __forceinline__ void load_patch(unsigned char* lds_img, const void* s
                                    // A/B at 2 frames in flight: 8 270-8 470 frames/s with LDS-DMA against 8 130-8 200 through registers;
                                    // the register-queue 3x3 kernels (conv_igemm.hip) go the other way: 8 240-8 360 against 8 130-8 170)
 #endif
+#ifndef UNINA_BLOCK_DIRECT_STORE
+#define UNINA_BLOCK_DIRECT_STORE 0
+#endif
 // The same patch through REGISTERS: plain 16-byte global loads (all requested back to back: ~16 cycles of issue each, against
 // the 60-185 cycles an LDS-DMA piece costs the issuing wave), then ds_write_b128 once they have landed -- the compiler's
 // counted s_waitcnt vmcnt leaves whatever was requested after them (the weight queue) in flight. Same LDS image.

@@ -139,7 +139,13 @@ __device__ __forceinline__ void load_epi_consts(const ConvSeg& sg, int n_first, 
   }
 }
 
-template <typename T, int BM, int BN, int WM_T, int WN_T, typename PixToM>
+#ifndef UNINA_REGQ_DIRECT_STORE
+#define UNINA_REGQ_DIRECT_STORE 1   // same-box A/B: 18.3 vs 19.1 us per head pair, -5 us serial latency, +0.5-1.5 % frames/s
+#endif
+// DIRECT (register-queue 3x3 kernels, fp16 destinations without the x2 upsample): every lane stores its 4 channels (8 bytes)
+// straight from the accumulators -- 32-byte runs per pixel and wave instead of full rows, but no LDS staging and NO
+// workgroup barrier: a wave that has finished its K loop stores and retires without waiting for the others.
+template <typename T, int BM, int BN, int WM_T, int WN_T, typename PixToM, bool DIRECT = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg& sg,
                                               typename Elem<T>::acc_t (&acc)[WN_T][WM_T], const EpiConsts<WN_T>& ec,
                                               int wm, int wn, int nb0, int l15, int lq, PixToM pix_to_m,
@@ -149,7 +155,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg
   const int esz = od == kF32 ? 4 : (od == kF16 ? 2 : 1);
   const int rowb = BN * esz + 16;              // padded LDS row (bytes)
   const int n_w0 = wn * (WN_T * 16);           // tile-local first channel of this wave
-  const bool planar = sg.dst_planar != nullptr;
+  const bool direct = DIRECT && od == kF16 && !sg.up2 && sg.dst_planar == nullptr;
+  const bool planar = sg.dst_planar != nullptr || direct;
   if (!planar) __syncthreads();                // every wave is done reading the operand buffers: reuse them
 #pragma unroll
   for (int j = 0; j < WN_T; ++j) {
@@ -187,7 +194,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg
           for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf((float)(signed char)(rv >> (8 * r)), p.res_scale, v[r]);
         }
       }
-      if (planar) {
+      if (direct) {
+        half4 hv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[r] = (half_t)v[r];
+        *reinterpret_cast<half4*>(static_cast<half_t*>(sg.dst) + (size_t)m * sg.dst_ld + n) = hv;
+      } else if (planar) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (n + r < sg.n_count) sg.dst_planar[(size_t)(n + r) * p.M + m] = v[r];
@@ -818,12 +830,12 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
   });
 
   if constexpr (STAMPS) stamp_b(p, 3, bid, nwg);
-  conv_epilogue<T, BM, BN, WM_T, WN>(p, sg, acc, ec, wm, wn, nb0, l15, lq,
-                                         [&](int pl) {
-                                           const int oy = ty0 + pl / TW, ox = tx0 + pl % TW;
-                                           return (pl < BM && oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
-                                         },
-                                         conv_smem, NT);
+  auto pix_to_m = [&](int pl) {
+    const int oy = ty0 + pl / TW, ox = tx0 + pl % TW;
+    return (pl < BM && oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
+  };
+  conv_epilogue<T, BM, BN, WM_T, WN, decltype(pix_to_m), (UNINA_REGQ_DIRECT_STORE != 0 && sizeof(T) == 2)>(p, sg, acc, ec, wm, wn, nb0, l15, lq, pix_to_m,
+                                                                                                       conv_smem, NT);
   if constexpr (STAMPS) stamp_b(p, 4, bid, nwg);
 }
 
