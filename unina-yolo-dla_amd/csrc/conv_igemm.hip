@@ -139,6 +139,9 @@ __device__ __forceinline__ void load_epi_consts(const ConvSeg& sg, int n_first, 
   }
 }
 
+#ifndef UNINA_GLDS_DIRECT_STORE
+#define UNINA_GLDS_DIRECT_STORE 1   // conv_glds too: same-box A/B +1-2 % frames/s (8 400-8 570 vs 8 300-8 400), latency unchanged
+#endif
 #ifndef UNINA_REGQ_DIRECT_STORE
 #define UNINA_REGQ_DIRECT_STORE 1   // same-box A/B: 18.3 vs 19.1 us per head pair, -5 us serial latency, +0.5-1.5 % frames/s
 #endif
@@ -438,8 +441,8 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, int bid, int
   wait_vmcnt<0>();  // drain the dummy tail before the wave retires
 
   // ---- epilogue ----
-  conv_epilogue<T, BM, BN, WM_T, WN_T>(p, sg, acc, ec, wm, wn, nb0, l15, lq,
-                                       [&](int pl) { const int m = m_blk + pl; return m < p.M ? m : -1; }, conv_smem);
+  auto pix_to_m = [&](int pl) { const int m = m_blk + pl; return m < p.M ? m : -1; };
+  conv_epilogue<T, BM, BN, WM_T, WN_T, decltype(pix_to_m), (UNINA_GLDS_DIRECT_STORE != 0 && sizeof(T) == 2)>(p, sg, acc, ec, wm, wn, nb0, l15, lq, pix_to_m, conv_smem);
 }
 
 template <typename T, int BM, int BN, int BK, int WAVES_M, int WAVES_N, int STAGES>
