@@ -204,6 +204,9 @@ int unina_debug_conv_stamps(unina_engine_t *e, int op_index, long long *out5, hi
  * layers): out16[0..7] = stamps of conv A's mid workgroup, out16[8..15] = conv B's (each: start, loads issued, patch
  * landed, K loop done, stores issued, 2 x 100 MHz reference). UNINA_ERR_ARG if the op does not lead such a launch. */
 int unina_debug_dual_stamps(unina_engine_t *e, int op_index, long long *out16, hipStream_t stream);
+/* Debug: the same launch with every workgroup's start / end on the 100 MHz wall clock (out[2*i], out[2*i+1]); returns the
+   grid size or a negative error code. */
+int unina_debug_dual_timeline(unina_engine_t* e, int op_index, long long* out, int cap, hipStream_t stream);
 
 /* Library/build identification: "unina_mi355 <version> gfx950". */
 const char *unina_version(void);

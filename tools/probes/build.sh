@@ -1,0 +1,11 @@
+#!/bin/bash
+# Stand-alone micro-benchmarks behind the design decisions of DESIGN.md 4.2 (results: profiles/r02/v20_probe_*.txt).
+#   ifetch_probe : is straight-line (fully unrolled) MFMA code slower than a loop?        -> no (16.8 cold / 15.9 warm cycles per MFMA)
+#   mix_probe    : issue cost of ds_read_b128 / address VALU ops between MFMAs, one wave per SIMD
+#   ingest_probe : L2 -> CU bytes per clock against waves per workgroup, workgroups in flight, L2 hits / misses
+#   l2warm_probe : does an L2 warm-up by the previous kernel survive the kernel boundary?  -> yes
+set -e
+cd "$(dirname "$0")"
+for p in ifetch_probe mix_probe ingest_probe l2warm_probe; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -ftemplate-depth=2048 -o $p $p.hip
+done

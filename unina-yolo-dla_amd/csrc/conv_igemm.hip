@@ -43,13 +43,15 @@ typedef float floatx4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void tile_of_block(const ConvParams& p, int orig, int nwg, int* bx, int* by) {
   const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
   const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  if (p.xcd_m_major) {   // an XCD owns a contiguous range of PIXEL tiles (all channel tiles): its L2 holds its share of the input
-    *bx = fast_div(v, p.gn_magic);
-    *by = v - *bx * p.grid_n;
-  } else {               // ... of CHANNEL tiles (all pixel tiles): its L2 holds its share of the weights
-    *by = fast_div(v, p.gm_magic);
-    *bx = v - *by * p.grid_m;
-  }
+  // xcd_m_major: an XCD owns a contiguous range of PIXEL tiles (all channel tiles): its L2 holds its share of the input;
+  // otherwise of CHANNEL tiles (all pixel tiles): its L2 holds its share of the weights.
+  // (Selects, not two branches storing through the pointers in swapped order: the compiler turned those into a
+  // dynamically indexed private array -- a scratch store + load in every conv kernel's prologue, and tile indices in VGPRs.)
+  const bool mm = p.xcd_m_major != 0;
+  const int major = fast_div(v, mm ? p.gn_magic : p.gm_magic);
+  const int minor = v - major * (mm ? p.grid_n : p.grid_m);
+  *bx = mm ? major : minor;
+  *by = mm ? minor : major;
 }
 
 __device__ __forceinline__ void stamp_entry(const ConvParams& p, long long t) {
@@ -69,6 +71,11 @@ __device__ __forceinline__ void stamp_b(const ConvParams& p, int k, int bid, int
     p.stamps[k] = __builtin_amdgcn_s_memtime();
     if (k == 0 || k == 4) p.stamps[5 + (k >> 2)] = wall_clock64();
   }
+}
+
+// debug: every workgroup's start / end on the 100 MHz wall clock (dispatch ramp and tail of a launch)
+__device__ __forceinline__ void stamp_wg(const ConvParams& p, int which) {
+  if (p.wg_times && threadIdx.x == 0) p.wg_times[2 * blockIdx.x + which] = wall_clock64();
 }
 
 // Element-type traits. A 1-KiB fragment block is always 16 rows x 4 chunks of 16 bytes:
@@ -742,7 +749,7 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
   constexpr int NS = BN / 16 / WN, WVM = NW / NS, MS = (BM + 15) / 16, WM_T = (MS + WVM - 1) / WVM;   // NS = waves along the channels
   static_assert((BN / 16) % WN == 0 && NW % NS == 0 && WM_T >= 1 && KB * WN >= D, "tile");
 
-  if constexpr (STAMPS) stamp_b(p, 0, bid, nwg);
+  if constexpr (STAMPS) { stamp_b(p, 0, bid, nwg); stamp_wg(p, 0); }
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wid / NS, wn = wid % NS;
@@ -839,7 +846,7 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
   };
   conv_epilogue<T, BM, BN, WM_T, WN, decltype(pix_to_m), (UNINA_REGQ_DIRECT_STORE != 0 && sizeof(T) == 2)>(p, sg, acc, ec, wm, wn, nb0, l15, lq, pix_to_m,
                                                                                                        conv_smem, NT);
-  if constexpr (STAMPS) stamp_b(p, 4, bid, nwg);
+  if constexpr (STAMPS) { stamp_b(p, 4, bid, nwg); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_wg(p, 1); }
 }
 
 template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, int WN = 1, typename T = half_t>
@@ -847,6 +854,153 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
   conv3x3_regq_body<TH, TW, BN, CIN, NW, D, S, false, WN, T>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// ============================================================================================ 3x3 weights-stationary kernel
+// 3x3 / stride 1 / pad 1, fp16, ReLU, fp16 NHWC destination. The register-queue kernel above reads one activation
+// fragment from LDS per MFMA and is bound by exactly that (profiles/r02/pmc_mfma.json: LDS busy = the whole K loop), and
+// two of its waves fetch every weight block. Here a wave owns ONE 16-channel subtile and keeps ALL of its K/32 weight
+// blocks in registers (Cin 128: 144, Cin 256: 288 of the 512 a lone wave per SIMD may use), and walks DOWN the patch rows:
+// the fragment of patch row rho (shifted by kx, channel block cb) feeds the three output rows rho, rho-1, rho-2 (taps
+// ky = 0, 1, 2), so LDS is read once per ~3 MFMAs, every weight block is fetched once per workgroup, and only four
+// accumulators are live (a row is converted and stored while the next ones are being accumulated). Each output row still
+// receives its products in the order ky, kx, cb from a zero accumulator, i.e. the K order of every other conv kernel:
+// results are bit-identical.
+template <int TH, int CIN, int NW, bool STAMPS = false>
+__device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, int nwg) {
+  typedef Elem<half_t> E;
+  typedef E::frag frag;
+  constexpr int TW = 16, R0W = TW + 2, R0H = TH + 2, NT = NW * 64, CB = CIN / 32, KB = 9 * CB, BN = NW * 16;
+  constexpr int STEPS = R0H * 3 * CB, PF = 4;     // (rho, kx, cb) steps; LDS fragments are requested PF steps ahead
+  // LDS patch image: pixel pitch = Cin*2 + 16 bytes, NO xor swizzle. The pad makes the 16 pixels of a fragment read hit 16
+  // different bank groups, and the address of (rho, kx, cb) is lane_base + a compile-time constant: the ds_read takes it as
+  // its immediate offset. The K loop is ISSUE-bound (tools/probes/mix_probe.hip: an MFMA holds the SIMD's vector issue
+  // for 8 of its 16 cycles, a ds_read_b128 for ~16, every VALU op for 4): with the swizzled image's 2-3 address ops per
+  // fragment it ran at 28 cycles per MFMA; three MFMAs + one ds_read + one s_waitcnt fit the 48.
+  constexpr int PITCH = CIN * 2 + 16, SPLIT = 60 * 1024;
+  if constexpr (STAMPS) { stamp_b(p, 0, bid, nwg); stamp_wg(p, 0); }
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  int bx, by;
+  tile_of_block(p, bid, nwg, &bx, &by);
+  const int sidx = (p.nseg > 1 && by >= p.seg[1].tile0) ? 1 : 0;
+  const ConvSeg& sg = p.seg[sidx];
+  const int n_pad = (sg.n_count + 15) & ~15;
+  const int nb0 = (by - sg.tile0) * BN;
+  const int tiles_x = (p.Wo + TW - 1) / TW;
+  const int tyi = fast_div(bx, p.tx_magic), txi = bx - tyi * tiles_x;
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+
+  int nsub = (nb0 >> 4) + wid;
+  nsub = nsub * 16 < n_pad ? nsub : (n_pad >> 4) - 1;   // tail subtile: clamp (never stored)
+  const unsigned char* wptr = static_cast<const unsigned char*>(sg.w) + (size_t)nsub * KB * 1024 + (4 * l15 + (lq ^ swz_g(l15))) * 16;
+  frag w[KB];
+  const int n = nb0 + wid * 16 + lq * 4;                // slice-relative first channel of this lane's 4 outputs
+  const bool n_ok = n < sg.n_count;
+  const floatx4 bias = *reinterpret_cast<const floatx4*>(sg.bias + (n_ok ? n : 0));
+  // tap row ky = 0 first: the patch (requested next) and these are all the first patch row needs
+  static_for<0, 3 * CB>([&](auto g) { w[decltype(g)::value] = *reinterpret_cast<const frag*>(wptr + decltype(g)::value * 1024); });
+  asm volatile("" ::: "memory");
+  // the patch through registers (plain loads, then ds_write): with LDS-DMA in the mix hipcc's wait-count pass sees two kinds
+  // of vector-memory events in flight and turns EVERY s_waitcnt into vmcnt(0) -- the first MFMA would wait for all K/32
+  // weight blocks. With plain loads only, its counted vmcnt lets the patch be committed while the weight rows ky = 1, 2 are
+  // still in flight and each block's first MFMA waits for exactly that block.
+  // (buffer loads: a slot outside the image -- the conv's zero padding -- or past the patch gets an out-of-range offset and the
+  // range check returns zeros: no branch around a load, no select on loaded data, nothing that makes the compiler wait early)
+  constexpr int nchx = CIN / 8, nslots = R0H * R0W * nchx, PITER = (nslots + NT - 1) / NT;
+  typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+  uintx4 pv[PITER];
+  __builtin_amdgcn_sched_barrier(0);   // request order = the order things are needed in: ky = 0 blocks, patch, ky = 1, 2 blocks
+  {
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.H * p.W * p.src_ld * 2, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < PITER; ++it) {
+      const int sl = it * NT + (int)threadIdx.x;
+      const int r = sl / nchx, cs = sl - r * nchx;
+      const int ry = r / R0W, rx = r - ry * R0W;
+      const int iy = ty0 - 1 + ry, ix = tx0 - 1 + rx;
+      const bool in = sl < nslots && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const unsigned off = (unsigned)(((iy * p.W + ix) * p.src_ld + sg.src_coff) * 2 + (cs << 4));
+      pv[it] = __builtin_amdgcn_raw_buffer_load_b128(srs, in ? off : 0x40000000u, 0, 0);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  static_for<3 * CB, KB>([&](auto g) {   // (pinned one by one: issue order = order of first use, so the counted waits are exact)
+    w[decltype(g)::value] = *reinterpret_cast<const frag*>(wptr + decltype(g)::value * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  if constexpr (STAMPS) stamp_b(p, 1, bid, nwg);
+#pragma unroll
+  for (int it = 0; it < PITER; ++it) {
+    const int sl = it * NT + (int)threadIdx.x;
+    const int r = sl / nchx, cs = sl - r * nchx;
+    if (sl < nslots) *reinterpret_cast<uintx4*>(conv_smem + r * PITCH + cs * 16) = pv[it];
+  }
+  lds_barrier();
+  if constexpr (STAMPS) stamp_b(p, 2, bid, nwg);
+
+  // destination through a buffer descriptor: lanes outside the image / past the slice get an out-of-range offset and
+  // the range check drops their store -- no exec masking, the whole K loop stays one basic block
+  const unsigned rowb = (unsigned)(p.Wo * sg.dst_ld * 2);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(sg.dst, 0, (int)((unsigned)p.Ho * rowb), 0x00020000);
+  const bool lane_ok = n_ok && tx0 + l15 < p.Wo;
+  const unsigned voff0 = lane_ok ? (unsigned)(((ty0 * p.Wo + tx0 + l15) * sg.dst_ld + n) * 2) : 0x40000000u;
+
+  const unsigned lo0 = (unsigned)(l15 * PITCH + lq * 16);
+  unsigned lo1 = lo0 + SPLIT;                     // second base: ds offsets are 16 bits
+  asm volatile("" : "+v"(lo1));                   // (opaque, or the compiler folds it back into lo0 + a too-large constant)
+  auto bfrag = [&](auto sc) {
+    constexpr int s = decltype(sc)::value, rho = s / (3 * CB), kx = (s / CB) % 3, cb = s % CB;
+    constexpr int imm = (rho * R0W + kx) * PITCH + cb * 64;
+    if constexpr (imm < 65536 - 16) return *reinterpret_cast<const frag*>(conv_smem + lo0 + imm);
+    else return *reinterpret_cast<const frag*>(conv_smem + lo1 + (imm - SPLIT));
+  };
+  frag b[PF + 1];
+  static_for<0, PF>([&](auto sc) { b[decltype(sc)::value] = bfrag(sc); });
+  floatx4 acc[4];
+  auto store_row = [&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    floatx4 v = acc[r & 3] + bias;
+    half4 hv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hv[e] = (half_t)(v[e] > 0.f ? v[e] : 0.f);
+    typedef float floatx2 __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs, voff0 + (unsigned)r * rowb, 0, 0);
+  };
+  static_for<0, STEPS>([&](auto sc) {
+    constexpr int s = decltype(sc)::value, rho = s / (3 * CB), kx = (s / CB) % 3, cb = s % CB;
+    if constexpr (s + PF < STEPS) b[(s + PF) % (PF + 1)] = bfrag(std::integral_constant<int, s + PF>{});
+    if constexpr (kx == 0 && cb == 0 && rho < TH) acc[rho & 3] = floatx4{0.f, 0.f, 0.f, 0.f};
+    static_for<0, 3>([&](auto kyc) {
+      constexpr int ky = decltype(kyc)::value, r = rho - ky;
+      if constexpr (r >= 0 && r < TH) acc[r & 3] = E::mma(w[(ky * 3 + kx) * CB + cb], b[s % (PF + 1)], acc[r & 3]);
+    });
+    // row rho-3 was completed by the previous patch row: convert and store it in the shadow of this row's MFMAs
+    if constexpr (kx == 1 && cb == 0 && rho >= 3) store_row(std::integral_constant<int, rho - 3>{});
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  if constexpr (STAMPS) stamp_b(p, 3, bid, nwg);
+  store_row(std::integral_constant<int, TH - 1>{});
+  if constexpr (STAMPS) { stamp_b(p, 4, bid, nwg); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_wg(p, 1); }
+}
+
+template <int TH, int CIN, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_ws(const ConvParams p) {
+  conv3x3_ws_body<TH, CIN, NW>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// the pair on the weights-stationary kernel: 4 waves, ONE wave per SIMD (Cin 256 keeps 288 weight registers per lane).
+// Conv B's workgroups (P4: twice the weight bytes per workgroup, the longer life) take the FIRST block ids: they are
+// dispatched first. (Block ids only decide placement: `nb` = conv B's workgroup count.)
+__global__ __launch_bounds__(256) void conv_dual_head3x3_ws(const ConvParams pa, const ConvParams pb, int nb) {
+  if ((int)blockIdx.x < nb) conv3x3_ws_body<8, 256, 4>(pb, (int)blockIdx.x, nb);
+  else conv3x3_ws_body<16, 128, 4>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
+}
+__global__ __launch_bounds__(256) void conv_dual_head3x3_ws_stamped(const ConvParams pa, const ConvParams pb, int nb) {
+  if ((int)blockIdx.x < nb) conv3x3_ws_body<8, 256, 4, true>(pb, (int)blockIdx.x, nb);
+  else conv3x3_ws_body<16, 128, 4, true>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
+}
+
+#ifndef UNINA_CONV_PROBE   // (ISA probe builds stop here: tools/isa_probe.sh compiles only the kernels above)
 // backbone.stem -> backbone.stage1_conv as ONE launch: the 3x3/s2 conv's input patch is the stem's output, computed in
 // place (stem_patch) instead of being written to HBM by one launch and DMA'd back by the next (6.6 MB each way at 640^2).
 struct StemConvParams {
@@ -880,25 +1034,9 @@ __global__ __launch_bounds__(512) void conv_dual_head3x3_big(const ConvParams pa
   if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 16, 1>(pa, (int)blockIdx.x, na);
   else conv3x3_regq_body<8, 16, 64, 256, 8, 16, 1>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
 }
-// The same tiles on FOUR waves (2 along the channels x 2 along the pixels, two channel subtiles per wave): every activation
-// fragment read from LDS feeds two MFMAs, so the LDS array -- which the 8-wave form saturates at exactly the MFMA rate, one
-// ds_read_b128 per MFMA -- runs at half load; the L2 -> register weight traffic per workgroup is unchanged (4 waves x 2
-// subtiles instead of 8 x 1).
-__global__ __launch_bounds__(256) void conv_dual_head3x3_big4(const ConvParams pa, const ConvParams pb, int na) {
-  if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 4, 16, 1, false, 2>(pa, (int)blockIdx.x, na);
-  else conv3x3_regq_body<8, 16, 64, 256, 4, 16, 1, false, 2>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
-}
-// experiment: 8 waves, two channel subtiles per wave for the P3 conv (2 x 4 waves: half the LDS reads per MFMA, twice the
-// weight fetches per workgroup), the P4 conv unchanged
-__global__ __launch_bounds__(512) void conv_dual_head3x3_big_w2a(const ConvParams pa, const ConvParams pb, int na) {
-  if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 16, 1, false, 2>(pa, (int)blockIdx.x, na);
-  else conv3x3_regq_body<8, 16, 64, 256, 8, 16, 1>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
-}
-// experiment: the 8-wave form with a 32-deep weight queue (twice the weight bytes in flight per CU)
-__global__ __launch_bounds__(512) void conv_dual_head3x3_big_d32(const ConvParams pa, const ConvParams pb, int na) {
-  if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 32, 1>(pa, (int)blockIdx.x, na);
-  else conv3x3_regq_body<8, 16, 64, 256, 8, 32, 1>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
-}
+// (Tried on these tiles and dropped, same-box A/B in DESIGN.md 7: four waves with two channel subtiles each, 30 us per pair;
+// a 32-deep weight queue, 21-22 us; two subtiles per wave for the P3 conv only, 21 us; 128-channel workgroup tiles, slower
+// than the 64-channel ones. The weights-stationary pair below replaced the search.)
 // debug twin of conv_dual_head3x3_big with in-kernel phase stamps (unina_debug_dual_stamps)
 __global__ __launch_bounds__(512) void conv_dual_head3x3_big_stamped(const ConvParams pa, const ConvParams pb, int na) {
   if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 16, 1, false, 1, half_t, true>(pa, (int)blockIdx.x, na);
@@ -907,12 +1045,6 @@ __global__ __launch_bounds__(512) void conv_dual_head3x3_big_stamped(const ConvP
 __global__ __launch_bounds__(512) void conv_dual_head3x3_big_i8(const ConvParams pa, const ConvParams pb, int na) {
   if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 16, 1, false, 1, signed char>(pa, (int)blockIdx.x, na);
   else conv3x3_regq_body<8, 16, 64, 256, 8, 16, 1, false, 1, signed char>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
-}
-// Variant with 128-channel workgroup tiles and two subtiles per wave (half the LDS fragment reads per MFMA): 100 + 100
-// workgroups, one per CU.
-__global__ __launch_bounds__(512) void conv_dual_head3x3_w2(const ConvParams pa, const ConvParams pb, int na) {
-  if ((int)blockIdx.x < na) conv3x3_regq_body<8, 16, 128, 128, 8, 16, 1, false, 2>(pa, (int)blockIdx.x, na);
-  else conv3x3_regq_body<8, 8, 128, 256, 8, 16, 1, false, 2>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
 }
 __global__ __launch_bounds__(256) void conv_dual_head1x1(const ConvParams pa, const ConvParams pb, int na) {
   if ((int)blockIdx.x < na) conv_glds_body<half_t, 128, 16, 64, 4, 1, 4>(pa, (int)blockIdx.x, na);
@@ -931,6 +1063,7 @@ struct CfgInfo {
   int cin = 0;         // register-queue kernel: the input channel count it is instantiated for (0 = any)
   int nthreads = 256;
   int stride = 1;      // register-queue kernel: conv stride it is instantiated for
+  bool ws = false;     // weights-stationary 3x3 kernel: fp16 NHWC destination, ReLU, no residual / upsample / planar output
 };
 
 constexpr size_t stage_bytes(int bm, int bn) { return (size_t)bm * (bn * 4 + 16); }  // epilogue staging tile (fp32 worst case)
@@ -963,6 +1096,9 @@ constexpr size_t smem_of() {
 #define REGQI2(TH, TW, BN, CIN, NW, D)                                                               \
   {(TH) * (TW), BN, 32, 3, "conv3x3_regq<i8," #TH "x" #TW "," #BN "," #CIN "," #NW "w,s2>",              \
    conv3x3_regq<TH, TW, BN, CIN, NW, D, 2, 1, signed char>, 0, TH, TW, CIN, (NW) * 64, 2}
+#define WS(TH, CIN, NW)                                                                              \
+  {(TH) * 16, (NW) * 16, 32, 3, "conv3x3_ws<f16," #TH "x16," #CIN "," #NW "w>",                          \
+   conv3x3_ws<TH, CIN, NW>, 0, TH, 16, CIN, (NW) * 64, 1, true}
 #define NOCFG {0, 0, 0, 0, "n/a", nullptr, 0, 0, 0, -1, 0, 0}
 
 // [dtype][config]; BK is in fp16-equivalent k (KSUB = BK/32 fragment blocks): a K-step covers BK channels in fp16
@@ -1024,6 +1160,8 @@ const CfgInfo kCfg[3][kCfgCount] = {
         REGQW(8, 8, 128, 256, 8, 16),                 // kCfgRegqW8x8n128c256
         REGQ(16, 16, 64, 128, 8, 16),                 // kCfgRegq16x16n64c128  (P3 head layers, one workgroup per CU with the next)
         REGQ(8, 16, 64, 256, 8, 16),                  // kCfgRegq8x16n64c256   (P4 head layers)
+        WS(16, 128, 4),                               // kCfgWs16x16n64c128    (P3 head layers, weights-stationary)
+        WS(8, 256, 4),                                // kCfgWs8x16n64c256     (P4 head layers, weights-stationary)
     },
     {
         CFG(float, "f32", 64, 64, 64, 2, 2, 4),
@@ -1056,6 +1194,7 @@ const CfgInfo kCfg[3][kCfgCount] = {
         CFG(float, "f32", 64, 64, 128, 2, 2, 4),
         NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,     // register-queue kernels: fp16 / int8 only
         NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
+        NOCFG, NOCFG,
     },
     {
         CFG(signed char, "i8", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
@@ -1102,6 +1241,7 @@ const CfgInfo kCfg[3][kCfgCount] = {
         NOCFG, NOCFG,
         REGQI(16, 16, 64, 128, 8, 16),                // kCfgRegq16x16n64c128
         REGQI(8, 16, 64, 256, 8, 16),                 // kCfgRegq8x16n64c256
+        NOCFG, NOCFG,
     },
 };
 #undef CFG
@@ -1112,6 +1252,7 @@ const CfgInfo kCfg[3][kCfgCount] = {
 #undef REGQI
 #undef REGQI2
 #undef NOCFG
+#undef WS
 
 inline int block_k(int dtype) { return dtype == kF32 ? 16 : (dtype == kI8 ? 64 : 32); }
 inline int kstep_of(const ConvParams& p, const CfgInfo& c) { return (c.bk / 32) * block_k(p.dtype); }
@@ -1121,6 +1262,7 @@ inline size_t smem_for(const ConvParams& p, const CfgInfo& c) {
   if (c.cin) {  // register-queue kernel: patch (+ < 1 KiB overrun of its last DMA instruction) or the epilogue staging tile
     const size_t ph = c.stride * (c.th - 1) + 3, pw = c.stride * (c.tw - 1) + 3;
     const size_t patch = ((ph * pw * c.cin * esize(p) + 1023) & ~(size_t)1023) + 1024;
+    if (c.ws) return ph * pw * (c.cin * 2 + 16);   // padded pixel pitch, no swizzle (conv3x3_ws_body)
     return max_sz(patch, stage_bytes((c.bm + 15) & ~15, c.bn));
   }
   const size_t patch = (size_t)(c.th + 2) * (c.tw + 2) * p.Cin * esize(p);
@@ -1138,10 +1280,10 @@ int n_tiles(const ConvParams& p, int bn) {
 
 hipError_t conv_init() {
   for (const void* f : {reinterpret_cast<const void*>(conv_dual_head3x3), reinterpret_cast<const void*>(conv_dual_head1x1),
-                        reinterpret_cast<const void*>(conv_dual_head3x3_w2), reinterpret_cast<const void*>(conv_dual_head3x3_i8),
+                        reinterpret_cast<const void*>(conv_dual_head3x3_i8),
                         reinterpret_cast<const void*>(conv_dual_head3x3_big), reinterpret_cast<const void*>(conv_dual_head3x3_big_i8),
-                        reinterpret_cast<const void*>(conv_dual_head3x3_big4), reinterpret_cast<const void*>(conv_dual_head3x3_big_stamped),
-                        reinterpret_cast<const void*>(conv_dual_head3x3_big_d32), reinterpret_cast<const void*>(conv_dual_head3x3_big_w2a),
+                        reinterpret_cast<const void*>(conv_dual_head3x3_big_stamped),
+                        reinterpret_cast<const void*>(conv_dual_head3x3_ws), reinterpret_cast<const void*>(conv_dual_head3x3_ws_stamped),
                         reinterpret_cast<const void*>(stem_conv3x3s2_kernel)}) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (e != hipSuccess) return e;
@@ -1162,6 +1304,11 @@ bool conv_config_valid(const ConvParams& p, int cfg) {
   if (!c.fn) return false;
   if (c.cin) {  // register-queue kernel: 3x3 on exactly its Cin and stride (fp16 / int8 rows of the table); every slice at least one tile wide
     if (p.Cin != c.cin || p.ksize != 3 || p.stride != c.stride || p.pad != 1 || smem_for(p, c) > kMaxLds) return false;
+    if (c.ws) {
+      if (!p.relu || p.res || !p.zeros) return false;
+      for (int s = 0; s < p.nseg; ++s)
+        if (p.seg[s].out_dtype != kF16 || p.seg[s].up2 || p.seg[s].dst_planar || p.seg[s].mult) return false;
+    }
     for (int s = 0; s < p.nseg; ++s)
       if (((p.seg[s].n_count + 15) & ~15) < c.bn) return false;
     return true;
@@ -1288,42 +1435,41 @@ struct DualKind {
   const char* name;
   void (*fn)(const ConvParams, const ConvParams, int);
 };
-const DualKind kDual[] = {
+enum { kDualRegq = 0, kDual1x1, kDualRegqI8, kDualBig, kDualBigI8, kDualWs, kDualKinds };
+const DualKind kDual[kDualKinds] = {
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3<regq 8x16,64,128 | regq 8x8,64,256>", conv_dual_head3x3},
     {kCfg128x16k64, kCfg128x16k64, 256, "conv_dual_head1x1<glds 128,16,64 x2>", conv_dual_head1x1},
-    {kCfgRegqW8x16n128c128, kCfgRegqW8x8n128c256, 512, "conv_dual_head3x3_w2<regq 8x16,128,128,wn2 | regq 8x8,128,256,wn2>", conv_dual_head3x3_w2},
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3_i8<regq i8,8x16,64,128 | regq i8,8x8,64,256>", conv_dual_head3x3_i8},
     {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big<regq 16x16,64,128 | regq 8x16,64,256>", conv_dual_head3x3_big},
     {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big_i8<regq i8,16x16,64,128 | regq i8,8x16,64,256>", conv_dual_head3x3_big_i8},
-    {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 256, "conv_dual_head3x3_big4<regq 16x16,64,128,4w,wn2 | regq 8x16,64,256,4w,wn2>", conv_dual_head3x3_big4},
-    {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big_d32<regq 16x16,64,128,d32 | regq 8x16,64,256,d32>", conv_dual_head3x3_big_d32},
-    {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big_w2a<regq 16x16,64,128,wn2 | regq 8x16,64,256>", conv_dual_head3x3_big_w2a},
+    {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws<ws 16x16,64,128 | ws 8x16,64,256>", conv_dual_head3x3_ws},
 };
-constexpr int kDualKinds = 9;
 }  // namespace
 
 int conv_dual_match(const ConvParams& a, const ConvParams& b) {
   if (a.stamps || b.stamps) return -1;   // (stamped launches go through conv_dual_launch with an explicit kind)
+  auto fits = [&](int k) { return a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[k].cfg_a) && conv_config_valid(b, kDual[k].cfg_b); };
   // 16x16 | 8x16 pixel tiles (one workgroup per CU): default for fp16 (39.5 vs 41.4 us per frame for the two pairs,
   // +2.5 % frames/s), opt-in for int8 (measured slower: 0.229 vs 0.2245 ms). UNINA_DUAL_BIG=0 / 1 overrides.
   const char* bigenv = getenv("UNINA_DUAL_BIG");
   const bool big = bigenv ? bigenv[0] == '1' : (a.dtype == kF16);
   if (a.dtype == kI8 && b.dtype == kI8) {
-    if (big && a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[5].cfg_a) && conv_config_valid(b, kDual[5].cfg_b)) return 5;
-    return (a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[3].cfg_a) && conv_config_valid(b, kDual[3].cfg_b)) ? 3 : -1;
+    if (big && fits(kDualBigI8)) return kDualBigI8;
+    return fits(kDualRegqI8) ? kDualRegqI8 : -1;
   }
   if (a.dtype != kF16 || b.dtype != kF16) return -1;
-  static const bool w2 = getenv("UNINA_DUAL_W2") && getenv("UNINA_DUAL_W2")[0] == '1';
-  static const int variant = getenv("UNINA_DUAL_4W") ? atoi(getenv("UNINA_DUAL_4W")) : 0;   // 1: four waves, wn 2; 2: queue depth 32
-  if (big && a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[4].cfg_a) && conv_config_valid(b, kDual[4].cfg_b)) return variant == 1 ? 6 : (variant == 2 ? 7 : (variant == 3 ? 8 : 4));
-  if (w2 && a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[2].cfg_a) && conv_config_valid(b, kDual[2].cfg_b)) return 2;
-  if (a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[0].cfg_a) && conv_config_valid(b, kDual[0].cfg_b)) return 0;
+  // the weights-stationary pair: default for fp16 (same-box A/B against the register-queue pair: +2-3 % frames/s at 2 frames in
+  // flight, serial latency equal within noise; workgroup lives 9-11 us against 12-15). UNINA_DUAL_WS=0 falls back.
+  const char* wsenv = getenv("UNINA_DUAL_WS");
+  if (!(wsenv && wsenv[0] == '0') && !bigenv && fits(kDualWs)) return kDualWs;
+  if (big && fits(kDualBig)) return kDualBig;
+  if (fits(kDualRegq)) return kDualRegq;
   auto tiny = [](const ConvParams& p) {
     for (int s = 0; s < p.nseg; ++s)
       if (p.seg[s].n_count > 16) return false;
     return p.ksize == 1 && p.stride == 1;
   };
-  if (tiny(a) && tiny(b) && a.Cin != b.Cin && conv_config_valid(a, kDual[1].cfg_a) && conv_config_valid(b, kDual[1].cfg_b)) return 1;
+  if (tiny(a) && tiny(b) && a.Cin != b.Cin && conv_config_valid(a, kDual[kDual1x1].cfg_a) && conv_config_valid(b, kDual[kDual1x1].cfg_b)) return kDual1x1;
   return -1;
 }
 
@@ -1339,10 +1485,10 @@ hipError_t conv_dual_launch(int kind, const ConvParams& pa_in, const ConvParams&
   if (grid_out) *grid_out = na + nb;
   auto fn = k.fn;
   if (pa.stamps || pb.stamps) {   // debug: the stamped twin (only the default fp16 pair has one)
-    if (kind != 4) return hipErrorInvalidValue;
-    fn = conv_dual_head3x3_big_stamped;
+    if (kind != kDualBig && kind != kDualWs) return hipErrorInvalidValue;
+    fn = kind == kDualWs ? conv_dual_head3x3_ws_stamped : conv_dual_head3x3_big_stamped;
   }
-  hipLaunchKernelGGL(fn, dim3(na + nb, 1, 1), dim3(k.threads, 1, 1), max_sz(sa, sb), stream, pa, pb, na);
+  hipLaunchKernelGGL(fn, dim3(na + nb, 1, 1), dim3(k.threads, 1, 1), max_sz(sa, sb), stream, pa, pb, kind == kDualWs ? nb : na);   // (the weights-stationary pair puts conv B first)
   return hipGetLastError();
 }
 
@@ -1351,3 +1497,6 @@ const char* conv_config_name(int cfg, int dtype) {
 }
 
 }  // namespace unina
+#else
+}  // namespace unina
+#endif

@@ -1842,6 +1842,42 @@ int unina_debug_dual_stamps(unina_engine_t* e, int op_index, long long* out16, h
   return UNINA_OK;
 }
 
+namespace unina {
+__global__ void debug_stamp_kernel(long long* t) { if (threadIdx.x == 0) *t = wall_clock64(); }
+}
+// Same launch with EVERY workgroup's start / end on the 100 MHz wall clock: out[2*i], out[2*i+1] for workgroup i (conv A's
+// workgroups first), then the clock of a one-wave marker kernel enqueued right before and of one right after the launch
+// (dispatch gaps); cap >= 2 * grid + 2 values. Returns the grid size (> 0) or a negative error code.
+int unina_debug_dual_timeline(unina_engine_t* e, int op_index, long long* out, int cap, hipStream_t stream) {
+  if (!e || !out || op_index < 0 || op_index >= (int)e->ops.size()) return -UNINA_ERR_ARG;
+  if (hipSetDevice(e->device) != hipSuccess) return -UNINA_ERR_HIP;
+  if (e->plan_dirty) {
+    int rc = plan(e);
+    if (rc != UNINA_OK) return -rc;
+  }
+  const PlannedOp& op = e->ops[op_index];
+  if (op.d.kind != kOpConv || op.fuse_role || op.dual_with < 0 || op.dual_absorbed) return -UNINA_ERR_ARG;
+  ConvParams pa = op.cp, pb = e->ops[op.dual_with].cp;
+  long long* d = nullptr;
+  if (hipMalloc(&d, sizeof(long long) * (18 + 2 * 4096)) != hipSuccess) return -UNINA_ERR_HIP;
+  hipMemsetAsync(d, 0, sizeof(long long) * (18 + 2 * 4096), stream);
+  long long* marks = d + 16 + 2 * 4096;
+  pa.stamps = d;
+  pb.stamps = d + 8;
+  pa.wg_times = pb.wg_times = d + 16;
+  int grid = 0;
+  hipLaunchKernelGGL(unina::debug_stamp_kernel, dim3(1), dim3(64), 0, stream, marks);
+  hipError_t he = conv_dual_launch(op.dual_kind, pa, pb, stream, &grid);
+  hipLaunchKernelGGL(unina::debug_stamp_kernel, dim3(1), dim3(64), 0, stream, marks + 1);
+  if (he == hipSuccess) he = hipStreamSynchronize(stream);
+  const bool fits = grid <= 4096 && 2 * grid + 2 <= cap;
+  if (he == hipSuccess && fits) he = hipMemcpy(out, d + 16, sizeof(long long) * 2 * grid, hipMemcpyDeviceToHost);
+  if (he == hipSuccess && fits) he = hipMemcpy(out + 2 * grid, marks, sizeof(long long) * 2, hipMemcpyDeviceToHost);
+  hipFree(d);
+  if (he != hipSuccess) return -UNINA_ERR_HIP;
+  return fits ? grid : -UNINA_ERR_ARG;
+}
+
 int unina_op_count(const unina_engine_t* e) { return e ? (int)e->ops.size() : -1; }
 
 int unina_get_op_info(const unina_engine_t* ce, int index, unina_op_info* info) {

@@ -55,6 +55,7 @@ struct ConvParams {
   unsigned gm_magic, wo_magic, spt_magic, tx_magic;  // ceil(2^32/d) for d = grid_m, Wo, K-steps per tap, spatial tiles per row (0: d == 1), filled at launch
   int debug_mode;      // debug ablations (results invalid): 1 = no loads inside the K loop, 2 = no LDS reads/MFMA, 3 = MFMA without LDS reads
   long long* stamps;   // debug: s_memtime stamps of workgroup (0,0) (nullptr = off): start, prologue issued, first data, loop end, end
+  long long* wg_times; // debug (stamped dual kernels): [2 * blockIdx.x] = 100 MHz wall clock at the workgroup's start, [+1] at its end
 };
 
 // tile configurations of the conv kernel: block tile = BM pixels x BN output channels, K-step BK
@@ -71,6 +72,7 @@ enum ConvConfig : int {
   kCfgRegqS2_8x8n64c64, kCfgRegqS2_8x16n64c64, kCfgRegqS2_8x8n64c128, kCfgRegqS2_4x8n64c128, kCfgRegqS2_8x16n64c32, kCfgRegqS2_8x8n32c128,
   kCfgRegqW8x16n128c128, kCfgRegqW8x8n128c256,
   kCfgRegq16x16n64c128, kCfgRegq8x16n64c256,
+  kCfgWs16x16n64c128, kCfgWs8x16n64c256,
   kCfgCount
 };
 struct ConvLaunch {

@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "unina_load_engine", "unina_unload_engine", "unina_engine_input_dims", "unina_set_tensor_address",
     "unina_tensor_address", "unina_enqueue", "unina_infer", "unina_infer_bgra", "unina_infer_async", "unina_postprocess_async",
     "unina_last_error", "unina_op_count", "unina_get_op_info", "unina_profile_ops", "unina_profile_post", "unina_debug_read_buffer",
-    "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune", "unina_debug_post_stamps", "unina_debug_conv_stamps", "unina_debug_dual_stamps",
+    "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune", "unina_debug_post_stamps", "unina_debug_conv_stamps", "unina_debug_dual_stamps", "unina_debug_dual_timeline",
     "unina_set_fusion", "unina_fusion_groups", "unina_debug_fusable_groups",
     "create_norm_params_imagenet", "create_norm_params", "preprocess_bgra_resize", "preprocess_bgra", "preprocess_nv12",
     "allocate_preprocess_buffer", "free_preprocess_buffer", "create_preprocess_stream", "destroy_preprocess_stream",
@@ -96,6 +96,7 @@ def load_library() -> C.CDLL:
     L.unina_debug_post_stamps.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.unina_debug_conv_stamps.argtypes = [vp, ci, C.POINTER(C.c_longlong), vp]
     L.unina_debug_dual_stamps.argtypes = [vp, ci, C.POINTER(C.c_longlong), vp]
+    L.unina_debug_dual_timeline.argtypes = [vp, ci, C.POINTER(C.c_longlong), ci, vp]
     # cuda_preprocess.h drop-in symbols
     L.create_norm_params_imagenet.restype = NormParams
     L.create_norm_params.restype = NormParams
@@ -342,6 +343,16 @@ class Engine:
         buf = (C.c_longlong * 16)()
         self._check(self.L.unina_debug_dual_stamps(self.h, op_index, buf, _stream_ptr(stream)))
         return [int(v) for v in buf]
+
+    def dual_timeline(self, op_index: int, stream=None):
+        """Start / end (100 MHz wall clock) of every workgroup of the dual conv launch led by op `op_index`: array [grid + 1, 2];
+        the last row = a marker kernel enqueued right before the launch, one right after it."""
+        cap = 2 * 4096 + 2
+        buf = (C.c_longlong * cap)()
+        n = self.L.unina_debug_dual_timeline(self.h, op_index, buf, cap, _stream_ptr(stream))
+        if n <= 0:
+            raise RuntimeError(f"unina_debug_dual_timeline: error {-n}")
+        return np.array(buf[:2 * n + 2], dtype=np.int64).reshape(n + 1, 2)
 
     def conv_configs(self) -> List[str]:
         return [self.L.unina_conv_config_name(i).decode() for i in range(self.L.unina_conv_config_count())]
