@@ -1305,8 +1305,9 @@ int launch_full(unina_engine* e, const PostParams& pp, hipStream_t stream) {
 template <typename F>
 int time_in_sequence(unina_engine* e, size_t i, int iters, hipStream_t stream, hipEvent_t a, hipEvent_t b, F launch, float* ms_out) {
   float total = 0.f;
+  static const bool warm = getenv("UNINA_PROFILE_WARM") != nullptr;   // debug: back-to-back repeats (weights and inputs L2-warm)
   for (int it = 0; it < iters; ++it) {
-    for (size_t k = 0; k < i; ++k) {
+    for (size_t k = 0; k < (warm && it > 0 ? 0 : i); ++k) {
       hipError_t err = launch_op(e, k, stream);
       if (err != hipSuccess) return fail(e, UNINA_ERR_HIP, "op %zu (%s): %s", k, e->ops[k].d.name, hipGetErrorString(err));
     }
