@@ -35,6 +35,20 @@ __global__ __launch_bounds__(512, 4) void block_dual_s2c3k2i8_128x384_head64(con
   else head_fused_body<64, 8, 16, 8, 4>(ph, (int)blockIdx.x - nc, bd_smem);
 }
 
+// The head as the row-streaming / weights-stationary body (head_ws_body: 16 x 14 output pixels per workgroup, 120 workgroups at
+// 640^2) next to the block's 100: ONE 512-thread workgroup per CU (234 VGPRs), so the block's weight queue can be as deep as
+// the stand-alone kernel's. 30.5 -> 23.5 us for the launch, -7 us serial latency, frames/s unchanged (same-box A/B).
+#define BLOCK_DUAL_WS(NAME, ...)                                                                                     \
+  __global__ __launch_bounds__(512) void NAME(const C3k2Params pc, const HeadParams ph, int nc) {                    \
+    if ((int)blockIdx.x < nc) c3k2_fused_body<__VA_ARGS__>(pc, (int)blockIdx.x, bd_smem);                           \
+    else head_ws_body<64, 16, 8>(ph, (int)blockIdx.x - nc, bd_smem);                                                 \
+  }
+BLOCK_DUAL_WS(block_dual_s2c3k2_128x384_head64ws, 128, 4, 4, 1, 384, 8, 16, 0, EltH, 128, 128)
+BLOCK_DUAL_WS(block_dual_s2c3k2i8_128x384_head64ws, 128, 4, 4, 1, 384, 8, 8, 0, EltI8, 128, 128)
+BLOCK_DUAL_WS(block_dual_c3k2_128x384_head64ws, 128, 4, 4, 1, 384, 8, 16, 0)
+BLOCK_DUAL_WS(block_dual_c3k2i8_128x384_head64ws, 128, 4, 4, 1, 384, 8, 8, 0, EltI8)
+#undef BLOCK_DUAL_WS
+
 // One workgroup per CU: the head on 16x16 tiles (100 workgroups at 640^2) next to the block's 100 (UNINA_HEAD_ALT=2).
 // Measured slower than the default (29.0 vs 27.2 us): kept as an A/B knob only.
 __global__ __launch_bounds__(512) void block_dual_c3k2_128x384_head64_big(const C3k2Params pc, const HeadParams ph, int nc) {
@@ -49,6 +63,8 @@ hipError_t block_dual_init() {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
   for (const void* f : {reinterpret_cast<const void*>(block_dual_s2c3k2_128x384_head64),
+                        reinterpret_cast<const void*>(block_dual_s2c3k2_128x384_head64ws), reinterpret_cast<const void*>(block_dual_s2c3k2i8_128x384_head64ws),
+                        reinterpret_cast<const void*>(block_dual_c3k2_128x384_head64ws), reinterpret_cast<const void*>(block_dual_c3k2i8_128x384_head64ws),
                         reinterpret_cast<const void*>(block_dual_s2c3k2i8_128x384_head64)}) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -58,12 +74,21 @@ hipError_t block_dual_init() {
 }
 
 bool block_dual_match(const C3k2Params& pc, const HeadParams& ph) {
+  if (head_tile_is(ph, 16, 14))   // the row-streaming head: next to either block form, fp16 or int8
+    return (pc.dtype == kF16 || pc.dtype == kI8) && pc.hid == 128 && pc.nb == 1 && pc.Cin == 384 && pc.tail == 0 && ph.C == 64 &&
+           (pc.cpre == 0 || (pc.cpre == 128 && pc.cx == 128)) && c3k2_tile_is(pc, 4, 4);
   const bool pre_ok = pc.cpre == 0 || (pc.cpre == 128 && pc.cx == 128 && head_tile_is(ph, 8, 16));
   return (pc.dtype == kF16 || pc.dtype == kI8) && pc.hid == 128 && pc.nb == 1 && pc.Cin == 384 && pc.tail == 0 && ph.C == 64 && pre_ok &&
          c3k2_tile_is(pc, 4, 4) && (head_tile_is(ph, 8, 16) || (head_tile_is(ph, 16, 16) && pc.dtype == kF16));
 }
 
 const char* block_dual_name(int dtype, int cpre) {
+  if (head_is_ws(64)) {
+    if (cpre) return dtype == kI8 ? "block_dual_s2c3k2i8_128x384_head64ws<s2conv 128 + c3k2 i8,128,4x4,1,384 | head_ws 64,16x14>"
+                                  : "block_dual_s2c3k2_128x384_head64ws<s2conv 128 + c3k2 128,4x4,1,384 | head_ws 64,16x14>";
+    return dtype == kI8 ? "block_dual_c3k2i8_128x384_head64ws<c3k2 i8,128,4x4,1,384 | head_ws 64,16x14>"
+                        : "block_dual_c3k2_128x384_head64ws<c3k2 128,4x4,1,384 | head_ws 64,16x14>";
+  }
   if (cpre) return dtype == kI8 ? "block_dual_s2c3k2i8_128x384_head64<s2conv 128 + c3k2 i8,128,4x4,1,384 | head 64,8x16>"
                                 : "block_dual_s2c3k2_128x384_head64<s2conv 128 + c3k2 128,4x4,1,384 | head 64,8x16>";
   return dtype == kI8 ? "block_dual_c3k2i8_128x384_head64<c3k2 i8,128,4x4,1,384 | head 64,8x16>"
@@ -74,7 +99,11 @@ hipError_t block_dual_launch(const C3k2Params& pc, const HeadParams& ph, hipStre
   const int nc = pc.tiles_x * pc.tiles_y, nh = ph.tiles_x * ph.tiles_y;
   const int smem = pc.smem_bytes > ph.smem_bytes ? pc.smem_bytes : ph.smem_bytes;
   if (grid_out) *grid_out = nc + nh;
-  if (pc.cpre && pc.dtype == kI8)
+  if (head_tile_is(ph, 16, 14)) {
+    auto fn = pc.cpre ? (pc.dtype == kI8 ? block_dual_s2c3k2i8_128x384_head64ws : block_dual_s2c3k2_128x384_head64ws)
+                      : (pc.dtype == kI8 ? block_dual_c3k2i8_128x384_head64ws : block_dual_c3k2_128x384_head64ws);
+    hipLaunchKernelGGL(fn, dim3(nc + nh, 1, 1), dim3(512, 1, 1), smem, stream, pc, ph, nc);
+  } else if (pc.cpre && pc.dtype == kI8)
     hipLaunchKernelGGL(block_dual_s2c3k2i8_128x384_head64, dim3(nc + nh, 1, 1), dim3(512, 1, 1), smem, stream, pc, ph, nc);
   else if (pc.cpre)
     hipLaunchKernelGGL(block_dual_s2c3k2_128x384_head64, dim3(nc + nh, 1, 1), dim3(512, 1, 1), smem, stream, pc, ph, nc);

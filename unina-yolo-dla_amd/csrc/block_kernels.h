@@ -481,5 +481,176 @@ __device__ __forceinline__ void head_fused_body(const HeadParams& p, int bid, un
 #undef STEP
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// head_ws_body: the same DetectionHead as head_fused_body, ROW-STREAMING with the weights stationary in registers
+// (the idea of conv_igemm.hip's conv3x3_ws, chained over the head's two 3x3 layers). A workgroup owns a strip of TH x 14
+// output pixels. Wave w keeps ALL weight blocks of channel subtile w of layer 0 (cls.0 | reg.0: 2C channels, K = 9C) and of
+// layer 1 (cls.1 | reg.1: the same subtile index, its branch = w / (C/16)) in registers -- 2 x 9C/32 blocks = 144 VGPRs at
+// C = 64 -- and walks down the input patch rows:
+//   layer 0: the fragment of patch row rho (kx, cb) feeds h0 rows rho, rho-1, rho-2 (ky = 0, 1, 2); a finished h0 row (16
+//            pixels wide = one MFMA subtile: hence 14 output columns) gets bias + ReLU, is zeroed outside the image (layer 1's
+//            zero padding) and goes to a two-row LDS ring as fp16 -- every wave writes its 16 channels;
+//   layer 1: one iteration later (a barrier in between) the h0 row feeds output rows i, i-1, i-2 the same way; a finished h1
+//            row goes to the LDS h1 tile;
+//   layer 2: after the last row, the 1x1 output convs read h1 from LDS and store the fp32 planes.
+// LDS is read once per three MFMAs, with immediate offsets (padded pixel pitch, no xor swizzle: conv3x3_ws_body explains
+// why), every weight block is fetched once per workgroup, and each output receives its products in the order (ky, kx, cb)
+// from a zero accumulator with the same fp16 rounding points as head_fused_body: bit-identical results.
+template <int C, int TH, int NW>
+__device__ __forceinline__ void head_ws_body(const HeadParams& p, int bid, unsigned char* smem) {
+  static_assert(NW * 16 == 2 * C, "one wave per 16-channel subtile of the 2C-channel layers");
+  typedef half8 frag;
+  typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+  constexpr int TWO = 14, CB = C / 32, KBL = 9 * CB, NS = 2 * C / 16, SPR = 3 * CB;
+  constexpr int XR = TH + 4, XW = 18, HR = TH + 2, NT = NW * 64;
+  constexpr int PX = C * 2 + 16, PH = 2 * C * 2 + 16;            // padded pixel pitches of the x image and of the h0 / h1 images
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int tyi = fast_div(bid, p.tiles_x_magic), txi = bid - tyi * p.tiles_x;
+  const int ty0 = tyi * TH, tx0 = txi * TWO;
+  const int br = wid / (C / 16);                                  // layer-1 branch of this wave's subtile: 0 = cls, 1 = reg
+
+  const unsigned char* wbase = p.wstream + (4 * l15 + (lq ^ swz_g(l15))) * 16;
+  frag w0[KBL], w1[KBL], w2[CB];
+  auto ld0 = [&](auto kc) { w0[decltype(kc)::value] = *reinterpret_cast<const frag*>(wbase + (size_t)(decltype(kc)::value * NS + wid) * 1024); __builtin_amdgcn_sched_barrier(0); };
+  auto ld1 = [&](auto kc) { w1[decltype(kc)::value] = *reinterpret_cast<const frag*>(wbase + (size_t)(KBL * NS + decltype(kc)::value * NS + wid) * 1024); __builtin_amdgcn_sched_barrier(0); };
+  // request order = order of first use: layer 0's ky = 0 blocks, the patch, the rest of layer 0, layer 1, layer 2
+  static_for<0, 3 * CB>(ld0);
+  constexpr int nchx = C / 8, nslots = XR * XW * nchx, PITER = (nslots + NT - 1) / NT;
+  uintx4 pv[PITER];
+  {
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.src), 0, p.H * p.W * p.src_ld * 2, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < PITER; ++it) {
+      const int sl = it * NT + (int)threadIdx.x;
+      const int r = sl / nchx, cs = sl - r * nchx;
+      const int ry = r / XW, rx = r - ry * XW;
+      const int iy = ty0 - 2 + ry, ix = tx0 - 2 + rx;
+      const bool in = sl < nslots && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const unsigned off = (unsigned)((iy * p.W + ix) * p.src_ld * 2 + (cs << 4));
+      pv[it] = __builtin_amdgcn_raw_buffer_load_b128(srs, in ? off : 0x40000000u, 0, 0);   // out of range: zeros (the conv's padding)
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.n_bias * 4, 0x00020000);
+  const uintx4 cvec = __builtin_amdgcn_raw_buffer_load_b128(brs, threadIdx.x * 16, 0, 0);   // (past the array: zeros, never committed)
+  __builtin_amdgcn_sched_barrier(0);
+  static_for<3 * CB, KBL>(ld0);
+  static_for<0, KBL>(ld1);
+  static_for<0, CB>([&](auto kc) {   // layer 2: branch w & 1 (see below)
+    w2[decltype(kc)::value] = *reinterpret_cast<const frag*>(wbase + (size_t)(2 * KBL * NS + decltype(kc)::value * 2 + (wid & 1)) * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  float* bias_lds = reinterpret_cast<float*>(smem + p.off_bias);
+#pragma unroll
+  for (int it = 0; it < PITER; ++it) {
+    const int sl = it * NT + (int)threadIdx.x;
+    const int r = sl / nchx, cs = sl - r * nchx;
+    if (sl < nslots) *reinterpret_cast<uintx4*>(smem + p.off_x + r * PX + cs * 16) = pv[it];
+  }
+  if ((int)threadIdx.x * 4 < p.n_bias) reinterpret_cast<uintx4*>(bias_lds)[threadIdx.x] = cvec;
+  lds_barrier();
+
+  const unsigned xb = (unsigned)(p.off_x + l15 * PX + lq * 16);
+  const unsigned hb = (unsigned)(p.off_h0 + l15 * PH + (br * (C / 8) + lq) * 16);
+  const unsigned hw = (unsigned)(p.off_h0 + l15 * PH + (wid * 16 + lq * 4) * 2);
+  const unsigned h1w = (unsigned)(p.off_h1 + l15 * PH + (wid * 16 + lq * 4) * 2);
+  const int nch = wid * 16 + lq * 4;                               // this lane's 4 channels of the 2C-channel layers
+  const bool col_in = (unsigned)(tx0 - 1 + l15) < (unsigned)p.W;   // h0 column l15 is image column tx0 - 1 + l15
+  const floatx4 bias0 = *reinterpret_cast<const floatx4*>(bias_lds + nch);            // (in registers: an LDS read in every row's
+  const floatx4 bias1 = *reinterpret_cast<const floatx4*>(bias_lds + 2 * C + nch);    //  epilogue would wait for the whole LDS queue)
+  floatx4 a0[4], a1[4];
+  frag bx[SPR], bh[SPR];
+  auto xfrag = [&](auto rc, auto sc) {
+    constexpr int rho = decltype(rc)::value, st = decltype(sc)::value, kx = st / CB, cb = st % CB;
+    return *reinterpret_cast<const frag*>(smem + xb + ((rho * XW + kx) * PX + cb * 64));
+  };
+  auto hfrag = [&](auto ic, auto sc) {
+    constexpr int i = decltype(ic)::value, st = decltype(sc)::value, kx = st / CB, cb = st % CB;
+    return *reinterpret_cast<const frag*>(smem + hb + (((i & 1) * XW + kx) * PH + cb * 64));
+  };
+  static_for<0, SPR>([&](auto sc) { bx[decltype(sc)::value] = xfrag(std::integral_constant<int, 0>{}, sc); });
+  __builtin_amdgcn_sched_barrier(0);
+
+  static_for<0, XR + 1>([&](auto rc) {
+    constexpr int rho = decltype(rc)::value, i1 = rho - 3;          // layer 1 works on h0 row rho - 3 (published by the last barrier)
+    if constexpr (i1 >= 0 && i1 < HR) {
+      static_for<0, SPR>([&](auto sc) { bh[decltype(sc)::value] = hfrag(std::integral_constant<int, i1>{}, sc); });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (rho < XR) {                                        // ---- layer 0 on patch row rho
+      if constexpr (rho < HR) a0[rho & 3] = floatx4{0.f, 0.f, 0.f, 0.f};
+      static_for<0, SPR>([&](auto sc) {
+        constexpr int st = decltype(sc)::value, kx = st / CB, cb = st % CB;
+        static_for<0, 3>([&](auto kyc) {
+          constexpr int ky = decltype(kyc)::value, i = rho - ky;
+          if constexpr (i >= 0 && i < HR) a0[i & 3] = EltH::mma(w0[(ky * 3 + kx) * CB + cb], bx[st], a0[i & 3]);
+        });
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (rho >= 2) {                                      // h0 row rho - 2 is complete
+        constexpr int i = rho - 2;
+        const floatx4 v = a0[i & 3] + bias0;
+        const bool in = col_in && (unsigned)(ty0 - 1 + i) < (unsigned)p.H;
+        half4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(in && v[e] > 0.f ? v[e] : 0.f);
+        *reinterpret_cast<half4*>(smem + hw + (i & 1) * XW * PH) = hv;
+      }
+      if constexpr (rho + 1 < XR) {
+        static_for<0, SPR>([&](auto sc) { bx[decltype(sc)::value] = xfrag(std::integral_constant<int, rho + 1>{}, sc); });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (i1 >= 0 && i1 < HR) {                              // ---- layer 1 on h0 row i1
+      if constexpr (i1 < TH) a1[i1 & 3] = floatx4{0.f, 0.f, 0.f, 0.f};
+      static_for<0, SPR>([&](auto sc) {
+        constexpr int st = decltype(sc)::value, kx = st / CB, cb = st % CB;
+        static_for<0, 3>([&](auto kyc) {
+          constexpr int ky = decltype(kyc)::value, r = i1 - ky;
+          if constexpr (r >= 0 && r < TH) a1[r & 3] = EltH::mma(w1[(ky * 3 + kx) * CB + cb], bh[st], a1[r & 3]);
+        });
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (i1 >= 2) {                                       // h1 row i1 - 2 is complete
+        constexpr int r = i1 - 2;
+        const floatx4 v = a1[r & 3] + bias1;
+        half4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(v[e] > 0.f ? v[e] : 0.f);
+        *reinterpret_cast<half4*>(smem + h1w + r * 16 * PH) = hv;
+      }
+    }
+    lds_barrier();
+  });
+
+  // ---- layer 2: raw outputs = W2 h1[branch] + b2, planar fp32. Wave w: branch w & 1, rows (w >> 1) + 4t.
+  const int br2 = wid & 1;
+  const float* bias_2 = bias_lds + 4 * C;
+  const int M = p.H * p.W;
+  const unsigned h1r = (unsigned)(p.off_h1 + l15 * PH + (br2 * (C / 8) + lq) * 16);
+  const floatx4 b2 = *reinterpret_cast<const floatx4*>(bias_2 + br2 * 16 + lq * 4);
+  float* dst0 = br2 ? p.out_reg : p.out_cls;
+  const int cnt = br2 ? p.n_reg : p.n_cls;
+#pragma unroll
+  for (int t = 0; t < (TH + 3) / 4; ++t) {
+    const int r = (wid >> 1) + 4 * t;
+    if (r >= TH) break;
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < CB; ++kb) acc = EltH::mma(w2[kb], *reinterpret_cast<const frag*>(smem + h1r + r * 16 * PH + kb * 64), acc);
+    const int oy = ty0 + r, ox = tx0 + l15;
+    if (l15 >= TWO || oy >= p.H || ox >= p.W) continue;
+    const floatx4 v = acc + b2;
+    float* dst = dst0 + (size_t)oy * p.W + ox;
+    const int c = lq * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < cnt) dst[(size_t)(c + e) * M] = v[e];
+  }
+}
+
 }  // namespace dev
 }  // namespace unina

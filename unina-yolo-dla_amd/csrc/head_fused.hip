@@ -28,6 +28,11 @@ __global__ __launch_bounds__(NW * 64) void head_fused_kernel(const HeadParams p)
   head_fused_body<C, TH, TW, NW, D>(p, (int)blockIdx.x, head_smem);
 }
 
+template <int C, int TH, int NW>
+__global__ __launch_bounds__(NW * 64) void head_ws_kernel(const HeadParams p) {
+  head_ws_body<C, TH, NW>(p, (int)blockIdx.x, head_smem);
+}
+
 // ------------------------------------------------------------------------------------------------- host side
 namespace {
 
@@ -35,14 +40,18 @@ struct HClass {
   int c, th, tw, nw;
   const char* name;
   void (*fn)(const HeadParams);
+  bool ws = false;     // row-streaming / weights-stationary body (head_ws_body): th x 14 output pixels per workgroup
 };
 const HClass kHeadClasses[] = {
-    {64, 8, 16, 8, "head_fused<64,8x16,8w>", head_fused_kernel<64, 8, 16, 8, 16>},
+    {64, 8, 16, 8, "head_fused<64,8x16,8w>", head_fused_kernel<64, 8, 16, 8, 16>},   // UNINA_HEAD_ALT=0 (round 1's default)
     {64, 8, 8, 8, "head_fused<64,8x8,8w>", head_fused_kernel<64, 8, 8, 8, 16>},     // UNINA_HEAD_ALT=1 (A/B experiments)
     {64, 16, 16, 8, "head_fused<64,16x16,8w>", head_fused_kernel<64, 16, 16, 8, 16>},  // UNINA_HEAD_ALT=2
+    {64, 16, 14, 8, "head_ws<64,16x14,8w>", head_ws_kernel<64, 16, 8>, true},          // default (UNINA_HEAD_ALT=3)
 };
 const HClass* find_hclass(int c) {
-  static const int alt = getenv("UNINA_HEAD_ALT") ? atoi(getenv("UNINA_HEAD_ALT")) : 0;
+  // default: the row-streaming class (same-box A/B against the 8x16 tile class: the block dual 30.5 -> 23.5 us, -7 us serial
+  // latency, frames/s equal); UNINA_HEAD_ALT=0 / 1 / 2 select the tile classes
+  static const int alt = getenv("UNINA_HEAD_ALT") ? atoi(getenv("UNINA_HEAD_ALT")) : 3;
   const int n = (int)(sizeof(kHeadClasses) / sizeof(kHeadClasses[0]));
   if (alt >= 0 && alt < n && kHeadClasses[alt].c == c) return &kHeadClasses[alt];
   return nullptr;
@@ -66,14 +75,22 @@ bool head_layout(HeadParams* p) {
   const HClass* c = find_hclass(p->C);
   if (!c || p->n_cls < 1 || p->n_cls > 16 || p->n_reg < 1 || p->n_reg > 16) return false;
   const int C = p->C;
-  const int p0 = (c->th + 4) * (c->tw + 4), p1 = (c->th + 2) * (c->tw + 2), pt = c->th * c->tw;
   p->tiles_x = (p->W + c->tw - 1) / c->tw;
   p->tiles_y = (p->H + c->th - 1) / c->th;
   p->tiles_x_magic = div_magic((unsigned)p->tiles_x);
   p->n_bias = 4 * C + 32;
-  const int x_bytes = align_up(p0 * C * 2, 1024) + 1024, h1_bytes = pt * 2 * C * 2;
   int off = 0;
   p->off_bias = off; off += align_up(p->n_bias * 4, 1024);
+  if (c->ws) {   // padded images (head_ws_body): x patch (th+4) x 18, two h0 rows of 18, h1 th x 16 pixels
+    const int px = C * 2 + 16, ph = 2 * C * 2 + 16;
+    p->off_x = off; off += align_up((c->th + 4) * 18 * px, 1024);
+    p->off_h0 = off; off += align_up(2 * 18 * ph, 1024);
+    p->off_h1 = off; off += align_up(c->th * 16 * ph, 1024);
+    p->smem_bytes = off;
+    return off <= kMaxLds;
+  }
+  const int p0 = (c->th + 4) * (c->tw + 4), p1 = (c->th + 2) * (c->tw + 2), pt = c->th * c->tw;
+  const int x_bytes = align_up(p0 * C * 2, 1024) + 1024, h1_bytes = pt * 2 * C * 2;
   p->off_x = off;
   p->off_h1 = off;                                            // h1 replaces the patch once step 0 has consumed it
   off += align_up(x_bytes > h1_bytes ? x_bytes : h1_bytes, 1024);
@@ -94,6 +111,10 @@ bool head_tile_is(const HeadParams& p, int th, int tw) {
   return k && k->th == th && k->tw == tw;
 }
 
+bool head_is_ws(int c) {
+  const HClass* k = find_hclass(c);
+  return k && k->ws;
+}
 const char* head_kernel_name(int c) {
   const HClass* k = find_hclass(c);
   return k ? k->name : "head_fused<?>";

@@ -173,6 +173,7 @@ bool head_supported(int c);
 bool head_layout(HeadParams* p);
 hipError_t head_launch(const HeadParams& p, hipStream_t stream);
 const char* head_kernel_name(int c);
+bool head_is_ws(int c);                // the row-streaming / weights-stationary class is selected (head_ws_body)
 int head_block_threads(int c);
 
 // Two consecutive 1x1 ConvBlocks (SPPF cv2 -> FPN lateral, + x2 upsample store) in ONE launch (conv_pair.hip).
