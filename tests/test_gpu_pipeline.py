@@ -123,3 +123,38 @@ open(sys.argv[1], "w").write("\n".join(out))
     tiled = run({}, "tiled.txt")
     assert len(tiled.split()) == 6
     assert run({"UNINA_STEM_V1": "1"}, "v1.txt") == tiled
+
+
+@pytest.mark.parametrize("env", [{"UNINA_DUAL_WS": "0"}, {"UNINA_HEAD_ALT": "0"}, {"UNINA_DUAL_WS": "0", "UNINA_HEAD_ALT": "0"}])
+def test_weights_stationary_kernels_match_the_tile_kernels_bit_for_bit(env, tmp_path):
+    """Round 2's weights-stationary kernels -- conv_dual_head3x3_ws for the P3 | P4 head pairs, head_ws for the P2 head (both the
+    defaults) -- accumulate every output in the K order of the tile kernels they replaced (conv_dual_head3x3_big, head_fused:
+    UNINA_DUAL_WS=0 / UNINA_HEAD_ALT=0, read once per process, hence child processes): head tensors and detections must be
+    the same bytes, at 640x640 and at a size with partial tiles / strips."""
+    code = r'''
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, %r)
+import unina_yolo_dla_amd as u
+from unina_yolo_dla_amd.engine import Engine
+out = []
+for (h, w) in ((640, 640), (224, 352)):
+    g = u.graph.Graph(in_h=h, in_w=w)
+    e = Engine.from_state_dict(u.synth.make_state_dict(7), g)
+    for seed in (1234, 1235):
+        x = torch.from_numpy(u.rng.frame(seed, h, w)).cuda()
+        heads = e.forward(x)
+        out.append(" ".join(hashlib.sha256(np.ascontiguousarray(heads[k]).tobytes()).hexdigest()[:16] for k in sorted(heads)))
+        out.append(hashlib.sha256(e.infer(x, 0.3, 0.45, 0.1).tobytes()).hexdigest())
+    out.append(",".join(sorted(set(o["kernel"].split("<")[0] for o in e.op_infos() if "head" in o["kernel"]))))
+    e.close()
+open(sys.argv[1], "w").write("\n".join(out))
+''' % ROOT
+    def run(extra, name):
+        out = str(tmp_path / name)
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return open(out).read().split("\n")
+    base, alt = run({}, "base.txt"), run(env, "alt.txt")
+    assert len(base) == 10 and "head64ws" in base[4] and "conv_dual_head3x3_ws" in base[4]      # the defaults are the new kernels
+    assert alt[4] != base[4]                                                                        # ... and the switch selected the old ones
+    assert [l for i, l in enumerate(alt) if i % 5 != 4] == [l for i, l in enumerate(base) if i % 5 != 4]

@@ -4,8 +4,9 @@
 #   mix_probe    : issue cost of ds_read_b128 / address VALU ops between MFMAs, one wave per SIMD
 #   ingest_probe : L2 -> CU bytes per clock against waves per workgroup, workgroups in flight, L2 hits / misses
 #   l2warm_probe : does an L2 warm-up by the previous kernel survive the kernel boundary?  -> yes
+#   ldsbank_probe: ds_read_b128 fragment reads against the pixel pitch of a padded LDS image -> +32 bytes is conflict-free, +16 is not
 set -e
 cd "$(dirname "$0")"
-for p in ifetch_probe mix_probe ingest_probe l2warm_probe; do
+for p in ifetch_probe mix_probe ingest_probe l2warm_probe ldsbank_probe; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -ftemplate-depth=2048 -o $p $p.hip
 done

@@ -504,7 +504,8 @@ __device__ __forceinline__ void head_ws_body(const HeadParams& p, int bid, unsig
   typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
   constexpr int TWO = 14, CB = C / 32, KBL = 9 * CB, NS = 2 * C / 16, SPR = 3 * CB;
   constexpr int XR = TH + 4, XW = 18, HR = TH + 2, NT = NW * 64;
-  constexpr int PX = C * 2 + 16, PH = 2 * C * 2 + 16;            // padded pixel pitches of the x image and of the h0 / h1 images
+  constexpr int PX = C * 2 + 32, PH = 2 * C * 2 + 32;            // padded pixel pitches of the x image and of the h0 / h1 images
+                                                                 // (+32: conflict-free fragment reads, tools/probes/ldsbank_probe.hip)
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, lq = lane >> 4;

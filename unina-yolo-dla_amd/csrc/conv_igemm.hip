@@ -870,12 +870,12 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
   typedef E::frag frag;
   constexpr int TW = 16, R0W = TW + 2, R0H = TH + 2, NT = NW * 64, CB = CIN / 32, KB = 9 * CB, BN = NW * 16;
   constexpr int STEPS = R0H * 3 * CB, PF = 4;     // (rho, kx, cb) steps; LDS fragments are requested PF steps ahead
-  // LDS patch image: pixel pitch = Cin*2 + 16 bytes, NO xor swizzle. The pad makes the 16 pixels of a fragment read hit 16
+  // LDS patch image: pixel pitch = Cin*2 + 32 bytes, NO xor swizzle. The pad makes the 16 pixels of a fragment read hit 16
   // different bank groups, and the address of (rho, kx, cb) is lane_base + a compile-time constant: the ds_read takes it as
   // its immediate offset. The K loop is ISSUE-bound (tools/probes/mix_probe.hip: an MFMA holds the SIMD's vector issue
   // for 8 of its 16 cycles, a ds_read_b128 for ~16, every VALU op for 4): with the swizzled image's 2-3 address ops per
   // fragment it ran at 28 cycles per MFMA; three MFMAs + one ds_read + one s_waitcnt fit the 48.
-  constexpr int PITCH = CIN * 2 + 16, SPLIT = 60 * 1024;
+  constexpr int PITCH = CIN * 2 + 32, SPLIT = 60 * 1024;   // (+32, not +16: tools/probes/ldsbank_probe.hip -- 28.0 against 34.5 cycles per read)
   if constexpr (STAMPS) { stamp_b(p, 0, bid, nwg); stamp_wg(p, 0); }
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1262,7 +1262,7 @@ inline size_t smem_for(const ConvParams& p, const CfgInfo& c) {
   if (c.cin) {  // register-queue kernel: patch (+ < 1 KiB overrun of its last DMA instruction) or the epilogue staging tile
     const size_t ph = c.stride * (c.th - 1) + 3, pw = c.stride * (c.tw - 1) + 3;
     const size_t patch = ((ph * pw * c.cin * esize(p) + 1023) & ~(size_t)1023) + 1024;
-    if (c.ws) return ph * pw * (c.cin * 2 + 16);   // padded pixel pitch, no swizzle (conv3x3_ws_body)
+    if (c.ws) return ph * pw * (c.cin * 2 + 32);   // padded pixel pitch, no swizzle (conv3x3_ws_body)
     return max_sz(patch, stage_bytes((c.bm + 15) & ~15, c.bn));
   }
   const size_t patch = (size_t)(c.th + 2) * (c.tw + 2) * p.Cin * esize(p);

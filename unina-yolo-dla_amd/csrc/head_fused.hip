@@ -82,7 +82,7 @@ bool head_layout(HeadParams* p) {
   int off = 0;
   p->off_bias = off; off += align_up(p->n_bias * 4, 1024);
   if (c->ws) {   // padded images (head_ws_body): x patch (th+4) x 18, two h0 rows of 18, h1 th x 16 pixels
-    const int px = C * 2 + 16, ph = 2 * C * 2 + 16;
+    const int px = C * 2 + 32, ph = 2 * C * 2 + 32;
     p->off_x = off; off += align_up((c->th + 4) * 18 * px, 1024);
     p->off_h0 = off; off += align_up(2 * 18 * ph, 1024);
     p->off_h1 = off; off += align_up(c->th * 16 * ph, 1024);
