@@ -234,6 +234,25 @@ def main():
                             for k, v in top],
         }
 
+        # Where the dominant launch's time goes: for the dual conv launches a stamped twin of the kernel records every
+        # workgroup's start / end on the 100 MHz wall clock (unina_debug_dual_timeline). `workgroups_span_us` = first start ->
+        # last end, i.e. the launch WITHOUT the dispatch gap on either side; `frac` above stays the event-timed launch.
+        try:
+            lead = [i for i, o in enumerate(ops) if o["kernel"] == dom_name and o["ms"] > 0.0]
+            if lead and dom_name.startswith("conv_dual_head3x3"):
+                spans = []
+                for i in lead:
+                    for _ in range(5):
+                        e0.forward(frames[0])                                  # replay the frame: cold weights, fresh inputs
+                        tl = e0.dual_timeline(i)[:-1].astype(np.float64) * 0.01
+                        spans.append(float(tl[:, 1].max() - tl[:, 0].min()))
+                span = float(np.median(spans))
+                roofline["workgroups_span_us"] = round(span, 2)
+                roofline["frac_of_workgroups_span"] = round(dom["flops"] / dom["launches"] / (span * 1e-6) / 1e12 / PEAK_TFLOPS[dname], 4)
+        except Exception as ex:                                                # debug API: never fail the bench line over it
+            roofline["workgroups_span_us"] = None
+            roofline["workgroups_span_note"] = str(ex)[:120]
+
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(u, sd, S, conf, args.cpu_seconds, args.variant)
