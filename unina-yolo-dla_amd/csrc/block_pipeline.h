@@ -9,6 +9,12 @@
 #pragma once
 #include <type_traits>
 
+#ifndef UNINA_BLOCK_FAKE_ADDR
+#define UNINA_BLOCK_FAKE_ADDR 0   // timing experiments (results invalid): 1 = run_step reads its fragments at lane base + immediate (no
+                                  // address arithmetic: -0.2..-1.3 us per block kernel, -4.6 us per frame at most); 2 = no weight loads after
+                                  // the first D blocks of a wave
+#endif
+
 #include "mfma_common.h"
 
 namespace unina {
@@ -94,7 +100,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Element G of this wave's flat weight sequence -> queue slot G % D. wbase = stream + this lane's 16 bytes of a block.
 template <typename ST, int D, int G, typename FRAG>
 __device__ __forceinline__ void wq_fetch(FRAG (&q)[D], const unsigned char* wbase, int wid) {
+#if UNINA_BLOCK_FAKE_ADDR == 2   // timing experiment only (results invalid): no weight loads after the first D blocks
+  if constexpr (G < D) {
+#else
   if constexpr (G < ST::total()) {
+#endif
     constexpr int s = ST::step_of(G), e = G - ST::first(s), wnt = ST::wnt(s), kb = e / wnt, j = e - kb * wnt, ns = ST::ns(s);
     const int nsub = (wid % ST::waves_n(s)) * wnt + j;
     q[G % D] = *reinterpret_cast<const FRAG*>(wbase + (size_t)(ST::blk(s) + kb * ns + nsub) * 1024);
@@ -123,11 +133,17 @@ __device__ __forceinline__ void run_step(typename E::frag (&q)[D], const unsigne
   const int wm = wid / WVN, wn = wid % WVN, lq = lane >> 4;
   acc_t acc[WN_T][WM_T];
   frag b[2][WM_T];
+#if UNINA_BLOCK_FAKE_ADDR == 1   // timing experiment only (results invalid): fragment reads at lane base + immediate, no address arithmetic
+  const int fake_base = lane * 16;
+  auto baddr_t = [&](int sub, auto kc) { return fake_base + (((sub % WM_T) * KB + decltype(kc)::value) * 1024) % 32768; };
+#else
+  auto& baddr_t = baddr;
+#endif
 #pragma unroll
   for (int i = 0; i < WM_T; ++i) {
 #pragma unroll
     for (int j = 0; j < WN_T; ++j) acc[j][i] = acc_t{0, 0, 0, 0};
-    if constexpr (DB) b[0][i] = *reinterpret_cast<const frag*>(smem + baddr(wm * WM_T + i, std::integral_constant<int, 0>{}));
+    if constexpr (DB) b[0][i] = *reinterpret_cast<const frag*>(smem + baddr_t(wm * WM_T + i, std::integral_constant<int, 0>{}));
   }
   static_for<0, KB>([&](auto kc) {
     constexpr int kb = decltype(kc)::value;
@@ -139,11 +155,11 @@ __device__ __forceinline__ void run_step(typename E::frag (&q)[D], const unsigne
       if constexpr (kb + 1 < KB) {
 #pragma unroll
         for (int i = 0; i < WM_T; ++i)
-          b[(kb + 1) & 1][i] = *reinterpret_cast<const frag*>(smem + baddr(wm * WM_T + i, std::integral_constant<int, kb + 1>{}));
+          b[(kb + 1) & 1][i] = *reinterpret_cast<const frag*>(smem + baddr_t(wm * WM_T + i, std::integral_constant<int, kb + 1>{}));
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < WM_T; ++i) b[kb & 1][i] = *reinterpret_cast<const frag*>(smem + baddr(wm * WM_T + i, kc));
+      for (int i = 0; i < WM_T; ++i) b[kb & 1][i] = *reinterpret_cast<const frag*>(smem + baddr_t(wm * WM_T + i, kc));
     }
 #pragma unroll
     for (int j = 0; j < WN_T; ++j)
