@@ -864,18 +864,19 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
 // accumulators are live (a row is converted and stored while the next ones are being accumulated). Each output row still
 // receives its products in the order ky, kx, cb from a zero accumulator, i.e. the K order of every other conv kernel:
 // results are bit-identical.
-template <int TH, int CIN, int NW, bool STAMPS = false>
+template <int TH, int CIN, int NW, bool STAMPS = false, typename T = half_t>
 __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, int nwg) {
-  typedef Elem<half_t> E;
-  typedef E::frag frag;
-  constexpr int TW = 16, R0W = TW + 2, R0H = TH + 2, NT = NW * 64, CB = CIN / 32, KB = 9 * CB, BN = NW * 16;
+  typedef Elem<T> E;     // half_t, or signed char (INT8 engines: int8 patch, 64-k weight blocks, exact int32 accumulators)
+  typedef typename E::frag frag;
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int TW = 16, R0W = TW + 2, R0H = TH + 2, NT = NW * 64, CB = CIN / E::kBlockK, KB = 9 * CB, BN = NW * 16;
   constexpr int STEPS = R0H * 3 * CB, PF = 4;     // (rho, kx, cb) steps; LDS fragments are requested PF steps ahead
   // LDS patch image: pixel pitch = Cin*2 + 32 bytes, NO xor swizzle. The pad makes the 16 pixels of a fragment read hit 16
   // different bank groups, and the address of (rho, kx, cb) is lane_base + a compile-time constant: the ds_read takes it as
   // its immediate offset. The K loop is ISSUE-bound (tools/probes/mix_probe.hip: an MFMA holds the SIMD's vector issue
   // for 8 of its 16 cycles, a ds_read_b128 for ~16, every VALU op for 4): with the swizzled image's 2-3 address ops per
   // fragment it ran at 28 cycles per MFMA; three MFMAs + one ds_read + one s_waitcnt fit the 48.
-  constexpr int PITCH = CIN * 2 + 32, SPLIT = 60 * 1024;   // (+32, not +16: tools/probes/ldsbank_probe.hip -- 28.0 against 34.5 cycles per read)
+  constexpr int PITCH = CIN * ESZ + 32, SPLIT = 60 * 1024;   // (+32, not +16: tools/probes/ldsbank_probe.hip -- 28.0 against 34.5 cycles per read)
   if constexpr (STAMPS) { stamp_b(p, 0, bid, nwg); stamp_wg(p, 0); }
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -897,6 +898,8 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
   const int n = nb0 + wid * 16 + lq * 4;                // slice-relative first channel of this lane's 4 outputs
   const bool n_ok = n < sg.n_count;
   const floatx4 bias = *reinterpret_cast<const floatx4*>(sg.bias + (n_ok ? n : 0));
+  floatx4 mult = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (ESZ == 1) mult = *reinterpret_cast<const floatx4*>(sg.mult + (n_ok ? n : 0));   // int8: s_in * s_w * bn_scale per channel
   // tap row ky = 0 first: the patch (requested next) and these are all the first patch row needs
   static_for<0, 3 * CB>([&](auto g) { w[decltype(g)::value] = *reinterpret_cast<const frag*>(wptr + decltype(g)::value * 1024); });
   asm volatile("" ::: "memory");
@@ -906,12 +909,12 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
   // still in flight and each block's first MFMA waits for exactly that block.
   // (buffer loads: a slot outside the image -- the conv's zero padding -- or past the patch gets an out-of-range offset and the
   // range check returns zeros: no branch around a load, no select on loaded data, nothing that makes the compiler wait early)
-  constexpr int nchx = CIN / 8, nslots = R0H * R0W * nchx, PITER = (nslots + NT - 1) / NT;
+  constexpr int nchx = CIN * ESZ / 16, nslots = R0H * R0W * nchx, PITER = (nslots + NT - 1) / NT;
   typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
   uintx4 pv[PITER];
   __builtin_amdgcn_sched_barrier(0);   // request order = the order things are needed in: ky = 0 blocks, patch, ky = 1, 2 blocks
   {
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.H * p.W * p.src_ld * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.H * p.W * p.src_ld * ESZ, 0x00020000);
 #pragma unroll
     for (int it = 0; it < PITER; ++it) {
       const int sl = it * NT + (int)threadIdx.x;
@@ -919,7 +922,7 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
       const int ry = r / R0W, rx = r - ry * R0W;
       const int iy = ty0 - 1 + ry, ix = tx0 - 1 + rx;
       const bool in = sl < nslots && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const unsigned off = (unsigned)(((iy * p.W + ix) * p.src_ld + sg.src_coff) * 2 + (cs << 4));
+      const unsigned off = (unsigned)(((iy * p.W + ix) * p.src_ld + sg.src_coff) * ESZ + (cs << 4));
       pv[it] = __builtin_amdgcn_raw_buffer_load_b128(srs, in ? off : 0x40000000u, 0, 0);
     }
   }
@@ -940,10 +943,10 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
 
   // destination through a buffer descriptor: lanes outside the image / past the slice get an out-of-range offset and
   // the range check drops their store -- no exec masking, the whole K loop stays one basic block
-  const unsigned rowb = (unsigned)(p.Wo * sg.dst_ld * 2);
+  const unsigned rowb = (unsigned)(p.Wo * sg.dst_ld * ESZ);
   const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(sg.dst, 0, (int)((unsigned)p.Ho * rowb), 0x00020000);
   const bool lane_ok = n_ok && tx0 + l15 < p.Wo;
-  const unsigned voff0 = lane_ok ? (unsigned)(((ty0 * p.Wo + tx0 + l15) * sg.dst_ld + n) * 2) : 0x40000000u;
+  const unsigned voff0 = lane_ok ? (unsigned)(((ty0 * p.Wo + tx0 + l15) * sg.dst_ld + n) * ESZ) : 0x40000000u;
 
   const unsigned lo0 = (unsigned)(l15 * PITCH + lq * 16);
   unsigned lo1 = lo0 + SPLIT;                     // second base: ds offsets are 16 bits
@@ -956,20 +959,35 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
   };
   frag b[PF + 1];
   static_for<0, PF>([&](auto sc) { b[decltype(sc)::value] = bfrag(sc); });
-  floatx4 acc[4];
+  typename E::acc_t acc[4];
+  const float out_inv = sg.out_inv_scale;
   auto store_row = [&](auto rc) {
     constexpr int r = decltype(rc)::value;
-    floatx4 v = acc[r & 3] + bias;
-    half4 hv;
+    if constexpr (ESZ == 2) {
+      floatx4 v = acc[r & 3] + bias;
+      half4 hv;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) hv[e] = (half_t)(v[e] > 0.f ? v[e] : 0.f);
-    typedef float floatx2 __attribute__((ext_vector_type(2)));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs, voff0 + (unsigned)r * rowb, 0, 0);
+      for (int e = 0; e < 4; ++e) hv[e] = (half_t)(v[e] > 0.f ? v[e] : 0.f);
+      typedef float floatx2 __attribute__((ext_vector_type(2)));
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs, voff0 + (unsigned)r * rowb, 0, 0);
+    } else {   // the per-op kernels' int8 epilogue operation for operation (conv_epilogue): fma, ReLU, rint(y / s_out), clamp
+      const floatx4 c = E::to_float(acc[r & 3]);
+      unsigned q = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = __builtin_fmaf(c[e], mult[e], bias[e]);
+        v = v > 0.f ? v : 0.f;
+        float t = __builtin_rintf(v * out_inv);
+        t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
+        q |= ((unsigned)(int)t & 0xFFu) << (8 * e);
+      }
+      __builtin_amdgcn_raw_buffer_store_b32(q, drs, voff0 + (unsigned)r * rowb, 0, 0);
+    }
   };
   static_for<0, STEPS>([&](auto sc) {
     constexpr int s = decltype(sc)::value, rho = s / (3 * CB), kx = (s / CB) % 3, cb = s % CB;
     if constexpr (s + PF < STEPS) b[(s + PF) % (PF + 1)] = bfrag(std::integral_constant<int, s + PF>{});
-    if constexpr (kx == 0 && cb == 0 && rho < TH) acc[rho & 3] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (kx == 0 && cb == 0 && rho < TH) acc[rho & 3] = typename E::acc_t{0, 0, 0, 0};
     static_for<0, 3>([&](auto kyc) {
       constexpr int ky = decltype(kyc)::value, r = rho - ky;
       if constexpr (r >= 0 && r < TH) acc[r & 3] = E::mma(w[(ky * 3 + kx) * CB + cb], b[s % (PF + 1)], acc[r & 3]);
@@ -983,9 +1001,9 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
   if constexpr (STAMPS) { stamp_b(p, 4, bid, nwg); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_wg(p, 1); }
 }
 
-template <int TH, int CIN, int NW>
+template <int TH, int CIN, int NW, typename T = half_t>
 __global__ __launch_bounds__(NW * 64) void conv3x3_ws(const ConvParams p) {
-  conv3x3_ws_body<TH, CIN, NW>(p, (int)blockIdx.x, (int)gridDim.x);
+  conv3x3_ws_body<TH, CIN, NW, false, T>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // the pair on the weights-stationary kernel: 4 waves, ONE wave per SIMD (Cin 256 keeps 288 weight registers per lane).
@@ -998,6 +1016,12 @@ __global__ __launch_bounds__(256) void conv_dual_head3x3_ws(const ConvParams pa,
 __global__ __launch_bounds__(256) void conv_dual_head3x3_ws_stamped(const ConvParams pa, const ConvParams pb, int nb) {
   if ((int)blockIdx.x < nb) conv3x3_ws_body<8, 256, 4, true>(pb, (int)blockIdx.x, nb);
   else conv3x3_ws_body<16, 128, 4, true>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
+}
+
+// INT8 engines: the same pair on int8 tensors (18 / 36 weight blocks of 64 k per wave: 72 / 144 registers)
+__global__ __launch_bounds__(256) void conv_dual_head3x3_ws_i8(const ConvParams pa, const ConvParams pb, int nb) {
+  if ((int)blockIdx.x < nb) conv3x3_ws_body<8, 256, 4, false, signed char>(pb, (int)blockIdx.x, nb);
+  else conv3x3_ws_body<16, 128, 4, false, signed char>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
 }
 
 #ifndef UNINA_CONV_PROBE   // (ISA probe builds stop here: tools/isa_probe.sh compiles only the kernels above)
@@ -1099,6 +1123,9 @@ constexpr size_t smem_of() {
 #define WS(TH, CIN, NW)                                                                              \
   {(TH) * 16, (NW) * 16, 32, 3, "conv3x3_ws<f16," #TH "x16," #CIN "," #NW "w>",                          \
    conv3x3_ws<TH, CIN, NW>, 0, TH, 16, CIN, (NW) * 64, 1, true}
+#define WSI(TH, CIN, NW)                                                                             \
+  {(TH) * 16, (NW) * 16, 32, 3, "conv3x3_ws<i8," #TH "x16," #CIN "," #NW "w>",                           \
+   conv3x3_ws<TH, CIN, NW, signed char>, 0, TH, 16, CIN, (NW) * 64, 1, true}
 #define NOCFG {0, 0, 0, 0, "n/a", nullptr, 0, 0, 0, -1, 0, 0}
 
 // [dtype][config]; BK is in fp16-equivalent k (KSUB = BK/32 fragment blocks): a K-step covers BK channels in fp16
@@ -1241,7 +1268,8 @@ const CfgInfo kCfg[3][kCfgCount] = {
         NOCFG, NOCFG,
         REGQI(16, 16, 64, 128, 8, 16),                // kCfgRegq16x16n64c128
         REGQI(8, 16, 64, 256, 8, 16),                 // kCfgRegq8x16n64c256
-        NOCFG, NOCFG,
+        WSI(16, 128, 4),                              // kCfgWs16x16n64c128
+        WSI(8, 256, 4),                               // kCfgWs8x16n64c256
     },
 };
 #undef CFG
@@ -1253,6 +1281,7 @@ const CfgInfo kCfg[3][kCfgCount] = {
 #undef REGQI2
 #undef NOCFG
 #undef WS
+#undef WSI
 
 inline int block_k(int dtype) { return dtype == kF32 ? 16 : (dtype == kI8 ? 64 : 32); }
 inline int kstep_of(const ConvParams& p, const CfgInfo& c) { return (c.bk / 32) * block_k(p.dtype); }
@@ -1262,7 +1291,7 @@ inline size_t smem_for(const ConvParams& p, const CfgInfo& c) {
   if (c.cin) {  // register-queue kernel: patch (+ < 1 KiB overrun of its last DMA instruction) or the epilogue staging tile
     const size_t ph = c.stride * (c.th - 1) + 3, pw = c.stride * (c.tw - 1) + 3;
     const size_t patch = ((ph * pw * c.cin * esize(p) + 1023) & ~(size_t)1023) + 1024;
-    if (c.ws) return ph * pw * (c.cin * 2 + 32);   // padded pixel pitch, no swizzle (conv3x3_ws_body)
+    if (c.ws) return ph * pw * (c.cin * esize(p) + 32);   // padded pixel pitch, no swizzle (conv3x3_ws_body)
     return max_sz(patch, stage_bytes((c.bm + 15) & ~15, c.bn));
   }
   const size_t patch = (size_t)(c.th + 2) * (c.tw + 2) * p.Cin * esize(p);
@@ -1284,6 +1313,7 @@ hipError_t conv_init() {
                         reinterpret_cast<const void*>(conv_dual_head3x3_big), reinterpret_cast<const void*>(conv_dual_head3x3_big_i8),
                         reinterpret_cast<const void*>(conv_dual_head3x3_big_stamped),
                         reinterpret_cast<const void*>(conv_dual_head3x3_ws), reinterpret_cast<const void*>(conv_dual_head3x3_ws_stamped),
+                        reinterpret_cast<const void*>(conv_dual_head3x3_ws_i8),
                         reinterpret_cast<const void*>(stem_conv3x3s2_kernel)}) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (e != hipSuccess) return e;
@@ -1307,7 +1337,7 @@ bool conv_config_valid(const ConvParams& p, int cfg) {
     if (c.ws) {
       if (!p.relu || p.res || !p.zeros) return false;
       for (int s = 0; s < p.nseg; ++s)
-        if (p.seg[s].out_dtype != kF16 || p.seg[s].up2 || p.seg[s].dst_planar || p.seg[s].mult) return false;
+        if (p.seg[s].out_dtype != p.dtype || p.seg[s].up2 || p.seg[s].dst_planar || (p.dtype == kI8) != (p.seg[s].mult != nullptr)) return false;
     }
     for (int s = 0; s < p.nseg; ++s)
       if (((p.seg[s].n_count + 15) & ~15) < c.bn) return false;
@@ -1435,7 +1465,7 @@ struct DualKind {
   const char* name;
   void (*fn)(const ConvParams, const ConvParams, int);
 };
-enum { kDualRegq = 0, kDual1x1, kDualRegqI8, kDualBig, kDualBigI8, kDualWs, kDualKinds };
+enum { kDualRegq = 0, kDual1x1, kDualRegqI8, kDualBig, kDualBigI8, kDualWs, kDualWsI8, kDualKinds };
 const DualKind kDual[kDualKinds] = {
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3<regq 8x16,64,128 | regq 8x8,64,256>", conv_dual_head3x3},
     {kCfg128x16k64, kCfg128x16k64, 256, "conv_dual_head1x1<glds 128,16,64 x2>", conv_dual_head1x1},
@@ -1443,6 +1473,7 @@ const DualKind kDual[kDualKinds] = {
     {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big<regq 16x16,64,128 | regq 8x16,64,256>", conv_dual_head3x3_big},
     {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big_i8<regq i8,16x16,64,128 | regq i8,8x16,64,256>", conv_dual_head3x3_big_i8},
     {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws<ws 16x16,64,128 | ws 8x16,64,256>", conv_dual_head3x3_ws},
+    {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws_i8<ws i8,16x16,64,128 | ws i8,8x16,64,256>", conv_dual_head3x3_ws_i8},
 };
 }  // namespace
 
@@ -1453,15 +1484,17 @@ int conv_dual_match(const ConvParams& a, const ConvParams& b) {
   // +2.5 % frames/s), opt-in for int8 (measured slower: 0.229 vs 0.2245 ms). UNINA_DUAL_BIG=0 / 1 overrides.
   const char* bigenv = getenv("UNINA_DUAL_BIG");
   const bool big = bigenv ? bigenv[0] == '1' : (a.dtype == kF16);
+  const char* wsenv = getenv("UNINA_DUAL_WS");
+  const bool ws = !(wsenv && wsenv[0] == '0') && !bigenv;
   if (a.dtype == kI8 && b.dtype == kI8) {
+    if (ws && fits(kDualWsI8)) return kDualWsI8;
     if (big && fits(kDualBigI8)) return kDualBigI8;
     return fits(kDualRegqI8) ? kDualRegqI8 : -1;
   }
   if (a.dtype != kF16 || b.dtype != kF16) return -1;
   // the weights-stationary pair: default for fp16 (same-box A/B against the register-queue pair: +2-3 % frames/s at 2 frames in
   // flight, serial latency equal within noise; workgroup lives 9-11 us against 12-15). UNINA_DUAL_WS=0 falls back.
-  const char* wsenv = getenv("UNINA_DUAL_WS");
-  if (!(wsenv && wsenv[0] == '0') && !bigenv && fits(kDualWs)) return kDualWs;
+  if (ws && fits(kDualWs)) return kDualWs;
   if (big && fits(kDualBig)) return kDualBig;
   if (fits(kDualRegq)) return kDualRegq;
   auto tiny = [](const ConvParams& p) {
@@ -1488,7 +1521,7 @@ hipError_t conv_dual_launch(int kind, const ConvParams& pa_in, const ConvParams&
     if (kind != kDualBig && kind != kDualWs) return hipErrorInvalidValue;
     fn = kind == kDualWs ? conv_dual_head3x3_ws_stamped : conv_dual_head3x3_big_stamped;
   }
-  hipLaunchKernelGGL(fn, dim3(na + nb, 1, 1), dim3(k.threads, 1, 1), max_sz(sa, sb), stream, pa, pb, kind == kDualWs ? nb : na);   // (the weights-stationary pair puts conv B first)
+  hipLaunchKernelGGL(fn, dim3(na + nb, 1, 1), dim3(k.threads, 1, 1), max_sz(sa, sb), stream, pa, pb, (kind == kDualWs || kind == kDualWsI8) ? nb : na);   // (the weights-stationary pairs put conv B first)
   return hipGetLastError();
 }
 
