@@ -943,10 +943,12 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
 
   // destination through a buffer descriptor: lanes outside the image / past the slice get an out-of-range offset and
   // the range check drops their store -- no exec masking, the whole K loop stays one basic block
-  const unsigned rowb = (unsigned)(p.Wo * sg.dst_ld * ESZ);
+  const bool out16 = ESZ == 2 || sg.out_dtype == kF16;   // (int8 convs may feed an fp16 buffer: the layer in front of the heads' fp16 output convs)
+  const int DSZ = out16 ? 2 : 1;
+  const unsigned rowb = (unsigned)(p.Wo * sg.dst_ld * DSZ);
   const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(sg.dst, 0, (int)((unsigned)p.Ho * rowb), 0x00020000);
   const bool lane_ok = n_ok && tx0 + l15 < p.Wo;
-  const unsigned voff0 = lane_ok ? (unsigned)(((ty0 * p.Wo + tx0 + l15) * sg.dst_ld + n) * ESZ) : 0x40000000u;
+  const unsigned voff0 = lane_ok ? (unsigned)(((ty0 * p.Wo + tx0 + l15) * sg.dst_ld + n) * DSZ) : 0x40000000u;
 
   const unsigned lo0 = (unsigned)(l15 * PITCH + lq * 16);
   unsigned lo1 = lo0 + SPLIT;                     // second base: ds offsets are 16 bits
@@ -970,18 +972,30 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
       for (int e = 0; e < 4; ++e) hv[e] = (half_t)(v[e] > 0.f ? v[e] : 0.f);
       typedef float floatx2 __attribute__((ext_vector_type(2)));
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs, voff0 + (unsigned)r * rowb, 0, 0);
-    } else {   // the per-op kernels' int8 epilogue operation for operation (conv_epilogue): fma, ReLU, rint(y / s_out), clamp
+    } else {   // the per-op kernels' int8 epilogue operation for operation (conv_epilogue): fma, ReLU, then fp16 or rint(y / s_out), clamp
       const floatx4 c = E::to_float(acc[r & 3]);
-      unsigned q = 0;
+      float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float v = __builtin_fmaf(c[e], mult[e], bias[e]);
-        v = v > 0.f ? v : 0.f;
-        float t = __builtin_rintf(v * out_inv);
-        t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
-        q |= ((unsigned)(int)t & 0xFFu) << (8 * e);
+        v[e] = __builtin_fmaf(c[e], mult[e], bias[e]);
+        v[e] = v[e] > 0.f ? v[e] : 0.f;
       }
-      __builtin_amdgcn_raw_buffer_store_b32(q, drs, voff0 + (unsigned)r * rowb, 0, 0);
+      if (out16) {   // (wave-uniform)
+        half4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = (half_t)v[e];
+        typedef float floatx2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs, voff0 + (unsigned)r * rowb, 0, 0);
+      } else {
+        unsigned q = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = __builtin_rintf(v[e] * out_inv);
+          t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
+          q |= ((unsigned)(int)t & 0xFFu) << (8 * e);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(q, drs, voff0 + (unsigned)r * rowb, 0, 0);
+      }
     }
   };
   static_for<0, STEPS>([&](auto sc) {
@@ -1337,7 +1351,8 @@ bool conv_config_valid(const ConvParams& p, int cfg) {
     if (c.ws) {
       if (!p.relu || p.res || !p.zeros) return false;
       for (int s = 0; s < p.nseg; ++s)
-        if (p.seg[s].out_dtype != p.dtype || p.seg[s].up2 || p.seg[s].dst_planar || (p.dtype == kI8) != (p.seg[s].mult != nullptr)) return false;
+        if ((p.seg[s].out_dtype != p.dtype && !(p.dtype == kI8 && p.seg[s].out_dtype == kF16)) || p.seg[s].up2 || p.seg[s].dst_planar ||
+            (p.dtype == kI8) != (p.seg[s].mult != nullptr)) return false;
     }
     for (int s = 0; s < p.nseg; ++s)
       if (((p.seg[s].n_count + 15) & ~15) < c.bn) return false;
