@@ -197,7 +197,11 @@ def main():
             e0.infer(f, conf, 0.45, 0.1)
             if i >= 20:
                 lat.append((time.perf_counter() - a) * 1e3)
-        lat = np.array(lat)
+        lat_py = np.array(lat)
+        # the same serial loop timed INSIDE the C ABI (unina_serial_latency): what a C / C++ caller of the drop-in library sees.
+        # The ctypes call above adds ~12 us per frame of binding cost (argument conversion, record copy into a fresh array).
+        torch.cuda.synchronize()
+        lat = e0.serial_latency(frames, 20 + args.latency_frames, conf, 0.45, 0.1)[20:]
 
         # ---- roofline of the dominant kernel: live HIP-event timing of every op on the launch stream ----
         ops = e0.profile_ops(iters=20)
@@ -267,7 +271,9 @@ def main():
                        "frames_in_flight_per_gpu": IN_FLIGHT, "parallelism": f"replica x{world}, RCCL all-gather of detection slots every {GATHER_EVERY} frames on a comm stream ({GATHER_BANKS} banks)" if world > 1 else "1 GPU",
                        "thresholds": {"conf": conf, "iou": 0.45, "conformal_q": 0.1}, "detections_last_frame": n_det},
             "latency_ms": {"p50": round(float(np.percentile(lat, 50)), 4), "p99": round(float(np.percentile(lat, 99)), 4),
-                           "mean": round(float(lat.mean()), 4), "frames": len(lat), "mode": "serial, submit->detections on host"},
+                           "mean": round(float(lat.mean()), 4), "frames": len(lat),
+                           "mode": "serial, submit->detections on host, timed inside the C ABI (unina_serial_latency)",
+                           "through_python_ctypes": {"p50": round(float(np.percentile(lat_py, 50)), 4), "p99": round(float(np.percentile(lat_py, 99)), 4)}},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -111,6 +111,11 @@ typedef struct {
   float std_r, std_g, std_b;
 } NormParams; /* cuda_preprocess.h:38-45 */
 
+/* `n_calls` serial unina_infer calls over a ring of `n_ring` device frames, each timed on the host's steady clock from entry to
+ * return (records copied out): the latency a C / C++ caller sees, free of a binding layer's per-call cost. lat_us[n_calls]. */
+int unina_serial_latency(unina_engine_t *e, const float *const *d_frames, int n_ring, int n_calls, float conf_threshold,
+                         float iou_threshold, float conformal_q, double *lat_us, hipStream_t stream);
+
 /* Camera frame -> detections in one call: unina_infer with the pre-process of cuda_preprocess.h:50-112
  * (preprocess_bgra when the frame has the network's size, preprocess_bgra_resize otherwise) computed inside the
  * stem kernel, i.e. perception_node.cpp:601-656 (preprocess_bgra_resize ... copy_valid_detections_to_host) as ONE

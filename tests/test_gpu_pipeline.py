@@ -158,3 +158,26 @@ open(sys.argv[1], "w").write("\n".join(out))
     assert len(base) == 10 and "head64ws" in base[4] and "conv_dual_head3x3_ws" in base[4]      # the defaults are the new kernels
     assert alt[4] != base[4]                                                                        # ... and the switch selected the old ones
     assert [l for i, l in enumerate(alt) if i % 5 != 4] == [l for i, l in enumerate(base) if i % 5 != 4]
+
+
+def test_serial_latency_entry_point_times_unina_infer_inside_the_abi(pkg, sd7, torch_cuda):
+    """unina_serial_latency = the bench's serial latency loop inside the C ABI (what a C / C++ caller sees): plausible values, below
+    what the ctypes path measures for the same frames, and the engine still returns the same detections afterwards."""
+    import time
+    from unina_yolo_dla_amd.engine import Engine
+    torch = torch_cuda
+    e = Engine.from_state_dict(sd7)
+    try:
+        frames = [torch.from_numpy(pkg.rng.frame(1234 + i, 640, 640)).cuda() for i in range(3)]
+        want = e.infer(frames[0], 0.5, 0.45, 0.1).tobytes()
+        lat = e.serial_latency(frames, 120, 0.5, 0.45, 0.1)[20:]
+        assert lat.shape == (100,) and 0.05 < np.median(lat) < 2.0 and lat.min() > 0.03
+        py = []
+        for i in range(60):
+            t = time.perf_counter()
+            e.infer(frames[i % 3], 0.5, 0.45, 0.1)
+            py.append((time.perf_counter() - t) * 1e3)
+        assert np.median(lat) < np.median(py[10:]) + 0.002
+        assert e.infer(frames[0], 0.5, 0.45, 0.1).tobytes() == want
+    finally:
+        e.close()

@@ -105,6 +105,8 @@ struct unina_engine {
   std::vector<hipStream_t> side_streams;   // extra capture streams: independent branches become parallel graph paths
   std::vector<hipEvent_t> op_events;       // one per op (capture-time dependency edges)
   hipEvent_t fork_event = nullptr;
+  double t_submit_us = 0, t_wait_us = 0, t_copy_us = 0;   // UNINA_TIMING=1: host-side split of unina_infer (printed at unload)
+  long t_calls = 0;
   int n_streams = 1;                       // parallel graph paths (UNINA_STREAMS); measured no gain on ROCm 7.2, so 1
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -1601,6 +1603,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
 
 void unina_unload_engine(unina_engine_t* e) {
   if (!e) return;
+  if (e->t_calls) fprintf(stderr, "unina_infer host split over %ld calls: submit (params + hipGraphLaunch) %.2f us, wait for the completion word %.2f us, record copy %.2f us\n", e->t_calls, e->t_submit_us / e->t_calls, e->t_wait_us / e->t_calls, e->t_copy_us / e->t_calls);
   (void)hipSetDevice(e->device);
   drop_graph(e);
   if (e->capture_stream) (void)hipStreamDestroy(e->capture_stream);
@@ -1720,9 +1723,12 @@ int unina_infer(unina_engine_t* e, const float* d_images, float conf, float iou,
       e->done_flag = &e->h_result_dev->seq;
       e->done_value = seq;
     }
+    static const bool timing = getenv("UNINA_TIMING") != nullptr;
+    const auto ta = std::chrono::steady_clock::now();
     int rc = unina_infer_async(e, d_images, conf, iou, q, e->h_result_dev->det, &e->h_result_dev->count, stream);
     e->done_flag = nullptr;
     if (rc != UNINA_OK) return rc;
+    const auto tb = std::chrono::steady_clock::now();
     if (host_poll) {
       volatile unsigned int* flag = &e->h_result->seq;
       const auto t0 = std::chrono::steady_clock::now();
@@ -1737,6 +1743,16 @@ int unina_infer(unina_engine_t* e, const float* d_images, float conf, float iou,
     } else {
       HIPCHK(e, hipStreamSynchronize(stream));
     }
+    if (timing) {
+      const auto tc = std::chrono::steady_clock::now();
+      const int n0 = e->h_result->count;
+      if (n0 >= 0 && n0 <= MAX_DETECTIONS) memcpy(out, e->h_result->det, sizeof(GpuDetection) * (size_t)n0);
+      const auto td = std::chrono::steady_clock::now();
+      e->t_submit_us += std::chrono::duration<double, std::micro>(tb - ta).count();
+      e->t_wait_us += std::chrono::duration<double, std::micro>(tc - tb).count();
+      e->t_copy_us += std::chrono::duration<double, std::micro>(td - tc).count();
+      ++e->t_calls;
+    }
   } else {
     int rc = unina_infer_async(e, d_images, conf, iou, q, e->d_result->det, &e->d_result->count, stream);
     if (rc != UNINA_OK) return rc;
@@ -1747,6 +1763,23 @@ int unina_infer(unina_engine_t* e, const float* d_images, float conf, float iou,
   if (n < 0 || n > MAX_DETECTIONS) return fail(e, UNINA_ERR_STATE, "post-process returned count %d", n);
   memcpy(out, e->h_result->det, sizeof(GpuDetection) * (size_t)n);
   *out_count = n;
+  return UNINA_OK;
+}
+
+// `n_calls` serial unina_infer calls over a ring of `n_ring` input frames, each timed on the host's steady clock from entry to
+// return (detections copied out): the latency a C / C++ caller of this ABI sees, without a binding layer's per-call cost
+// (the ctypes path adds ~12 us). lat_us[n_calls].
+int unina_serial_latency(unina_engine_t* e, const float* const* d_frames, int n_ring, int n_calls, float conf, float iou, float q,
+                         double* lat_us, hipStream_t stream) {
+  if (!e || !d_frames || !lat_us || n_ring < 1 || n_calls < 1) return UNINA_ERR_ARG;
+  std::vector<GpuDetection> out(MAX_DETECTIONS);
+  int n = 0;
+  for (int i = 0; i < n_calls; ++i) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = unina_infer(e, d_frames[i % n_ring], conf, iou, q, out.data(), &n, stream);
+    lat_us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (rc != UNINA_OK) return rc;
+  }
   return UNINA_OK;
 }
 

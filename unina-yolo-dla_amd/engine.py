@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "unina_load_engine", "unina_unload_engine", "unina_engine_input_dims", "unina_set_tensor_address",
     "unina_tensor_address", "unina_enqueue", "unina_infer", "unina_infer_bgra", "unina_infer_async", "unina_postprocess_async",
     "unina_last_error", "unina_op_count", "unina_get_op_info", "unina_profile_ops", "unina_profile_post", "unina_debug_read_buffer",
-    "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune", "unina_debug_post_stamps", "unina_debug_conv_stamps", "unina_debug_dual_stamps", "unina_debug_dual_timeline",
+    "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune", "unina_debug_post_stamps", "unina_debug_conv_stamps", "unina_debug_dual_stamps", "unina_debug_dual_timeline", "unina_serial_latency",
     "unina_set_fusion", "unina_fusion_groups", "unina_debug_fusable_groups",
     "create_norm_params_imagenet", "create_norm_params", "preprocess_bgra_resize", "preprocess_bgra", "preprocess_nv12",
     "allocate_preprocess_buffer", "free_preprocess_buffer", "create_preprocess_stream", "destroy_preprocess_stream",
@@ -97,6 +97,7 @@ def load_library() -> C.CDLL:
     L.unina_debug_conv_stamps.argtypes = [vp, ci, C.POINTER(C.c_longlong), vp]
     L.unina_debug_dual_stamps.argtypes = [vp, ci, C.POINTER(C.c_longlong), vp]
     L.unina_debug_dual_timeline.argtypes = [vp, ci, C.POINTER(C.c_longlong), ci, vp]
+    L.unina_serial_latency.argtypes = [vp, C.POINTER(vp), ci, ci, cf, cf, cf, C.POINTER(C.c_double), vp]
     # cuda_preprocess.h drop-in symbols
     L.create_norm_params_imagenet.restype = NormParams
     L.create_norm_params.restype = NormParams
@@ -232,6 +233,13 @@ class Engine:
         self._check(self.L.unina_infer(self.h, ptr, conf_thr, iou_thr, conformal_q, self._host_out_ptr, self._host_n_ref,
                                        _stream_ptr(stream)))
         return self._host_out[:self._host_n.value].copy()
+
+    def serial_latency(self, frames, n_calls: int, conf_thr: float = 0.5, iou_thr: float = 0.45, conformal_q: float = 0.1, stream=None):
+        """`n_calls` serial unina_infer calls over the ring `frames` (CUDA tensors), timed INSIDE the C ABI: latencies in ms."""
+        ptrs = (C.c_void_p * len(frames))(*[f.data_ptr() for f in frames])
+        lat = (C.c_double * n_calls)()
+        self._check(self.L.unina_serial_latency(self.h, ptrs, len(frames), n_calls, conf_thr, iou_thr, conformal_q, lat, _stream_ptr(stream)))
+        return np.array(lat[:], dtype=np.float64) * 1e-3
 
     def infer_bgra(self, frame, width: int, height: int, pitch: int, norm: Optional[NormParams] = None,
                    conf_thr: float = 0.5, iou_thr: float = 0.45, conformal_q: float = 0.1, stream=None):
