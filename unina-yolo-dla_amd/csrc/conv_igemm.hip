@@ -864,6 +864,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
 // accumulators are live (a row is converted and stored while the next ones are being accumulated). Each output row still
 // receives its products in the order ky, kx, cb from a zero accumulator, i.e. the K order of every other conv kernel:
 // results are bit-identical.
+#ifndef UNINA_WS_STORE_AUX
+#define UNINA_WS_STORE_AUX 0   // cache policy bits of the output stores. 16 = sc1 (write-through: no dirty L2 lines at the kernel boundary) was
+                               // tried: the launch itself 17.4 vs 17.8-18.0 us event-timed, serial latency and frames/s unchanged (same-box A/B)
+#endif
 template <int TH, int CIN, int NW, bool STAMPS = false, typename T = half_t>
 __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, int nwg) {
   typedef Elem<T> E;     // half_t, or signed char (INT8 engines: int8 patch, 64-k weight blocks, exact int32 accumulators)
@@ -971,7 +975,7 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
 #pragma unroll
       for (int e = 0; e < 4; ++e) hv[e] = (half_t)(v[e] > 0.f ? v[e] : 0.f);
       typedef float floatx2 __attribute__((ext_vector_type(2)));
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs, voff0 + (unsigned)r * rowb, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs, voff0 + (unsigned)r * rowb, 0, UNINA_WS_STORE_AUX);
     } else {   // the per-op kernels' int8 epilogue operation for operation (conv_epilogue): fma, ReLU, then fp16 or rint(y / s_out), clamp
       const floatx4 c = E::to_float(acc[r & 3]);
       float v[4];
@@ -985,7 +989,7 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
 #pragma unroll
         for (int e = 0; e < 4; ++e) hv[e] = (half_t)v[e];
         typedef float floatx2 __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs, voff0 + (unsigned)r * rowb, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs, voff0 + (unsigned)r * rowb, 0, UNINA_WS_STORE_AUX);
       } else {
         unsigned q = 0;
 #pragma unroll
@@ -994,7 +998,7 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
           t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
           q |= ((unsigned)(int)t & 0xFFu) << (8 * e);
         }
-        __builtin_amdgcn_raw_buffer_store_b32(q, drs, voff0 + (unsigned)r * rowb, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(q, drs, voff0 + (unsigned)r * rowb, 0, UNINA_WS_STORE_AUX);
       }
     }
   };
