@@ -11,8 +11,15 @@ import torch.nn.functional as F
 from unina_yolo_dla_amd import export
 
 
+def split16(t):
+    """fp32 tensor -> (hi, lo) fp16 pair as fp32 tensors: hi = fp16(t), lo = fp16(t - hi) (the SPLIT engine's storage format)."""
+    hi = t.float().half().float()
+    lo = (t.float() - hi).half().float()
+    return hi, lo
+
+
 def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = True, teacher: dict = None,
-                 precise_w=None, precise_a=None, builder32: "export.EngineBuilder" = None):
+                 precise_w=None, precise_a=None, builder32: "export.EngineBuilder" = None, split: bool = False):
     """x: [1,3,H,W] fp32. Returns ({output name: [C,H,W] fp32}, {buffer name: [C,H,W] fp32}).
     int8 buffers are returned as their integer codes (multiply by the buffer scale to dequantise).
 
@@ -24,13 +31,18 @@ def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = Tr
     Error-budget switches (tools/fp16_error_budget.py): ops whose index is in `precise_w` take their weights from
     `builder32` (an FP32 builder of the same state_dict: same op order, fp32 folded weights) instead of the fp16 blob;
     ops in `precise_a` store their output without the fp16 rounding. Everything else is unchanged, so the head error
-    of such a run against the fp32 oracle is the contribution of the roundings left switched on."""
+    of such a run against the fp32 oracle is the contribution of the roundings left switched on.
+
+    A SPLIT builder (or split=True with an FP32 builder): the SPLIT precision mode's arithmetic -- every folded weight and every stored
+    activation is an fp16 pair hi + lo, a conv is the three fp16 products hi*hi + lo*hi + hi*lo accumulated in fp32
+    (the lo*lo term is dropped), the stem and the epilogues are fp32."""
     precise_w = precise_w or ()
     precise_a = precise_a or ()
     blob32 = bytes(builder32.blob) if builder32 is not None else None
     cur_op = [0]
     prec = builder.precision
-    wdt = {export.FP16: "<f2", export.FP32: "<f4", export.INT8: "<f2"}[prec]
+    split = split or prec == export.SPLIT
+    wdt = {export.FP16: "<f2", export.FP32: "<f4", export.INT8: "<f2", export.SPLIT: "<f2"}[prec]
     blob = bytes(builder.blob)
     bdtype = [b[4] for b in builder.buffers]
     bscale = [b[6] for b in builder.buffers]
@@ -52,6 +64,9 @@ def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = Tr
             return torch.clamp(torch.round(y.float() * np.float32(1.0 / bscale[dst_buf])), -127, 127).to(y.dtype)
         if d == export.BUF_F16 and fp16 and cur_op[0] not in precise_a:
             return y.half().to(y.dtype)
+        if split and d in (export.BUF_F32_NHWC, export.BUF_S16):
+            hi, lo = split16(y)
+            return (hi + lo).to(y.dtype)
         return y.float().to(y.dtype)
 
     def real(buf_idx, t):
@@ -98,6 +113,18 @@ def run_op_table(builder: "export.EngineBuilder", x: np.ndarray, fp16: bool = Tr
                     w = export.unpack_weights(w, s.n_pad, K).reshape(s.n_pad, k, k, op.cin)[:s.n_count]
                     w = torch.from_numpy(w.astype(np.float32)).permute(0, 3, 1, 2).contiguous()
                     y = F.conv2d(real(op.src_buf, xin).float(), w, b, stride=op.s, padding=k // 2)[0].to(src.dtype)
+                elif split:
+                    if prec == export.SPLIT:
+                        w = np.frombuffer(blob, dtype="<f2", count=2 * s.n_pad * K, offset=s.w_off)
+                        w = export.unpack_weights_split(w, s.n_pad, K).reshape(s.n_pad, k, k, op.cin)[:s.n_count]
+                    else:
+                        w = np.frombuffer(blob, dtype="<f4", count=s.n_pad * K, offset=s.w_off)
+                        w = export.unpack_weights(w, s.n_pad, K).reshape(s.n_pad, k, k, op.cin)[:s.n_count]
+                    w = torch.from_numpy(w.astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+                    wh, wl = split16(w)
+                    xh, xl = split16(xin)
+                    y = (F.conv2d(xh, wl, None, stride=op.s, padding=k // 2) + F.conv2d(xl, wh, None, stride=op.s, padding=k // 2)
+                         + F.conv2d(xh, wh, b, stride=op.s, padding=k // 2))[0].to(src.dtype)
                 else:
                     w = np.frombuffer(blob, dtype=wdt, count=s.n_pad * K, offset=s.w_off)
                     w = export.unpack_weights(w, s.n_pad, K).reshape(s.n_pad, k, k, op.cin)[:s.n_count]

@@ -127,3 +127,30 @@ def test_histogram_calibrator_range_selections(pkg):
     assert export.calibrate(frames)["x"] == 40.0
     both = export.calibrate_all(frames, {"m": ("max", None), "e": ("entropy", None)})
     assert both["m"]["x"] == 40.0 and both["e"]["x"] < 40.0
+
+
+def test_split_op_table_is_fp32_like(pkg, sd7, oracle_mod, oracle_sd7):
+    """STRICT precision (export.SPLIT): fp16 hi/lo pairs for every folded weight and stored activation, three fp16 products per
+    term (hi*hi + hi*lo + lo*hi). The emulated table must sit two orders of magnitude closer to the fp32 oracle than the
+    fp16 table (tools/fp16_error_budget.py modes: worst detection 5.5e-6 / IoU 0.99999 over 4 711 detections at 640^2)."""
+    from unina_yolo_dla_amd import export
+    torch.set_num_threads(4)
+    g = pkg.graph.Graph(in_h=64, in_w=64)
+    b = export.EngineBuilder(sd7, g, export.SPLIT)
+    assert b.precision == export.SPLIT and all(buf[4] == export.BUF_S16 for buf in b.buffers if buf[0].startswith("backbone."))
+    # pack / unpack of the (hi | lo) block pairs round-trips and carries ~22 mantissa bits
+    rng = np.random.default_rng(1)
+    w = rng.normal(0, 0.05, (32, 64))
+    hi = w.astype(np.float16)
+    lo = (w - hi.astype(np.float64)).astype(np.float16)
+    packed = export.pack_weights_split(hi, lo)
+    assert packed.dtype == np.float16 and packed.size == 2 * w.size
+    back = export.unpack_weights_split(packed, 32, 64)
+    assert np.abs(back - w).max() < 2.0 ** -20 * np.abs(w).max()
+    x = pkg.rng.frame(1234, 64, 64)
+    outs, named = run_op_table(b, x)
+    ref = oracle_mod.forward(oracle_sd7, x, keep_all=True)
+    for n in pkg.graph.OUTPUT_NAMES:
+        np.testing.assert_allclose(outs[n], ref[n], atol=1e-4, rtol=0, err_msg=n)
+    for bname, oname in {"backbone.stem": "backbone.stem", "neck.cat_pan2": "neck.cat_pan2", "backbone.sppf.cat": "backbone.sppf.cat"}.items():
+        np.testing.assert_allclose(named[bname], ref[oname], atol=1e-4 * max(1.0, np.abs(ref[oname]).max()), rtol=0, err_msg=bname)

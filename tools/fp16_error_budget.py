@@ -143,12 +143,13 @@ def main():
     print(f"candidate mixed modes, {a.size}x{a.size}, seeds {seeds}, conf 0.5 / iou 0.45 / q 0.1: worst detection over all seeds")
     print(f"{'mode':38s}{'dets':>7s}{'min IoU':>10s}{'max|ds|':>10s}{'p99|ds|':>10s}{'IoU<.999':>10s}{'|ds|>=1e-3':>11s}"
           f"{'rms p3_cls':>11s}")
+    modes.append(("SPLIT: fp16 hi+lo pairs, 3 MFMA terms", None, None))
     for name, pw, pa in modes:
         agg = dict(n=0, min_iou=1.0, max_ds=0.0, p99=[], bi=[], bd=[], r=[])
         for seed in seeds:
             x = u.rng.frame(seed, a.size, a.size)
             ref = run(x, allops, allops)
-            h = run(x, pw, pa)
+            h = run_op_table(b32, x, fp16=False, split=True)[0] if pw is None else run(x, pw, pa)
             s = det_stats(h, ref)
             agg["n"] += s["n"]
             agg["min_iou"] = min(agg["min_iou"], s["min_iou"])

@@ -40,29 +40,60 @@ def hipcc() -> str:
 
 
 def _deps() -> List[str]:
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     hdrs.append(os.path.join(os.path.dirname(PKG), "include", "unina_mi355.h"))
     return hdrs
 
 
+def _sha(paths: List[str], extra: str = "") -> str:
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def source_hash() -> str:
+    """Hash of every source the library is built from (csrc/*.hip, csrc/*.h, include/unina_mi355.h). It is compiled into
+    the library (unina_version() ends with it), so a test can tell that the loaded binary was built from the sources
+    under test and not from an older tree (the .so travels to the GPU box; nothing else ties the two together)."""
+    return _sha([os.path.join(CSRC, u) for u in sorted(UNITS)] + _deps())[:16]
+
+
 def build_native(force: bool = False, verbose: bool = False) -> str:
+    """Rebuilds by CONTENT: a unit is recompiled when the hash of its source, the headers and its flags differs from the
+    one stored next to its object file (mtimes do not survive a checkout or a copy to another box)."""
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
-    dep_mtime = max(os.path.getmtime(h) for h in _deps())
+    deps = _deps()
+    shash = source_hash()
     objs = []
     jobs = []
     for unit, extra in UNITS.items():
         src = os.path.join(CSRC, unit)
         obj = os.path.join(OBJ, unit + ".o")
+        stamp = obj + ".hash"
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), dep_mtime):
-            jobs.append((unit, [cc, *COMMON, *extra, "-c", src, "-o", obj]))
+        flags = [*COMMON, *extra]
+        if unit == "engine.hip":
+            flags.append(f'-DUNINA_SOURCE_HASH="{shash}"')
+        want = _sha([src] + deps, " ".join(flags))
+        have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+        if force or not os.path.exists(obj) or have != want:
+            jobs.append((unit, [cc, *flags, "-c", src, "-o", obj], stamp, want))
 
     def compile_one(job):
-        unit, cmd = job
+        unit, cmd, stamp, want = job
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
+        if os.path.exists(stamp):
+            os.remove(stamp)
         r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode == 0:
+            with open(stamp, "w") as f:
+                f.write(want)
         return unit, r.returncode, r.stderr
 
     # the units are independent: compile them side by side (a cold build is ~3 min of hipcc time, ~1.5 min wall on 4 jobs)

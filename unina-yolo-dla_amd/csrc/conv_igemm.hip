@@ -86,16 +86,37 @@ __device__ __forceinline__ void stamp_wg(const ConvParams& p, int which) {
 typedef int intx4 __attribute__((ext_vector_type(4)));
 template <typename T> struct Elem;
 template <> struct Elem<half_t> {
-  static constexpr int kChunk = 8, kBlockK = 32;
+  static constexpr int kChunk = 8, kBlockK = 32, kPlanes = 1;
   typedef half8 frag;
   typedef floatx4 acc_t;
   static __device__ __forceinline__ acc_t mma(const frag& a, const frag& b, acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
   }
   static __device__ __forceinline__ floatx4 to_float(const acc_t& c) { return c; }
+  static __device__ __forceinline__ frag lds(const unsigned char* at, int) { return *reinterpret_cast<const frag*>(at); }
+};
+// split fp16 (kS16): a fragment is the pair (hi, lo) of 16-byte fragments; its LDS / block image keeps the lo plane `lo_off`
+// bytes behind the hi plane (the next 1-KiB block of a staged block pair). Three MFMAs per k block, small terms first.
+struct half8x2 {
+  half8 h, l;
+};
+template <> struct Elem<s16_t> {
+  static constexpr int kChunk = 8, kBlockK = 32, kPlanes = 2;
+  typedef half8x2 frag;
+  typedef floatx4 acc_t;
+  static __device__ __forceinline__ acc_t mma(const frag& a, const frag& b, acc_t c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.l, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.h, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ floatx4 to_float(const acc_t& c) { return c; }
+  static __device__ __forceinline__ frag lds(const unsigned char* at, int lo_off) {
+    return frag{*reinterpret_cast<const half8*>(at), *reinterpret_cast<const half8*>(at + lo_off)};
+  }
 };
 template <> struct Elem<float> {
-  static constexpr int kChunk = 4, kBlockK = 16;
+  static constexpr int kChunk = 4, kBlockK = 16, kPlanes = 1;
+  static __device__ __forceinline__ floatx4_t lds(const unsigned char* at, int) { return *reinterpret_cast<const floatx4_t*>(at); }
   typedef floatx4_t frag;
   typedef floatx4 acc_t;
   static __device__ __forceinline__ acc_t mma(const frag& a, const frag& b, acc_t c) {
@@ -106,7 +127,8 @@ template <> struct Elem<float> {
   static __device__ __forceinline__ floatx4 to_float(const acc_t& c) { return c; }
 };
 template <> struct Elem<signed char> {
-  static constexpr int kChunk = 16, kBlockK = 64;
+  static constexpr int kChunk = 16, kBlockK = 64, kPlanes = 1;
+  static __device__ __forceinline__ intx4 lds(const unsigned char* at, int) { return *reinterpret_cast<const intx4*>(at); }
   typedef intx4 frag;
   typedef intx4 acc_t;
   static __device__ __forceinline__ acc_t mma(const frag& a, const frag& b, acc_t c) {
@@ -165,6 +187,63 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvSeg
   const int esz = od == kF32 ? 4 : (od == kF16 ? 2 : 1);
   const int rowb = BN * esz + 16;              // padded LDS row (bytes)
   const int n_w0 = wn * (WN_T * 16);           // tile-local first channel of this wave
+  if constexpr (E::kPlanes == 2) {
+    // split fp16: 8 bytes of the hi plane and 8 of the lo plane per lane straight from the accumulators (no staging pass);
+    // the folded x2 upsample writes the pair to its 2x2 block
+#pragma unroll
+    for (int j = 0; j < WN_T; ++j) {
+      const int n = nb0 + n_w0 + j * 16 + lq * 4;
+      if (n >= sg.n_count) continue;
+      const floatx4 bias = ec.bias[j];
+#pragma unroll
+      for (int i = 0; i < WM_T; ++i) {
+        const int pl = (wm * WM_T + i) * 16 + l15;
+        const int m = pix_to_m(pl);
+        if (m < 0) continue;
+        floatx4 v = acc[j][i] + bias;
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+        }
+        if (p.res) {
+          const half_t* rp = static_cast<const half_t*>(p.res) + (size_t)m * p.res_ld + n;
+          const half4 rh = *reinterpret_cast<const half4*>(rp);
+          const half4 rl = *reinterpret_cast<const half4*>(reinterpret_cast<const unsigned char*>(rp) + p.res_lo);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rh[r] + (float)rl[r];
+        }
+        if (sg.dst_planar) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < sg.n_count) sg.dst_planar[(size_t)(n + r) * p.M + m] = v[r];
+          continue;
+        }
+        half4 hv, lv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          hv[r] = (half_t)v[r];
+          lv[r] = (half_t)(v[r] - (float)hv[r]);
+        }
+        unsigned char* dst = static_cast<unsigned char*>(sg.dst);
+        if (sg.up2) {
+          const int oy = m / p.Wo, ox = m - oy * p.Wo;
+          unsigned char* d = dst + (((size_t)(2 * oy) * (2 * p.Wo) + 2 * ox) * sg.dst_ld + n) * 2;
+          const size_t px = (size_t)sg.dst_ld * 2, row = (size_t)(2 * p.Wo) * px;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            unsigned char* dq = d + (q & 1) * px + (q >> 1) * row;
+            *reinterpret_cast<half4*>(dq) = hv;
+            *reinterpret_cast<half4*>(dq + sg.dst_lo) = lv;
+          }
+        } else {
+          unsigned char* d = dst + ((size_t)m * sg.dst_ld + n) * 2;
+          *reinterpret_cast<half4*>(d) = hv;
+          *reinterpret_cast<half4*>(d + sg.dst_lo) = lv;
+        }
+      }
+    }
+    return;
+  }
   const bool direct = DIRECT && od == kF16 && !sg.up2 && sg.dst_planar == nullptr;
   const bool planar = sg.dst_planar != nullptr || direct;
   if (!planar) __syncthreads();                // every wave is done reading the operand buffers: reuse them
@@ -272,7 +351,8 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, int bid, int
   typedef typename E::frag frag_t;
   constexpr int WM_T = BM / (WAVES_M * 16), WN_T = BN / (WAVES_N * 16), KSUB = BK / 32;
   constexpr int KSTEP = KSUB * E::kBlockK;  // input channels per K-step
-  constexpr int ABLK = (BM / 16) * KSUB, WBLK = (BN / 16) * KSUB, NBLK = ABLK + WBLK;
+  constexpr int NP = E::kPlanes;            // split fp16: every block comes as a (hi, lo) pair of adjacent 1-KiB blocks
+  constexpr int ABLK = (BM / 16) * KSUB * NP, WBLK = (BN / 16) * KSUB * NP, NBLK = ABLK + WBLK;
   constexpr int LPT = (NBLK + 3) / 4;            // LDS-DMA instructions per wave per stage (same for every wave)
   constexpr int STAGE_BYTES = LPT * 4 * 1024;
   static_assert(WM_T >= 1 && WN_T >= 1 && KSUB >= 1, "tile");
@@ -311,7 +391,7 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, int bid, int
     w_base[q] = nullptr;
     if (b < ABLK) {
       kind[q] = 0;
-      const int i = b / KSUB, j = b - i * KSUB;
+      const int i = b / (KSUB * NP), jp = b - i * (KSUB * NP), j = jp / NP, pl = jp - j * NP;
       const int m = m_blk + i * 16 + ld_row;
       if (m < p.M) {
         const int oy = fast_div(m, p.wo_magic), ox = m - oy * p.Wo;
@@ -319,13 +399,13 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, int bid, int
         a_ix0[q] = ox * p.stride - p.pad;
         a_off0[q] = (a_iy0[q] * p.W + a_ix0[q]) * p.src_ld;
       }
-      a_base[q] = static_cast<const T*>(p.src) + sg.src_coff + j * E::kBlockK + ld_chunk * E::kChunk;
+      a_base[q] = static_cast<const T*>(p.src) + sg.src_coff + j * E::kBlockK + ld_chunk * E::kChunk + pl * (p.src_lo / (long long)sizeof(T));
     } else if (b < NBLK) {
       kind[q] = 1;
       const int bb = b - ABLK;
-      const int n = bb / KSUB, j = bb - n * KSUB;
+      const int n = bb / (KSUB * NP), jp = bb - n * (KSUB * NP), j = jp / NP, pl = jp - j * NP;
       const int nsub = (nb0 >> 4) + n;
-      if (nsub * 16 < n_pad) w_base[q] = static_cast<const T*>(sg.w) + ((size_t)nsub * kblocks + j) * (1024 / sizeof(T)) + lane * E::kChunk;
+      if (nsub * 16 < n_pad) w_base[q] = static_cast<const T*>(sg.w) + (((size_t)nsub * kblocks + j) * NP + pl) * (1024 / sizeof(T)) + lane * E::kChunk;
     } else {
       kind[q] = 2;
     }
@@ -346,7 +426,7 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, int bid, int
         const bool ok = (unsigned)(a_iy0[q] + i_kh) < (unsigned)p.H && (unsigned)(a_ix0[q] + i_kw) < (unsigned)p.W;
         if (ok) g = a_base[q] + (a_off0[q] + tap_off);
       } else if (kind[q] == 1) {
-        if (w_base[q]) g = w_base[q] + (size_t)i_k32 * (1024 / sizeof(T));
+        if (w_base[q]) g = w_base[q] + (size_t)i_k32 * NP * (1024 / sizeof(T));
       }
       glds16(g, sb + (q * 4 + wid) * 1024);
     }
@@ -386,9 +466,9 @@ __device__ __forceinline__ void conv_glds_body(const ConvParams& p, int bid, int
 #pragma unroll
     for (int j = 0; j < KSUB; ++j) {
 #pragma unroll
-      for (int i = 0; i < WM_T; ++i) f.b[j][i] = *reinterpret_cast<const frag_t*>(sb + (((wm * WM_T + i) * KSUB + j) << 10));
+      for (int i = 0; i < WM_T; ++i) f.b[j][i] = E::lds(sb + ((((wm * WM_T + i) * KSUB + j) * NP) << 10), 1024);
 #pragma unroll
-      for (int n = 0; n < WN_T; ++n) f.a[j][n] = *reinterpret_cast<const frag_t*>(sb + ((ABLK + (wn * WN_T + n) * KSUB + j) << 10));
+      for (int n = 0; n < WN_T; ++n) f.a[j][n] = E::lds(sb + ((ABLK + ((wn * WN_T + n) * KSUB + j) * NP) << 10), 1024);
     }
   };
   auto mma_frags = [&](const Frags& f) {
@@ -1111,14 +1191,14 @@ struct CfgInfo {
 constexpr size_t stage_bytes(int bm, int bn) { return (size_t)bm * (bn * 4 + 16); }  // epilogue staging tile (fp32 worst case)
 constexpr size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 
-template <int BM, int BN, int BK, int WM, int WN, int ST>
+template <int BM, int BN, int BK, int WM, int WN, int ST, int NP = 1>
 constexpr size_t smem_of() {
-  return max_sz((size_t)ST * (((BM / 16 + BN / 16) * (BK / 32) + 3) / 4) * 4 * 1024, stage_bytes(BM, BN));
+  return max_sz((size_t)ST * (((BM / 16 + BN / 16) * (BK / 32) * NP + 3) / 4) * 4 * 1024, stage_bytes(BM, BN));
 }
 
 #define CFG(T, TN, BM, BN, BK, WM, WN, ST)                                                         \
   {BM, BN, BK, ST, "conv_glds<" TN "," #BM "," #BN "," #BK "," #WM "," #WN "," #ST ">",            \
-   conv_glds<T, BM, BN, BK, WM, WN, ST>, smem_of<BM, BN, BK, WM, WN, ST>(), 0, 0}
+   conv_glds<T, BM, BN, BK, WM, WN, ST>, smem_of<BM, BN, BK, WM, WN, ST, Elem<T>::kPlanes>(), 0, 0}
 #define HALO(T, TN, TH, TW, BN, BK, WM, WN, ST)                                                     \
   {(TH) * (TW), BN, BK, ST, "conv3x3_halo<" TN "," #TH "x" #TW "," #BN "," #BK "," #WM "," #WN "," #ST ">", \
    conv3x3_halo<T, TH, TW, BN, BK, WM, WN, ST>, (size_t)ST * ((((BN) / 16) * ((BK) / 32) + 3) / 4) * 4 * 1024, TH, TW}
@@ -1148,7 +1228,7 @@ constexpr size_t smem_of() {
 
 // [dtype][config]; BK is in fp16-equivalent k (KSUB = BK/32 fragment blocks): a K-step covers BK channels in fp16
 // and BK/2 channels in fp32.
-const CfgInfo kCfg[3][kCfgCount] = {
+const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
     {
         CFG(half_t, "f16", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
         CFG(half_t, "f16", 64, 64, 32, 2, 2, 4),    // kCfg64x64k32
@@ -1289,6 +1369,24 @@ const CfgInfo kCfg[3][kCfgCount] = {
         WSI(16, 128, 4),                              // kCfgWs16x16n64c128
         WSI(8, 256, 4),                               // kCfgWs8x16n64c256
     },
+    {   // split fp16 (kS16): a K-step stages (hi, lo) block pairs -- twice the LDS per stage, hence shallower rings on the wide tiles
+        CFG(s16_t, "s16", 64, 64, 64, 2, 2, 3),     // kCfg64x64k64
+        CFG(s16_t, "s16", 64, 64, 32, 2, 2, 4),     // kCfg64x64k32
+        CFG(s16_t, "s16", 128, 64, 64, 2, 2, 3),    // kCfg128x64k64
+        CFG(s16_t, "s16", 128, 64, 32, 2, 2, 4),    // kCfg128x64k32
+        NOCFG,                                      // kCfg128x128k64 (a stage would be 64 KB)
+        CFG(s16_t, "s16", 128, 32, 64, 4, 1, 3),    // kCfg128x32k64
+        CFG(s16_t, "s16", 128, 32, 32, 4, 1, 4),    // kCfg128x32k32
+        CFG(s16_t, "s16", 128, 16, 64, 4, 1, 3),    // kCfg128x16k64
+        CFG(s16_t, "s16", 32, 64, 64, 1, 4, 4),     // kCfg32x64k64
+        NOCFG,                                      // kCfg32x64k64s8
+        NOCFG,                                      // kCfg64x64k64s6
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,   // halo kernels
+        NOCFG, NOCFG,                               // kCfg32x64k128, kCfg64x64k128
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
+        NOCFG, NOCFG,
+    },
 };
 #undef CFG
 #undef HALO
@@ -1301,9 +1399,9 @@ const CfgInfo kCfg[3][kCfgCount] = {
 #undef WS
 #undef WSI
 
-inline int block_k(int dtype) { return dtype == kF32 ? 16 : (dtype == kI8 ? 64 : 32); }
+inline int block_k(int dtype) { return dtype == kF32 ? 16 : (dtype == kI8 ? 64 : 32); }   // (kS16: 32 per plane)
 inline int kstep_of(const ConvParams& p, const CfgInfo& c) { return (c.bk / 32) * block_k(p.dtype); }
-inline size_t esize(const ConvParams& p) { return p.dtype == kF32 ? 4 : (p.dtype == kI8 ? 1 : 2); }
+inline size_t esize(const ConvParams& p) { return p.dtype == kF32 ? 4 : (p.dtype == kI8 ? 1 : 2); }   // (kS16: per plane)
 inline size_t smem_for(const ConvParams& p, const CfgInfo& c) {
   if (!c.th) return c.smem;
   if (c.cin) {  // register-queue kernel: patch (+ < 1 KiB overrun of its last DMA instruction) or the epilogue staging tile
@@ -1336,7 +1434,7 @@ hipError_t conv_init() {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (e != hipSuccess) return e;
   }
-  for (int d = 0; d < 3; ++d)
+  for (int d = 0; d < kNumDTypes; ++d)
     for (int c = 0; c < kCfgCount; ++c) {
       if (!kCfg[d][c].fn) continue;
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kCfg[d][c].fn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1545,7 +1643,7 @@ hipError_t conv_dual_launch(int kind, const ConvParams& pa_in, const ConvParams&
 }
 
 const char* conv_config_name(int cfg, int dtype) {
-  return (cfg >= 0 && cfg < kCfgCount && dtype >= 0 && dtype < 3) ? kCfg[dtype][cfg].name : "?";
+  return (cfg >= 0 && cfg < kCfgCount && dtype >= 0 && dtype < kNumDTypes) ? kCfg[dtype][cfg].name : "?";
 }
 
 }  // namespace unina

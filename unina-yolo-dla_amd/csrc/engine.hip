@@ -148,14 +148,17 @@ int fail(unina_engine* e, int code, const char* fmt, ...) {
 
 size_t buffer_bytes(const BufferDesc& d) {
   const size_t n = (size_t)d.h * d.w * d.c;
-  return d.dtype == kBufF16Nhwc ? n * 2 : (d.dtype == kBufI8Nhwc ? n : n * 4);
+  return d.dtype == kBufF16Nhwc ? n * 2 : (d.dtype == kBufI8Nhwc ? n : n * 4);   // (kBufS16Nhwc: two fp16 planes, hi then lo)
 }
+// split fp16 buffers: byte distance from the hi plane to the lo plane
+long long lo_plane(const BufferDesc& d) { return d.dtype == kBufS16Nhwc ? (long long)d.h * d.w * d.c * 2 : 0; }
 
 // element type of an NHWC activation buffer (-1: not an activation buffer)
 int act_dtype_of(uint32_t buf_dtype) {
-  return buf_dtype == kBufF16Nhwc ? kF16 : (buf_dtype == kBufF32Nhwc ? kF32 : (buf_dtype == kBufI8Nhwc ? kI8 : -1));
+  return buf_dtype == kBufF16Nhwc ? kF16 : (buf_dtype == kBufF32Nhwc ? kF32 : (buf_dtype == kBufI8Nhwc ? kI8 : (buf_dtype == kBufS16Nhwc ? kS16 : -1)));
 }
-size_t dtype_size(int dt) { return dt == kF32 ? 4 : (dt == kI8 ? 1 : 2); }
+size_t dtype_size(int dt) { return dt == kF32 ? 4 : (dt == kI8 ? 1 : 2); }        // bytes per element of one plane (addressing)
+double dtype_bytes(int dt) { return dt == kS16 ? 4.0 : (double)dtype_size(dt); }   // bytes per value (traffic accounting)
 
 int engine_dtype(const unina_engine* e);
 
@@ -171,7 +174,7 @@ void drop_graph(unina_engine* e) {
   e->stem_node = e->post_node = e->post_node2 = nullptr;
 }
 
-int engine_dtype(const unina_engine* e) { return e->h.precision == kFp32 ? kF32 : kF16; }
+int engine_dtype(const unina_engine* e) { return e->h.precision == kFp32 ? kF32 : (e->h.precision == kSplit16 ? kS16 : kF16); }
 
 // ---- dependency analysis over the op table (buffer id + channel range granularity) ----
 struct Region {
@@ -292,6 +295,7 @@ int plan(unina_engine* e) {
       const size_t esz = dtype_size(dt);
       p.dtype = dt;
       p.src = src.ptr;
+      p.src_lo = lo_plane(src.d);
       p.src_ld = (int)src.d.c;
       p.H = (int)d.in_h; p.W = (int)d.in_w; p.Cin = (int)d.cin;
       p.Ho = (int)d.out_h; p.Wo = (int)d.out_w; p.M = p.Ho * p.Wo;
@@ -304,7 +308,9 @@ int plan(unina_engine* e) {
         p.res = static_cast<const char*>(rb.ptr) + (size_t)d.res_coff * dtype_size(rdt);
         p.res_ld = (int)rb.d.c;
         p.res_dtype = rdt;
+        p.res_lo = lo_plane(rb.d);
         p.res_scale = rb.d.scale;
+        if ((rdt == kS16) != (dt == kS16)) return fail(e, UNINA_ERR_FORMAT, "op %zu: split-fp16 conv with a residual of another type", i);
       }
       p.nseg = (int)d.nseg;
       p.zeros = e->d_zeros;
@@ -338,8 +344,10 @@ int plan(unina_engine* e) {
           cs.dst_planar = nullptr;
           cs.dst_ld = (int)db.d.c;
           cs.out_dtype = odt;
+          cs.dst_lo = lo_plane(db.d);
+          if ((odt == kS16) != (dt == kS16)) return fail(e, UNINA_ERR_FORMAT, "op %zu: split-fp16 conv into a buffer of another type", i);
           cs.out_inv_scale = odt == kI8 ? 1.0f / db.d.scale : 1.0f;
-          out_bytes += (double)dtype_size(odt) * sd.n_count * p.M * (cs.up2 ? 4 : 1);
+          out_bytes += dtype_bytes(odt) * sd.n_count * p.M * (cs.up2 ? 4 : 1);
         }
         ntot += (int)sd.n_count;
       }
@@ -352,8 +360,8 @@ int plan(unina_engine* e) {
       info.flops = 2.0 * p.M * (double)ntot * K;
       // algorithmic bytes: each distinct input element once, weights once, outputs once, residual once
       const bool shared_src = p.nseg == 1 || d.seg[0].src_coff == d.seg[1].src_coff;
-      info.bytes = (double)esz * p.H * p.W * p.Cin * (shared_src ? 1 : p.nseg) + (double)esz * ntot * K + 4.0 * ntot + out_bytes +
-                   (p.res ? (double)dtype_size(p.res_dtype) * p.M * ntot : 0.0);
+      info.bytes = dtype_bytes(dt) * p.H * p.W * p.Cin * (shared_src ? 1 : p.nseg) + dtype_bytes(dt) * ntot * K + 4.0 * ntot + out_bytes +
+                   (p.res ? dtype_bytes(p.res_dtype) * p.M * ntot : 0.0);
       snprintf(info.kernel, sizeof info.kernel, "%s", op.cl.kernel_name);
       info.grid = (int)(op.cl.grid.x * op.cl.grid.y);
       info.block = (int)op.cl.block.x;
@@ -362,8 +370,9 @@ int plan(unina_engine* e) {
       const Buffer& db = e->bufs[sd.dst_buf];
       StemParams& p = op.sp;
       const int odt = act_dtype_of(db.d.dtype);
-      if (odt != kF16 && odt != kF32) return fail(e, UNINA_ERR_UNSUPPORTED, "stem output must be fp16 or fp32");
+      if (odt != kF16 && odt != kF32 && odt != kS16) return fail(e, UNINA_ERR_UNSUPPORTED, "stem output must be fp16, fp32 or split fp16");
       p.dtype = odt;
+      p.dst_lo = lo_plane(db.d);
       p.src = static_cast<const float*>(src.ptr);
       p.w = reinterpret_cast<const float*>(blob + sd.w_off);
       p.wt = reinterpret_cast<const float*>(blob + op.wt_off);
@@ -373,11 +382,11 @@ int plan(unina_engine* e) {
       p.Co = (int)sd.n_count; p.dst_ld = (int)db.d.c;
       info.m = p.Ho * p.Wo; info.n = p.Co; info.k = 27;
       info.flops = 2.0 * info.m * info.n * 27;
-      info.bytes = 4.0 * 3 * p.H * p.W + (double)dtype_size(odt) * info.m * p.Co;
+      info.bytes = 4.0 * 3 * p.H * p.W + dtype_bytes(odt) * info.m * p.Co;
       {
         LaunchDesc sl;
         const bool tiled = stem_desc(p, &sl) == hipSuccess && sl.block.x == 128;
-        snprintf(info.kernel, sizeof info.kernel, "%s<%s,%d>", tiled ? "stem_tile_kernel" : "stem_conv_kernel", odt == kF32 ? "f32" : "f16", p.Co);
+        snprintf(info.kernel, sizeof info.kernel, "%s<%s,%d>", tiled ? "stem_tile_kernel" : "stem_conv_kernel", odt == kF32 ? "f32" : (odt == kS16 ? "s16" : "f16"), p.Co);
         info.grid = tiled ? (int)sl.grid.x : (2 * info.m + 255) / 256;
         info.block = tiled ? 128 : 256;
       }
@@ -387,9 +396,10 @@ int plan(unina_engine* e) {
       if (dt < 0) return fail(e, UNINA_ERR_FORMAT, "op %zu: pool on a non-activation buffer", i);
       p.dtype = dt;
       p.buf = src.ptr;
+      p.lo = lo_plane(src.d);
       p.H = (int)d.in_h; p.W = (int)d.in_w; p.C = (int)d.cin; p.ld = (int)src.d.c; p.coff = (int)d.seg[0].src_coff;
-      info.bytes = (double)dtype_size(dt) * p.H * p.W * p.C * 4;
-      snprintf(info.kernel, sizeof info.kernel, "sppf_pool_kernel<%s,32>", dt == kF32 ? "f32" : (dt == kI8 ? "i8" : "f16"));
+      info.bytes = dtype_bytes(dt) * p.H * p.W * p.C * 4;
+      snprintf(info.kernel, sizeof info.kernel, dt == kS16 ? "sppf_pool_split_kernel<%s32>" : "sppf_pool_kernel<%s,32>", dt == kF32 ? "f32" : (dt == kI8 ? "i8" : (dt == kS16 ? "" : "f16")));
       info.grid = p.H * (p.C / 32);
       info.block = 256;
     } else if (d.kind == kOpQuant) {
@@ -1436,7 +1446,11 @@ int fill_post_params(unina_engine* e, PostParams* pp, float conf, float iou, flo
 
 extern "C" {
 
-const char* unina_version(void) { return "unina_mi355 0.1.0 gfx950"; }
+#ifndef UNINA_SOURCE_HASH
+#define UNINA_SOURCE_HASH "unhashed"
+#endif
+// "... src:<hash of the sources this binary was built from>" (build.py source_hash(); tests compare it with the tree's)
+const char* unina_version(void) { return "unina_mi355 0.3.0 gfx950 src:" UNINA_SOURCE_HASH; }
 
 const char* unina_last_error(const unina_engine_t* e) { return e ? e->err.c_str() : g_load_error.c_str(); }
 
@@ -1456,7 +1470,8 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   if (fread(&e->h, sizeof e->h, 1, f) != 1) return bail(UNINA_ERR_FORMAT, "truncated header");
   if (memcmp(e->h.magic, kMagic, 8)) return bail(UNINA_ERR_FORMAT, "bad magic (not a UNINAENG file)");
   if (e->h.version != kVersion) return bail(UNINA_ERR_FORMAT, "unsupported engine file version");
-  if (e->h.precision != kFp16 && e->h.precision != kFp32 && e->h.precision != kInt8) return bail(UNINA_ERR_UNSUPPORTED, "unknown engine precision");
+  if (e->h.precision != kFp16 && e->h.precision != kFp32 && e->h.precision != kInt8 && e->h.precision != kSplit16)
+    return bail(UNINA_ERR_UNSUPPORTED, "unknown engine precision");
   if (e->h.n_heads != 3 || e->h.n_buffers == 0 || e->h.n_buffers > 4096 || e->h.n_ops == 0 || e->h.n_ops > 4096)
     return bail(UNINA_ERR_FORMAT, "implausible table sizes");
   e->bufs.resize(e->h.n_buffers);
@@ -1481,7 +1496,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
       if (sd.dst_buf >= e->h.n_buffers) return bail(UNINA_ERR_FORMAT, "op table: bad destination buffer");
       if (o.d.kind == kOpConv) {
         const uint32_t sdt = e->bufs[o.d.src_buf].d.dtype;
-        const uint64_t wbytes = (uint64_t)sd.n_pad * o.d.ksize * o.d.ksize * o.d.cin * (sdt == kBufF32Nhwc ? 4 : (sdt == kBufI8Nhwc ? 1 : 2));
+        const uint64_t wbytes = (uint64_t)sd.n_pad * o.d.ksize * o.d.ksize * o.d.cin * ((sdt == kBufF32Nhwc || sdt == kBufS16Nhwc) ? 4 : (sdt == kBufI8Nhwc ? 1 : 2));
         if (sd.m_off && (sd.m_off + (uint64_t)sd.n_pad * 4 > e->h.blob_bytes || sd.m_off % 16)) return bail(UNINA_ERR_FORMAT, "op table: multiplier offset outside blob");
         if (sd.w_off + wbytes > e->h.blob_bytes || sd.b_off + (uint64_t)sd.n_pad * 4 > e->h.blob_bytes || sd.w_off % 16 || sd.b_off % 16)
           return bail(UNINA_ERR_FORMAT, "op table: weight offset outside blob");
@@ -2135,6 +2150,13 @@ int unina_debug_read_buffer(unina_engine_t* e, const char* name, float* host_out
     const size_t hw = (size_t)b.d.h * b.d.w;
     for (size_t p = 0; p < hw; ++p)
       for (size_t ch = 0; ch < b.d.c; ++ch) host_out[ch * hw + p] = half_bits_to_float(tmp[p * b.d.c + ch]);
+  } else if (b.d.dtype == kBufS16Nhwc) {   // value = hi + lo
+    std::vector<uint16_t> tmp(2 * n);
+    HIPCHK(e, hipMemcpy(tmp.data(), b.ptr, n * 4, hipMemcpyDeviceToHost));
+    const size_t hw = (size_t)b.d.h * b.d.w;
+    for (size_t p = 0; p < hw; ++p)
+      for (size_t ch = 0; ch < b.d.c; ++ch)
+        host_out[ch * hw + p] = half_bits_to_float(tmp[p * b.d.c + ch]) + half_bits_to_float(tmp[n + p * b.d.c + ch]);
   } else {
     HIPCHK(e, hipMemcpy(host_out, b.ptr, n * 4, hipMemcpyDeviceToHost));
   }

@@ -11,8 +11,9 @@ namespace unina {
 constexpr char kMagic[8] = {'U', 'N', 'I', 'N', 'A', 'E', 'N', 'G'};
 constexpr uint32_t kVersion = 3;  // 2: packed fragment-block weights; 3: buffer scales, per-channel multipliers, QUANT op (int8)
 
-enum Precision : uint32_t { kFp16 = 0, kInt8 = 1, kFp32 = 2 };
-enum BufDtype : uint32_t { kBufF16Nhwc = 0, kBufF32Planar = 1, kBufF32NchwInput = 2, kBufI8Nhwc = 3, kBufF32Nhwc = 4 };
+enum Precision : uint32_t { kFp16 = 0, kInt8 = 1, kFp32 = 2, kSplit16 = 3 };   // kSplit16: fp16 hi/lo pairs ("strict" mode)
+enum BufDtype : uint32_t { kBufF16Nhwc = 0, kBufF32Planar = 1, kBufF32NchwInput = 2, kBufI8Nhwc = 3, kBufF32Nhwc = 4,
+                           kBufS16Nhwc = 5 };   // kBufS16Nhwc: two fp16 NHWC planes, hi then lo (h*w*c*2 bytes each)
 enum BufFlags : uint32_t { kBufInput = 1, kBufOutput = 2 };
 enum OpKind : uint32_t { kOpConv = 1, kOpStem = 2, kOpSppfPool = 3, kOpUpsample = 4, kOpQuant = 5 };
 enum SegFlags : uint32_t { kSegUp2 = 1, kSegPlanarF32 = 2 };
@@ -49,6 +50,7 @@ struct SegDesc {             // 64 bytes: one slice of an op's output-channel (N
   uint32_t dst_buf, dst_coff;
   uint32_t flags;            // SegFlags
   uint64_t w_off;            // blob offset: conv: fp16 fragment blocks [n_pad/16][K/32][64][8], K = (kh,kw,cin) (export.py pack_weights);
+                             //              kSplit16 engines: [n_pad/16][K/32][2 = hi, lo][64][8];
                              //              stem: fp32 [n][27] ordered (c,kh,kw)
   uint64_t b_off;            // blob offset: fp32 [n_pad] folded bias
   float w_scale, out_scale;  // int8 engines only (informational; the kernels use m_off / the buffer scale)

@@ -9,7 +9,13 @@
 namespace unina {
 
 typedef _Float16 half_t;
-enum DType : int { kF16 = 0, kF32 = 1, kI8 = 2 };   // element types (accumulation: fp32 for f16/f32 inputs, int32 for int8)
+// kS16 ("split fp16", the STRICT precision mode): a value is an fp16 PAIR hi + lo (hi = fp16(v), lo = fp16(v - hi), ~22 mantissa
+// bits). A tensor is two fp16 planes of identical NHWC layout: the hi plane at the tensor's address, the lo plane `*_lo` bytes
+// behind it; weights are pairs of 1-KiB fragment blocks [hi | lo]. A conv is three v_mfma_f32_16x16x32_f16 per k block
+// (lo*hi, hi*lo, hi*hi; the lo*lo term is below fp32 resolution) into one fp32 accumulator.
+enum DType : int { kF16 = 0, kF32 = 1, kI8 = 2, kS16 = 3 };   // element types (accumulation: fp32 for f16/f32/s16 inputs, int32 for int8)
+constexpr int kNumDTypes = 4;
+struct s16_t { _Float16 v; };                        // one plane element of a kS16 tensor (pointer arithmetic in plane elements)
 
 // ------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution  D[cout][pixel] = sum_k W[cout][k] * X[pixel][k]   (+bias, ReLU, +residual)
@@ -28,6 +34,7 @@ struct ConvSeg {
   int up2;             // 1: write every output pixel to its 2x2 block of a (2Ho x 2Wo) destination
   int tile0;           // first N-tile (blockIdx.y) that belongs to this slice
   int out_dtype;       // DType of dst (property of the destination buffer)
+  long long dst_lo;    // kS16 destinations: byte distance hi plane -> lo plane
   float out_inv_scale; // int8 destinations: 1 / s_out
   const float* mult;   // int8 convs: per-channel s_in*s_w*bn_scale applied to the int32 accumulator; nullptr otherwise
 };
@@ -35,6 +42,8 @@ struct ConvSeg {
 struct ConvParams {
   int dtype;           // DType of src and weights (kernel instantiation)
   const void* src;
+  long long src_lo;    // kS16: byte distance hi plane -> lo plane of the source buffer
+  long long res_lo;    // kS16 residual: the same for the residual buffer
   int src_ld;          // channels per pixel of the source buffer
   int H, W, Cin;       // input spatial size, input channels of each slice
   int Ho, Wo, M;       // output spatial size, M = Ho*Wo
@@ -229,6 +238,7 @@ struct StemParams {
   const float* wt;     // the same weights transposed to [27][Co] (prepared at load): wave-uniform scalar loads in the stem kernel
   const float* bias;   // [Co]
   void* dst;           // [Ho][Wo][dst_ld]
+  long long dst_lo;    // kS16: byte distance hi plane -> lo plane of dst
   int H, W, Ho, Wo, Co, dst_ld;
 };
 hipError_t stem_launch(const StemParams& p, hipStream_t stream, dim3* grid_out = nullptr, dim3* block_out = nullptr);
@@ -255,6 +265,7 @@ hipError_t stemconv_launch(const StemParams& sp, const ConvParams& cp, hipStream
 struct PoolParams {
   int dtype;
   void* buf;
+  long long lo;        // kS16: byte distance hi plane -> lo plane
   int H, W, C, ld, coff;
 };
 hipError_t sppf_pool_launch(const PoolParams& p, hipStream_t stream, dim3* grid_out = nullptr, dim3* block_out = nullptr);

@@ -6,10 +6,23 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 namespace unina {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// Storage of one output element: fp16 / fp32, or (kS16, the split-fp16 precision mode) an fp16 pair hi + lo in two planes.
+template <typename T> struct StemOut {
+  static constexpr bool kSplit = false;
+  static constexpr int kBytes = (int)sizeof(T);    // staged bytes per channel
+  typedef T plane_t;
+};
+template <> struct StemOut<s16_t> {
+  static constexpr bool kSplit = true;
+  static constexpr int kBytes = 4;
+  typedef half_t plane_t;
+};
 
 // ---------------------------------------------------------------------------------------------- stem
 // Cin = 3 makes K = 27: far too thin for a matrix-core tile, and the op is HBM-bound anyway
@@ -107,18 +120,22 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
 #pragma unroll
     for (int r = 0; r < CH / 2; ++r) acc[r] = __builtin_elementwise_fma(xk, floatx2{wt[k * CO + 2 * r], wt[k * CO + 2 * r + 1]}, acc[r]);
   }
-  T* d = static_cast<T*>(p.dst) + (size_t)m * p.dst_ld + c0;
-  constexpr int V = 16 / sizeof(T);  // elements per 16-byte store
-  typedef T vec_t __attribute__((ext_vector_type(V)));
+  typedef typename StemOut<T>::plane_t PT;
+  PT* d = static_cast<PT*>(p.dst) + (size_t)m * p.dst_ld + c0;
+  constexpr int V = 16 / sizeof(PT);  // elements per 16-byte store
+  typedef PT vec_t __attribute__((ext_vector_type(V)));
 #pragma unroll
   for (int r = 0; r < CH; r += V) {
-    vec_t hv;
+    vec_t hv, lv;
 #pragma unroll
     for (int q = 0; q < V; ++q) {
-      const float a = acc[(r + q) >> 1][(r + q) & 1];
-      hv[q] = (T)(a > 0.f ? a : 0.f);
+      float a = acc[(r + q) >> 1][(r + q) & 1];
+      a = a > 0.f ? a : 0.f;
+      hv[q] = (PT)a;
+      lv[q] = (PT)(a - (float)hv[q]);
     }
     *reinterpret_cast<vec_t*>(d + r) = hv;
+    if constexpr (StemOut<T>::kSplit) *reinterpret_cast<vec_t*>(reinterpret_cast<unsigned char*>(d + r) + p.dst_lo) = lv;
   }
 }
 
@@ -140,7 +157,7 @@ template <typename T, int CO>
 struct StemTile {
   static constexpr int NPATCH = 3 * kStemPR * kStemPW;                // floats
   static constexpr int NW = 27 * CO + CO;                             // weights [27][CO] then bias [CO]
-  static constexpr int ROWB = CO * (int)sizeof(T) + 16;               // padded staging row (bytes) of one output pixel
+  static constexpr int ROWB = CO * StemOut<T>::kBytes + 16;           // padded staging row (bytes) of one output pixel (split: [hi | lo])
   static constexpr int STAGE = kStemTH * kStemTW * ROWB;              // the staging tile reuses the patch + weight area
   static constexpr int IN_BYTES = (NPATCH + NW) * 4;
   static constexpr unsigned SMEM = (unsigned)(STAGE > IN_BYTES ? STAGE : IN_BYTES);
@@ -239,22 +256,28 @@ __global__ __launch_bounds__(kStemNT) void stem_tile_kernel(const StemParams p) 
     __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();                                              // every thread has read its inputs: the input area is free
-  constexpr int V = 16 / (int)sizeof(T);                        // elements per 16-byte chunk
-  typedef T vec_t __attribute__((ext_vector_type(V)));
+  typedef typename StemOut<T>::plane_t PT;
+  constexpr bool SPLIT = StemOut<T>::kSplit;
+  constexpr int V = 16 / (int)sizeof(PT);                       // elements per 16-byte chunk
+  typedef PT vec_t __attribute__((ext_vector_type(V)));
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int r = 0; r < CH; r += V) {
-      vec_t hv;
+      vec_t hv, lv;
 #pragma unroll
       for (int q = 0; q < V; ++q) {
-        const float a = acc[h][(r + q) >> 1][(r + q) & 1];
-        hv[q] = (T)(a > 0.f ? a : 0.f);
+        float a = acc[h][(r + q) >> 1][(r + q) & 1];
+        a = a > 0.f ? a : 0.f;
+        hv[q] = (PT)a;
+        lv[q] = (PT)(a - (float)hv[q]);
       }
-      *reinterpret_cast<vec_t*>(stem_smem + (h * kStemTW + tx) * ST::ROWB + (c0 + r) * (int)sizeof(T)) = hv;
+      *reinterpret_cast<vec_t*>(stem_smem + (h * kStemTW + tx) * ST::ROWB + (c0 + r) * (int)sizeof(PT)) = hv;
+      if constexpr (SPLIT) *reinterpret_cast<vec_t*>(stem_smem + (h * kStemTW + tx) * ST::ROWB + CO * 2 + (c0 + r) * 2) = lv;
     }
   __syncthreads();
-  constexpr int CPP = CO * (int)sizeof(T) / 16;                 // 16-byte chunks per pixel
+  constexpr int CPL = CO * (int)sizeof(PT) / 16;                // 16-byte chunks per pixel and plane
+  constexpr int CPP = SPLIT ? 2 * CPL : CPL;                    // ... per pixel
   typedef float vec16 __attribute__((ext_vector_type(4)));
   unsigned char* dst = static_cast<unsigned char*>(p.dst);
 #pragma unroll
@@ -262,8 +285,9 @@ __global__ __launch_bounds__(kStemNT) void stem_tile_kernel(const StemParams p) 
     const int chunk = i * kStemNT + tid;
     const int pl = chunk / CPP, part = chunk - pl * CPP;        // tile pixel (row-major), chunk of its channels
     const int oy = ty0 + (pl >> 6), ox = tx0 + (pl & 63);
+    const int plane = part / CPL, pc = part - plane * CPL;      // (split: the staged row is [hi chunks | lo chunks])
     if (oy < p.Ho && ox < p.Wo)
-      *reinterpret_cast<vec16*>(dst + ((size_t)(oy * p.Wo + ox) * p.dst_ld) * sizeof(T) + part * 16) =
+      *reinterpret_cast<vec16*>(dst + plane * p.dst_lo + ((size_t)(oy * p.Wo + ox) * p.dst_ld) * sizeof(PT) + pc * 16) =
           *reinterpret_cast<const vec16*>(stem_smem + pl * ST::ROWB + part * 16);
   }
 }
@@ -277,7 +301,9 @@ hipError_t stem_init() {
       {reinterpret_cast<const void*>(&stem_tile_kernel<half_t, 32>), stem_tile_smem<half_t, 32>()},
       {reinterpret_cast<const void*>(&stem_tile_kernel<half_t, 64>), stem_tile_smem<half_t, 64>()},
       {reinterpret_cast<const void*>(&stem_tile_kernel<float, 32>), stem_tile_smem<float, 32>()},
-      {reinterpret_cast<const void*>(&stem_tile_kernel<float, 64>), stem_tile_smem<float, 64>()}};
+      {reinterpret_cast<const void*>(&stem_tile_kernel<float, 64>), stem_tile_smem<float, 64>()},
+      {reinterpret_cast<const void*>(&stem_tile_kernel<s16_t, 32>), stem_tile_smem<s16_t, 32>()},
+      {reinterpret_cast<const void*>(&stem_tile_kernel<s16_t, 64>), stem_tile_smem<s16_t, 64>()}};
   for (const auto& k : ks) {
     hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.smem);
     if (e != hipSuccess) return e;
@@ -296,6 +322,8 @@ hipError_t stem_desc(const StemParams& p, LaunchDesc* out) {
     else if (p.Co == 64 && p.dtype == kF16) { out->func = reinterpret_cast<const void*>(&stem_tile_kernel<half_t, 64>); out->shmem = stem_tile_smem<half_t, 64>(); }
     else if (p.Co == 32 && p.dtype == kF32) { out->func = reinterpret_cast<const void*>(&stem_tile_kernel<float, 32>); out->shmem = stem_tile_smem<float, 32>(); }
     else if (p.Co == 64 && p.dtype == kF32) { out->func = reinterpret_cast<const void*>(&stem_tile_kernel<float, 64>); out->shmem = stem_tile_smem<float, 64>(); }
+    else if (p.Co == 32 && p.dtype == kS16) { out->func = reinterpret_cast<const void*>(&stem_tile_kernel<s16_t, 32>); out->shmem = stem_tile_smem<s16_t, 32>(); }
+    else if (p.Co == 64 && p.dtype == kS16) { out->func = reinterpret_cast<const void*>(&stem_tile_kernel<s16_t, 64>); out->shmem = stem_tile_smem<s16_t, 64>(); }
     else return hipErrorInvalidValue;
     return hipSuccess;
   }
@@ -305,6 +333,8 @@ hipError_t stem_desc(const StemParams& p, LaunchDesc* out) {
   else if (p.Co == 64 && p.dtype == kF16) out->func = reinterpret_cast<const void*>(&stem_conv_kernel<half_t, 64>);
   else if (p.Co == 32 && p.dtype == kF32) out->func = reinterpret_cast<const void*>(&stem_conv_kernel<float, 32>);
   else if (p.Co == 64 && p.dtype == kF32) out->func = reinterpret_cast<const void*>(&stem_conv_kernel<float, 64>);
+  else if (p.Co == 32 && p.dtype == kS16) out->func = reinterpret_cast<const void*>(&stem_conv_kernel<s16_t, 32>);
+  else if (p.Co == 64 && p.dtype == kS16) out->func = reinterpret_cast<const void*>(&stem_conv_kernel<s16_t, 64>);
   else return hipErrorInvalidValue;
   return hipSuccess;
 }
@@ -420,16 +450,101 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const PoolParams p) {
   }
 }
 
+// split fp16 (kS16): the same separable scheme on (hi, lo) pairs. A pair's value hi + lo fits an fp32 (11 + 11 mantissa bits, lo
+// below half an ulp of hi), so the maxima are taken on that fp32 value (exactly) and the winner is split again on the way out
+// (fp16(v) and fp16(v - fp16(v)): the pair it came from, up to the choice at a rounding tie -- the same VALUE either way).
+template <int CH>
+__global__ __launch_bounds__(256) void sppf_pool_split_kernel(const PoolParams p) {
+  typedef float vec_t __attribute__((ext_vector_type(8)));
+  constexpr int V = 8, NV = CH / V;
+  extern __shared__ __align__(16) unsigned char smem[];
+  vec_t* v5 = reinterpret_cast<vec_t*>(smem);  // [W][NV]
+  vec_t* v9 = v5 + p.W * NV;
+  vec_t* v13 = v9 + p.W * NV;
+  const int y = blockIdx.x;
+  const int c0 = blockIdx.y * CH;
+  const int nvec = p.W * NV;
+  half_t* base = static_cast<half_t*>(p.buf);
+  const half_t* x = base + p.coff + c0;
+  auto vmax = [](vec_t a, vec_t b) {
+    vec_t r;
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = a[i] > b[i] ? a[i] : b[i];
+    return r;
+  };
+  auto load = [&](const half_t* at) {
+    const half8 h = *reinterpret_cast<const half8*>(at);
+    const half8 l = *reinterpret_cast<const half8*>(reinterpret_cast<const unsigned char*>(at) + p.lo);
+    vec_t r;
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = (float)h[i] + (float)l[i];
+    return r;
+  };
+  auto store = [&](half_t* at, const vec_t& v) {
+    half8 h, l;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      h[i] = (half_t)v[i];
+      l[i] = (half_t)(v[i] - (float)h[i]);
+    }
+    *reinterpret_cast<half8*>(at) = h;
+    *reinterpret_cast<half8*>(reinterpret_cast<unsigned char*>(at) + p.lo) = l;
+  };
+  for (int t = threadIdx.x; t < nvec; t += blockDim.x) {
+    const int xx = t / NV, cv = t % NV;
+    vec_t v[13];
+#pragma unroll
+    for (int dy = -6; dy <= 6; ++dy) {
+      int yy = y + dy;
+      yy = yy < 0 ? 0 : (yy >= p.H ? p.H - 1 : yy);
+      v[dy + 6] = load(x + ((size_t)yy * p.W + xx) * p.ld + cv * V);
+    }
+    vec_t m5 = v[6];
+#pragma unroll
+    for (int d = 1; d <= 2; ++d) m5 = vmax(m5, vmax(v[6 - d], v[6 + d]));
+    vec_t m9 = m5;
+#pragma unroll
+    for (int d = 3; d <= 4; ++d) m9 = vmax(m9, vmax(v[6 - d], v[6 + d]));
+    vec_t m13 = m9;
+#pragma unroll
+    for (int d = 5; d <= 6; ++d) m13 = vmax(m13, vmax(v[6 - d], v[6 + d]));
+    v5[t] = m5;
+    v9[t] = m9;
+    v13[t] = m13;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < nvec; t += blockDim.x) {
+    const int xx = t / NV, cv = t % NV;
+    auto col = [&](int dx) {
+      int x2 = xx + dx;
+      x2 = x2 < 0 ? 0 : (x2 >= p.W ? p.W - 1 : x2);
+      return x2 * NV + cv;
+    };
+    vec_t o5 = v5[col(0)], o9 = v9[col(0)], o13 = v13[col(0)];
+#pragma unroll
+    for (int d = 1; d <= 6; ++d) {
+      o13 = vmax(o13, vmax(v13[col(-d)], v13[col(d)]));
+      if (d <= 4) o9 = vmax(o9, vmax(v9[col(-d)], v9[col(d)]));
+      if (d <= 2) o5 = vmax(o5, vmax(v5[col(-d)], v5[col(d)]));
+    }
+    half_t* o = base + ((size_t)y * p.W + xx) * p.ld + p.coff + c0 + cv * V;
+    store(o + p.C, o5);
+    store(o + 2 * p.C, o9);
+    store(o + 3 * p.C, o13);
+  }
+}
+
 hipError_t sppf_pool_launch(const PoolParams& p, hipStream_t stream, dim3* grid_out, dim3* block_out) {
   constexpr int CH = 32;
   if (p.C % CH) return hipErrorInvalidValue;
   dim3 grid(p.H, p.C / CH), block(256);
-  const size_t esz = p.dtype == kF32 ? 4 : (p.dtype == kI8 ? 1 : 2);
+  const size_t esz = (p.dtype == kF32 || p.dtype == kS16) ? 4 : (p.dtype == kI8 ? 1 : 2);
   const size_t smem = (size_t)3 * p.W * CH * esz;
   if (smem > 64 * 1024) return hipErrorInvalidValue;
   if (grid_out) *grid_out = grid;
   if (block_out) *block_out = block;
-  if (p.dtype == kF32) sppf_pool_kernel<float, CH><<<grid, block, smem, stream>>>(p);
+  if (p.dtype == kS16) sppf_pool_split_kernel<CH><<<grid, block, smem, stream>>>(p);
+  else if (p.dtype == kF32) sppf_pool_kernel<float, CH><<<grid, block, smem, stream>>>(p);
   else if (p.dtype == kI8) sppf_pool_kernel<signed char, CH><<<grid, block, smem, stream>>>(p);  // one scale per buffer: max commutes with it
   else sppf_pool_kernel<half_t, CH><<<grid, block, smem, stream>>>(p);
   return hipGetLastError();

@@ -31,8 +31,9 @@ from .graph import Graph, OUTPUT_NAMES, STRIDES
 
 MAGIC = b"UNINAENG"
 VERSION = 3
-FP16, INT8, FP32 = 0, 1, 2
-BUF_F16, BUF_F32_PLANAR, BUF_F32_NCHW_IN, BUF_I8, BUF_F32_NHWC = 0, 1, 2, 3, 4
+FP16, INT8, FP32, SPLIT = 0, 1, 2, 3
+STRICT = SPLIT            # the precision mode that meets the north-star tolerance on every detection at fp16-MFMA speed
+BUF_F16, BUF_F32_PLANAR, BUF_F32_NCHW_IN, BUF_I8, BUF_F32_NHWC, BUF_S16 = 0, 1, 2, 3, 4, 5
 BUF_INPUT, BUF_OUTPUT = 1, 2
 OP_CONV, OP_STEM, OP_SPPF_POOL, OP_UPSAMPLE, OP_QUANT = 1, 2, 3, 4, 5
 SEG_UP2, SEG_PLANAR_F32 = 1, 2
@@ -106,6 +107,25 @@ def pack_weights(wk: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(out).reshape(-1)
 
 
+def pack_weights_split(hi: np.ndarray, lo: np.ndarray) -> np.ndarray:
+    """SPLIT engines: two [n_pad][K] fp16 matrices (w = hi + lo) -> pairs of 1-KiB fragment blocks [n_pad/16][K/32][hi | lo],
+    each block in pack_weights' image: the kernels fetch a k block's hi and lo fragments from adjacent blocks."""
+    n_pad, K = hi.shape
+    nblk = (n_pad // 16) * (K // 32)
+    out = np.empty((nblk, 2, 512), dtype=np.float16)
+    out[:, 0] = pack_weights(hi).reshape(nblk, 512)
+    out[:, 1] = pack_weights(lo).reshape(nblk, 512)
+    return out.reshape(-1)
+
+
+def unpack_weights_split(packed: np.ndarray, n_pad: int, K: int) -> np.ndarray:
+    """Inverse of pack_weights_split: the fp32 values hi + lo, [n_pad][K] (tests / emulator)."""
+    blk = packed.reshape(-1, 2, 512)
+    hi = unpack_weights(np.ascontiguousarray(blk[:, 0]).reshape(-1), n_pad, K)
+    lo = unpack_weights(np.ascontiguousarray(blk[:, 1]).reshape(-1), n_pad, K)
+    return hi.astype(np.float32) + lo.astype(np.float32)
+
+
 def unpack_weights(packed: np.ndarray, n_pad: int, K: int) -> np.ndarray:
     """Inverse of pack_weights (tests / emulator)."""
     ce = 16 // packed.dtype.itemsize
@@ -148,13 +168,15 @@ class EngineBuilder:
     def __init__(self, sd: Dict[str, np.ndarray], graph: Optional[Graph] = None, precision: int = FP16,
                  amax: Optional[Dict[str, float]] = None, weight_amax: Optional[Dict[str, float]] = None):
         """precision: FP16 (fp16 weights + activations, v_mfma_f32_16x16x32_f16), FP32 (fp32 everywhere,
-        v_mfma_f32_16x16x4_f32: meets the north-star tolerance outright at 1/16 of the fp16 matrix rate), or INT8
+        v_mfma_f32_16x16x4_f32: meets the north-star tolerance outright at 1/16 of the fp16 matrix rate), SPLIT (= STRICT:
+        every folded weight and every stored activation is an fp16 PAIR hi + lo -- ~22 mantissa bits -- and a conv is three
+        fp16 MFMAs per k block, hi*hi + hi*lo + lo*hi, into one fp32 accumulator: the tolerance of FP32 at the fp16 rate), or INT8
         (per-tensor symmetric int8 activations AND weights as in qat.py:91-126, v_mfma_i32_16x16x64_i8, with the
         reference's FP16 carve-outs; needs `amax`: buffer name -> calibrated |activation| maximum, see calibrate() or,
         for a QAT checkpoint, amax_from_qat()). `weight_amax`: optional conv module -> weight range from a checkpoint's
         `_weight_quantizer._amax` (default: max |W| of the conv, which is what a max calibrator stores)."""
-        if precision not in (FP16, FP32, INT8):
-            raise NotImplementedError("precision must be FP16, FP32 or INT8")
+        if precision not in (FP16, FP32, INT8, SPLIT):
+            raise NotImplementedError("precision must be FP16, FP32, INT8 or SPLIT")
         if precision == INT8 and amax is None:
             raise ValueError("INT8 needs calibrated activation ranges (amax): run export.calibrate() first")
         self.sd = sd
@@ -162,7 +184,7 @@ class EngineBuilder:
         self.amax = amax
         self.weight_amax = weight_amax or {}
         self.wdtype = np.float32 if precision == FP32 else np.float16
-        self.act_dtype = BUF_F32_NHWC if precision == FP32 else BUF_F16
+        self.act_dtype = BUF_F32_NHWC if precision == FP32 else (BUF_S16 if precision == SPLIT else BUF_F16)
         self.g = graph or Graph()
         self.narrow_base_channels = 0
         if self.g.base_channels % 32:
@@ -514,6 +536,13 @@ class EngineBuilder:
                     mk[:sg.n_count] = (in_scale * sg.w_scale * sg.fold).astype(np.float32)
                     sg.w_off = self._blob_add(pack_weights(wk))
                     sg.m_off = self._blob_add(mk)
+                elif self.precision == SPLIT:
+                    wf = sg.w_raw * sg.fold[:, None]                                     # fp64 folded weights
+                    hi = np.zeros((sg.n_pad, K), dtype=np.float16)
+                    lo = np.zeros((sg.n_pad, K), dtype=np.float16)
+                    hi[:sg.n_count] = wf.astype(np.float16)
+                    lo[:sg.n_count] = (wf - hi[:sg.n_count].astype(np.float64)).astype(np.float16)
+                    sg.w_off = self._blob_add(pack_weights_split(hi, lo))
                 else:
                     wk = np.zeros((sg.n_pad, K), dtype=self.wdtype)
                     wk[:sg.n_count] = (sg.w_raw * sg.fold[:, None]).astype(self.wdtype)
