@@ -71,16 +71,32 @@ def test_strict_every_buffer_vs_oracle(pkg, sd7, oracle_mod, oracle_sd7, torch_c
         e.close()
 
 
-def test_strict_fused_equals_per_op_within_fp32_noise(pkg, strict64, torch_cuda):
-    """The frame as launched (fused blocks, paired launches) against the per-op table of the same engine. Kernel families of
-    the split mode may order their fp32 sums differently (no bit-identity contract here): fp32 rounding noise only."""
-    x = torch_cuda.from_numpy(pkg.rng.frame(1234, 64, 64)).cuda()
-    fused = strict64.forward(x)
-    strict64.set_fusion(False)
-    plain = strict64.forward(x)
-    strict64.set_fusion(True)
-    for name in pkg.graph.OUTPUT_NAMES:
-        np.testing.assert_allclose(fused[name], plain[name], atol=5e-5, rtol=0, err_msg=name)
+@pytest.mark.parametrize("size", [64, 96, 640])
+def test_strict_fused_equals_per_op_within_fp32_noise(pkg, sd7, torch_cuda, size):
+    """The frame as launched (fused C3k2 blocks, the conv pair, paired head launches) against the per-op table of the same
+    engine, heads and block outputs; 96^2 puts partial tiles on every level. Kernel families of the split mode may order
+    their fp32 sums differently (no bit-identity contract here): fp32 rounding noise only."""
+    from unina_yolo_dla_amd import export
+    from unina_yolo_dla_amd.engine import Engine
+    e = Engine.from_state_dict(sd7, pkg.graph.Graph(in_h=size, in_w=size), precision=export.STRICT)
+    try:
+        assert e.set_fusion(True) >= 8                            # 7 C3k2 blocks + the SPPF / lateral pair
+        kernels = " ".join(o["kernel"] for o in e.op_infos())
+        assert "c3k2_fused<s16" in kernels and "conv_pair<s16" in kernels and "conv_dual_head3x3_s16" in kernels, kernels
+        x = torch_cuda.from_numpy(pkg.rng.frame(1234, size, size)).cuda()
+        fused = e.forward(x)
+        # (cat_pan1 / cat_pan2 are left out: their down-sampled halves live only inside the fused PAN blocks)
+        outs = ("p2_fused", "p3_out", "p4_out", "backbone.sppf", "neck.cat_fpn1", "neck.cat_fpn2")
+        fbuf = {b: e.read_buffer(b) for b in outs}
+        e.set_fusion(False)
+        plain = e.forward(x)
+        for name in pkg.graph.OUTPUT_NAMES:
+            np.testing.assert_allclose(fused[name], plain[name], atol=5e-5, rtol=0, err_msg=name)
+        for b in outs:
+            want = e.read_buffer(b)
+            np.testing.assert_allclose(fbuf[b], want, atol=2e-5 * max(1.0, float(np.abs(want).max())), rtol=0, err_msg=b)
+    finally:
+        e.close()
 
 
 def test_strict_heads_vs_reference_fixture(pkg, strict640, torch_cuda):

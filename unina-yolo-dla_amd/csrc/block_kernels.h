@@ -65,12 +65,15 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
   constexpr int HB = H_ / E::KBLK;                              // k-blocks per tap of the hidden width
   constexpr int NT = NW * 64;
   constexpr int ESZ = E::ESZ;
+  constexpr int NPL = E::SPLIT ? 2 : 1;     // split fp16: every tensor is a (hi, lo) pair of images / planes
+  static_assert(!E::SPLIT || !UNINA_BLOCK_PATCH_REGS, "the split type loads its patches by LDS-DMA");
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
   const int tyi = fast_div(bid, p.tiles_x_magic), txi = bid - tyi * p.tiles_x;
   const int ty0 = tyi * TH, tx0 = txi * TW;
+  const int lds_lo = E::SPLIT ? p.lds_lo : 0;   // LDS distance image -> lo twin
 
   // ---- weight prefetch queue: element g of this wave's flat sequence lives in slot g % D ----
   const unsigned char* wbase = p.wstream + (4 * l15 + (lq ^ swz_g(l15))) * 16;   // this lane's 16 bytes of any block
@@ -110,12 +113,12 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
 #else
   if constexpr (PRE) {
     load_patch<PH, PW, (CPRE ? CPRE : E::KBLK), NT, E>(smem + p.off_p, p.src, p.src_ld, p.preH, p.preW, 2 * (ty0 - NB) - 1,
-                                                     2 * (tx0 - NB) - 1, p.zeros, wid, lane);
+                                                     2 * (tx0 - NB) - 1, p.zeros, wid, lane, p.src_lo, lds_lo);
     if constexpr (CREST > 0)
       load_patch<TH + 2 * NB, R0W, (CREST ? CREST : E::KBLK), NT, E>(smem + p.off_xr, p.src2, p.src2_ld, p.H, p.W, ty0 - NB, tx0 - NB,
-                                                                   p.zeros, wid, lane);
+                                                                   p.zeros, wid, lane, p.src2_lo, lds_lo);
   } else {
-    load_patch<TH + 2 * NB, R0W, CIN, NT, E>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0 - NB, tx0 - NB, p.zeros, wid, lane);
+    load_patch<TH + 2 * NB, R0W, CIN, NT, E>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0 - NB, tx0 - NB, p.zeros, wid, lane, p.src_lo, lds_lo);
   }
   static_for<0, D>([&](auto gc) { wq_fetch<ST, D, decltype(gc)::value>(q, wbase, wid); });
   consts_issue<NT>(cregs, p.bias, p.n_bias);
@@ -134,7 +137,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
   auto in_image = [&](int iy, int ix) { return (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W; };
 
   auto run_step = [&](auto sc, auto pc, auto baddr, auto epi) {
-    dev::run_step<ST, D, decltype(sc)::value, decltype(pc)::value, E>(q, wbase, smem, wid, lane, baddr, epi);
+    dev::run_step<ST, D, decltype(sc)::value, decltype(pc)::value, E>(q, wbase, smem, wid, lane, baddr, epi, lds_lo);
   };
 #define STEP(S, P) std::integral_constant<int, (S) + PRE>{}, std::integral_constant<int, (P)>{}
   typedef typename E::acc_t acc_t;
@@ -155,8 +158,8 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
         },
         [&](int sub, int n, const acc_t& acc) {
           const int r = sub * 16 + l15;
-          if (r < P0) store4<E, CX>(smem + img_at<E>(Xi, r, n), act_relu<E, CX>(acc, c0, n), c0, n);
-        });
+          if (r < P0) store4<E, CX>(smem + img_at<E>(Xi, r, n), act_relu<E, CX>(acc, c0, n), c0, n, lds_lo);
+        }, lds_lo);
   }
 
   // ---- step 0: a | b = ReLU(W12 x + b12) on R0 --------------------------------------------------------------------
@@ -169,7 +172,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
       },
       [&](int sub, int n, const acc_t& acc) {
         const int r = sub * 16 + l15;
-        if (r < P0) store4<E, 2 * H_>(smem + img_at<E>(Y, r, n), act_relu<E, 2 * H_>(acc, CST(0), n), CST(0), n);
+        if (r < P0) store4<E, 2 * H_>(smem + img_at<E>(Y, r, n), act_relu<E, 2 * H_>(acc, CST(0), n), CST(0), n, lds_lo);
       });
 
   // ---- bottleneck 0 -----------------------------------------------------------------------------------------------
@@ -185,7 +188,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
         const int ry = r / R0W, rx = r - ry * R0W;
         floatx4 v = act_relu<E, H_>(acc, CST(1), n);
         if (!in_image(ty0 - NB + ry, tx0 - NB + rx)) v = floatx4{0.f, 0.f, 0.f, 0.f};
-        store4<E, H_>(smem + img_at<E>(T, r, n), v, CST(1), n);
+        store4<E, H_>(smem + img_at<E>(T, r, n), v, CST(1), n, lds_lo);
       });
   if constexpr (NB == 1) {
     // u = ReLU(3x3(t) + b) + a on the tile
@@ -201,8 +204,8 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           const int pp = sub * 16 + l15;
           if (pp >= PT) return;
           const int py = pp / TW, px = pp - py * TW;
-          const floatx4 v = add_res<E>(act_relu<E, H_>(acc, CST(2), n), smem, Y, (py + 1) * R0W + px + 1, n, p.res_scale[0]);
-          store4<E, H_>(smem + img_at<E>(U2, pp, n), v, CST(2), n);
+          const floatx4 v = add_res<E>(act_relu<E, H_>(acc, CST(2), n), smem, Y, (py + 1) * R0W + px + 1, n, p.res_scale[0], lds_lo);
+          store4<E, H_>(smem + img_at<E>(U2, pp, n), v, CST(2), n, lds_lo);
         });
   } else {
     // u1 = ReLU(3x3(t1) + b) + a on R1
@@ -218,8 +221,8 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           const int pp = sub * 16 + l15;
           if (pp >= P1) return;
           const int py = pp / R1W, px = pp - py * R1W;
-          const floatx4 v = add_res<E>(act_relu<E, H_>(acc, CST(2), n), smem, Y, (py + 1) * R0W + px + 1, n, p.res_scale[0]);
-          store4<E, H_>(smem + img_at<E>(U1, pp, n), v, CST(2), n);
+          const floatx4 v = add_res<E>(act_relu<E, H_>(acc, CST(2), n), smem, Y, (py + 1) * R0W + px + 1, n, p.res_scale[0], lds_lo);
+          store4<E, H_>(smem + img_at<E>(U1, pp, n), v, CST(2), n, lds_lo);
         });
     // ---- bottleneck 1 ---------------------------------------------------------------------------------------------
     // t2 = ReLU(Wb1' u1 + b) on R1, 0 outside the image
@@ -234,7 +237,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           const int ry = r / R1W, rx = r - ry * R1W;
           floatx4 v = act_relu<E, H_>(acc, CST(3), n);
           if (!in_image(ty0 - 1 + ry, tx0 - 1 + rx)) v = floatx4{0.f, 0.f, 0.f, 0.f};
-          store4<E, H_>(smem + img_at<E>(T, r, n), v, CST(3), n);
+          store4<E, H_>(smem + img_at<E>(T, r, n), v, CST(3), n, lds_lo);
         });
     // u2 = ReLU(3x3(t2) + b) + u1 on the tile
     run_step(STEP(4, PT),
@@ -249,8 +252,8 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           const int pp = sub * 16 + l15;
           if (pp >= PT) return;
           const int py = pp / TW, px = pp - py * TW;
-          const floatx4 v = add_res<E>(act_relu<E, H_>(acc, CST(4), n), smem, U1, (py + 1) * R1W + px + 1, n, p.res_scale[1]);
-          store4<E, H_>(smem + img_at<E>(U2, pp, n), v, CST(4), n);
+          const floatx4 v = add_res<E>(act_relu<E, H_>(acc, CST(4), n), smem, U1, (py + 1) * R1W + px + 1, n, p.res_scale[1], lds_lo);
+          store4<E, H_>(smem + img_at<E>(U2, pp, n), v, CST(4), n, lds_lo);
         });
   }
 
@@ -279,12 +282,12 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
             const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
             if (oy < p.H && ox < p.W)
               store4<E, 2 * H_>(static_cast<unsigned char*>(p.dst) + ((size_t)(oy * p.W + ox) * p.dst_ld + n) * ESZ,
-                                act_relu<E, 2 * H_>(acc, CST(S3), n), CST(S3), n);
+                                act_relu<E, 2 * H_>(acc, CST(S3), n), CST(S3), n, p.dst_lo);
             return;
           }
         }
 #endif
-        store4<E, 2 * H_>(stage + pp * ROWB + n * ESZ, act_relu<E, 2 * H_>(acc, CST(S3), n), CST(S3), n);
+        store4<E, 2 * H_>(stage + pp * ROWB + n * ESZ, act_relu<E, 2 * H_>(acc, CST(S3), n), CST(S3), n, lds_lo);
       });
 #if UNINA_BLOCK_DIRECT_STORE
   if constexpr (!TAIL && !E::I8) {
@@ -294,13 +297,14 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
   typedef float vec16 __attribute__((ext_vector_type(4)));  // 16 opaque bytes
   constexpr int CPR = 2 * H_ * ESZ / 16;                    // 16-byte chunks per output pixel
   unsigned char* dst = static_cast<unsigned char*>(p.dst);
-  for (int c = threadIdx.x; c < PT * CPR; c += NT) {
-    const int pp = c / CPR, ch = c - pp * CPR;
+  for (int c = threadIdx.x; c < NPL * PT * CPR; c += NT) {
+    const int pl = NPL == 1 ? 0 : c / (PT * CPR), cc = c - pl * (PT * CPR);      // (split: the hi tile, then the lo tile)
+    const int pp = cc / CPR, ch = cc - pp * CPR;
     const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
     if (oy < p.H && ox < p.W) {
-      const vec16 v = *reinterpret_cast<const vec16*>(stage + pp * ROWB + ch * 16);
-      *reinterpret_cast<vec16*>(dst + ((size_t)(oy * p.W + ox) * p.dst_ld) * ESZ + ch * 16) = v;
-      if constexpr (!E::I8) {
+      const vec16 v = *reinterpret_cast<const vec16*>(stage + pl * lds_lo + pp * ROWB + ch * 16);
+      *reinterpret_cast<vec16*>(dst + (NPL == 1 ? 0 : pl * p.dst_lo) + ((size_t)(oy * p.W + ox) * p.dst_ld) * ESZ + ch * 16) = v;
+      if constexpr (!E::I8 && !E::SPLIT) {
         if (p.dst_q) {   // int8 twin of the output for the block's int8 consumers: stem_pool.hip quant_f16_i8_kernel's arithmetic
           const half8 hv = *reinterpret_cast<const half8*>(&v);
           unsigned int q[2] = {0u, 0u};
@@ -334,18 +338,19 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
         [&](int sub, int n, const acc_t& acc) {
           const int pp = sub * 16 + l15;
           if (pp >= PT) return;
-          store4<TE, H_>(tout + pp * ROWT + n * TSZ, act_relu<E, H_>(acc, CST(S4), n), CST(S4), n);
+          store4<TE, H_>(tout + pp * ROWT + n * TSZ, act_relu<E, H_>(acc, CST(S4), n), CST(S4), n, lds_lo);
         });
     constexpr int CPT = H_ * TSZ / 16;
     unsigned char* dst2 = static_cast<unsigned char*>(p.dst2);
     if constexpr (TAIL == 1 || TAIL == 3) {
       const size_t px = (size_t)p.dst2_ld * TSZ, row = (size_t)(2 * p.W) * px;
-      for (int c = threadIdx.x; c < PT * CPT; c += NT) {
-        const int pp = c / CPT, ch = c - pp * CPT;
+      for (int c = threadIdx.x; c < NPL * PT * CPT; c += NT) {
+        const int pl = NPL == 1 ? 0 : c / (PT * CPT), cc = c - pl * (PT * CPT);
+        const int pp = cc / CPT, ch = cc - pp * CPT;
         const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
         if (oy < p.H && ox < p.W) {
-          const vec16 v = *reinterpret_cast<const vec16*>(tout + pp * ROWT + ch * 16);
-          unsigned char* d = dst2 + ((size_t)(2 * oy) * (2 * p.W) + 2 * ox) * px + ch * 16;
+          const vec16 v = *reinterpret_cast<const vec16*>(tout + pl * lds_lo + pp * ROWT + ch * 16);
+          unsigned char* d = dst2 + (NPL == 1 ? 0 : pl * p.dst2_lo) + ((size_t)(2 * oy) * (2 * p.W) + 2 * ox) * px + ch * 16;
           *reinterpret_cast<vec16*>(d) = v;
           *reinterpret_cast<vec16*>(d + px) = v;
           *reinterpret_cast<vec16*>(d + row) = v;
@@ -353,12 +358,13 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
         }
       }
     } else {
-      for (int c = threadIdx.x; c < PT * CPT; c += NT) {
-        const int pp = c / CPT, ch = c - pp * CPT;
+      for (int c = threadIdx.x; c < NPL * PT * CPT; c += NT) {
+        const int pl = NPL == 1 ? 0 : c / (PT * CPT), cc = c - pl * (PT * CPT);
+        const int pp = cc / CPT, ch = cc - pp * CPT;
         const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
         if (oy < p.H && ox < p.W)
-          *reinterpret_cast<vec16*>(dst2 + ((size_t)(oy * p.W + ox) * p.dst2_ld) * TSZ + ch * 16) =
-              *reinterpret_cast<const vec16*>(tout + pp * ROWT + ch * 16);
+          *reinterpret_cast<vec16*>(dst2 + (NPL == 1 ? 0 : pl * p.dst2_lo) + ((size_t)(oy * p.W + ox) * p.dst2_ld) * TSZ + ch * 16) =
+              *reinterpret_cast<const vec16*>(tout + pl * lds_lo + pp * ROWT + ch * 16);
       }
     }
   }

@@ -23,23 +23,43 @@ namespace dev {
 // Element types of a block kernel. A 1-KiB weight fragment block is 16 rows x 4 chunks of 16 bytes for both:
 //   EltH : fp16, chunk = 8 channels,  block = 32 k, v_mfma_f32_16x16x32_f16, fp32 accumulators
 //   EltI8: int8, chunk = 16 channels, block = 64 k, v_mfma_i32_16x16x64_i8, exact int32 accumulators (INT8 engines)
+//   EltS : split fp16 (STRICT precision mode): every tensor is TWO fp16 images / planes of EltH's layout, hi and lo, the lo
+//          one a fixed distance behind the hi one (LDS: `lds_lo` bytes, HBM: the buffer's lo-plane distance); a weight block
+//          is the 2-KiB pair [hi | lo]; three v_mfma_f32_16x16x32_f16 per k block (hi*hi + hi*lo + lo*hi), fp32 accumulators
 typedef int intx4 __attribute__((ext_vector_type(4)));
 struct EltH {
-  static constexpr bool I8 = false;
-  static constexpr int CH = 8, KBLK = 32, ESZ = 2, CM = 1;   // CM: fp32 constants per output channel (bias)
+  static constexpr bool I8 = false, SPLIT = false;
+  static constexpr int CH = 8, KBLK = 32, ESZ = 2, CM = 1, WBLK = 1024;   // CM: fp32 constants per output channel (bias); WBLK: bytes per weight block
   typedef half8 frag;
   typedef floatx4 acc_t;
   static __device__ __forceinline__ acc_t mma(const frag& a, const frag& b, const acc_t& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
   }
+  static __device__ __forceinline__ frag ld(const unsigned char* at, long long) { return *reinterpret_cast<const frag*>(at); }   // fragment at `at`
+  static __device__ __forceinline__ frag ldw(const unsigned char* at) { return *reinterpret_cast<const frag*>(at); }             // this lane's 16 bytes of a weight block
 };
 struct EltI8 {
-  static constexpr bool I8 = true;
-  static constexpr int CH = 16, KBLK = 64, ESZ = 1, CM = 3;  // bias | multiplier | 1 / s_out
+  static constexpr bool I8 = true, SPLIT = false;
+  static constexpr int CH = 16, KBLK = 64, ESZ = 1, CM = 3, WBLK = 1024;  // bias | multiplier | 1 / s_out
   typedef intx4 frag;
   typedef intx4 acc_t;
   static __device__ __forceinline__ acc_t mma(const frag& a, const frag& b, const acc_t& c) {
     return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ frag ld(const unsigned char* at, long long) { return *reinterpret_cast<const frag*>(at); }
+  static __device__ __forceinline__ frag ldw(const unsigned char* at) { return *reinterpret_cast<const frag*>(at); }
+};
+struct EltS {
+  static constexpr bool I8 = false, SPLIT = true;
+  static constexpr int CH = 8, KBLK = 32, ESZ = 2, CM = 1, WBLK = 2048;   // (CH / ESZ per plane)
+  typedef half8x2 frag;
+  typedef floatx4 acc_t;
+  static __device__ __forceinline__ acc_t mma(const frag& a, const frag& b, const acc_t& c) { return mfma_split(a, b, c); }
+  static __device__ __forceinline__ frag ld(const unsigned char* at, long long lo) {
+    return frag{*reinterpret_cast<const half8*>(at), *reinterpret_cast<const half8*>(at + lo)};
+  }
+  static __device__ __forceinline__ frag ldw(const unsigned char* at) {
+    return frag{*reinterpret_cast<const half8*>(at), *reinterpret_cast<const half8*>(at + 1024)};
   }
 };
 
@@ -107,7 +127,9 @@ __device__ __forceinline__ void wq_fetch(FRAG (&q)[D], const unsigned char* wbas
 #endif
     constexpr int s = ST::step_of(G), e = G - ST::first(s), wnt = ST::wnt(s), kb = e / wnt, j = e - kb * wnt, ns = ST::ns(s);
     const int nsub = (wid % ST::waves_n(s)) * wnt + j;
-    q[G % D] = *reinterpret_cast<const FRAG*>(wbase + (size_t)(ST::blk(s) + kb * ns + nsub) * 1024);
+    constexpr int WBLK = (int)sizeof(FRAG) * 64;   // 1 KiB, or the 2-KiB (hi | lo) pair of the split type
+    if constexpr (sizeof(FRAG) == 32) q[G % D] = EltS::ldw(wbase + (size_t)(ST::blk(s) + kb * ns + nsub) * WBLK);
+    else q[G % D] = *reinterpret_cast<const FRAG*>(wbase + (size_t)(ST::blk(s) + kb * ns + nsub) * WBLK);
   }
 }
 
@@ -122,9 +144,10 @@ __device__ __forceinline__ void lds_barrier() {  // publishes this wave's LDS wr
 //                    std::integral_constant) -- the same for all of the wave's channel subtiles
 //   epi(sub, n, acc): consumes channels n..n+3 of pixel sub*16 + (lane & 15)
 // Ends with the barrier that publishes the epilogue's LDS writes.
+// lds_lo (EltS): byte distance from an LDS image to its lo twin.
 template <typename ST, int D, int S, int P, typename E = EltH, typename BAddr, typename Epi>
 __device__ __forceinline__ void run_step(typename E::frag (&q)[D], const unsigned char* wbase, const unsigned char* smem,
-                                         int wid, int lane, BAddr baddr, Epi epi) {
+                                         int wid, int lane, BAddr baddr, Epi epi, int lds_lo = 0) {
   typedef typename E::frag frag;
   typedef typename E::acc_t acc_t;
   constexpr int KB = ST::kb(S), G0 = ST::first(S), WN_T = ST::wnt(S), WVN = ST::waves_n(S), WVM = ST::waves_m(S);
@@ -143,7 +166,7 @@ __device__ __forceinline__ void run_step(typename E::frag (&q)[D], const unsigne
   for (int i = 0; i < WM_T; ++i) {
 #pragma unroll
     for (int j = 0; j < WN_T; ++j) acc[j][i] = acc_t{0, 0, 0, 0};
-    if constexpr (DB) b[0][i] = *reinterpret_cast<const frag*>(smem + baddr_t(wm * WM_T + i, std::integral_constant<int, 0>{}));
+    if constexpr (DB) b[0][i] = E::ld(smem + baddr_t(wm * WM_T + i, std::integral_constant<int, 0>{}), lds_lo);
   }
   static_for<0, KB>([&](auto kc) {
     constexpr int kb = decltype(kc)::value;
@@ -155,11 +178,11 @@ __device__ __forceinline__ void run_step(typename E::frag (&q)[D], const unsigne
       if constexpr (kb + 1 < KB) {
 #pragma unroll
         for (int i = 0; i < WM_T; ++i)
-          b[(kb + 1) & 1][i] = *reinterpret_cast<const frag*>(smem + baddr_t(wm * WM_T + i, std::integral_constant<int, kb + 1>{}));
+          b[(kb + 1) & 1][i] = E::ld(smem + baddr_t(wm * WM_T + i, std::integral_constant<int, kb + 1>{}), lds_lo);
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < WM_T; ++i) b[kb & 1][i] = *reinterpret_cast<const frag*>(smem + baddr_t(wm * WM_T + i, kc));
+      for (int i = 0; i < WM_T; ++i) b[kb & 1][i] = E::ld(smem + baddr_t(wm * WM_T + i, kc), lds_lo);
     }
 #pragma unroll
     for (int j = 0; j < WN_T; ++j)
@@ -212,8 +235,10 @@ __device__ __forceinline__ floatx4 act_relu(const typename E::acc_t& acc, const 
 }
 // v + residual (channels n..n+3 of image row `row`); int8: fma(code, s_res, v)
 template <typename E>
-__device__ __forceinline__ floatx4 add_res(floatx4 v, const unsigned char* smem, const Img& im, int row, int n, float res_scale) {
-  if constexpr (E::I8) {
+__device__ __forceinline__ floatx4 add_res(floatx4 v, const unsigned char* smem, const Img& im, int row, int n, float res_scale, int lds_lo = 0) {
+  if constexpr (E::SPLIT) {
+    return v + load_h4(smem, im, row, n) + load_h4(smem + lds_lo, im, row, n);
+  } else if constexpr (E::I8) {
     const int rv = *reinterpret_cast<const int*>(smem + im.addr(row, n >> 4) + (n & 15));
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf((float)(signed char)(rv >> (8 * r)), res_scale, v[r]);
@@ -223,9 +248,19 @@ __device__ __forceinline__ floatx4 add_res(floatx4 v, const unsigned char* smem,
   }
 }
 // 4 consecutive channels -> memory at `at` (fp16: 8 bytes; int8: q = clamp(rne(v * inv), -127, 127), 4 bytes)
+// (split fp16: 8 bytes of the hi value at `at`, 8 of the lo value `lo` bytes behind it)
 template <typename E, int NCH>
-__device__ __forceinline__ void store4(unsigned char* at, const floatx4& v, const float* c, int n) {
-  if constexpr (E::I8) {
+__device__ __forceinline__ void store4(unsigned char* at, const floatx4& v, const float* c, int n, long long lo = 0) {
+  if constexpr (E::SPLIT) {
+    half4 hv, lv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      hv[r] = (_Float16)v[r];
+      lv[r] = (_Float16)(v[r] - (float)hv[r]);
+    }
+    *reinterpret_cast<half4*>(at) = hv;
+    *reinterpret_cast<half4*>(at + lo) = lv;
+  } else if constexpr (E::I8) {
     const floatx4 inv = *reinterpret_cast<const floatx4*>(c + 2 * NCH + n);
     unsigned int q = 0;
 #pragma unroll
@@ -275,9 +310,10 @@ __device__ __forceinline__ void consts_commit(const floatx4 (&v)[kConstVecs], fl
 // Input patch -> LDS image by LDS-DMA: 16-byte slot s = (region pixel r of an RH x RW region whose origin is image
 // pixel (y0, x0), chunk cs); out-of-image pixels read the zero page. NT threads; every wave must afterwards wait
 // vmcnt(0) (its own DMAs) and pass a barrier before anyone reads the image.
+// EltS: the lo plane (src_lo bytes behind the hi plane in HBM) lands lds_lo bytes behind the hi image.
 template <int RH, int RW, int CIN, int NT, typename E = EltH>
 __device__ __forceinline__ void load_patch(unsigned char* lds_img, const void* src_, int src_ld, int H, int W, int y0,
-                                           int x0, const void* zeros, int wid, int lane) {
+                                           int x0, const void* zeros, int wid, int lane, long long src_lo = 0, int lds_lo = 0) {
   constexpr Img X = make_img(0, CIN / E::CH);
   constexpr int nchx = CIN / E::CH, nslots = RH * RW * nchx;
   const unsigned char* src = static_cast<const unsigned char*>(src_);
@@ -292,6 +328,7 @@ __device__ __forceinline__ void load_patch(unsigned char* lds_img, const void* s
         g = src + ((size_t)(iy * W + ix) * src_ld) * E::ESZ + ((cs ^ X.key(r)) << 4);
     }
     glds16(g, lds_img + s0 * 16);
+    if constexpr (E::SPLIT) glds16(g == static_cast<const unsigned char*>(zeros) ? g : g + src_lo, lds_img + lds_lo + s0 * 16);
   }
 }
 

@@ -65,6 +65,11 @@ struct Class {
   {kI8, H_, NB, CIN, 2, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,+1x1>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 2, EltI8>, 0, 0}
 #define C3K2IL(H_, TH, TW, NB, CIN, NW, D) \
   {kI8, H_, NB, CIN, 3, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,lat f16>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 3, EltI8>, 0, 0}
+// STRICT engines (split fp16: hi / lo images, 2-KiB weight block pairs, D pairs in flight per wave)
+#define C3K2X(H_, TH, TW, NB, CIN, NW, D, TAIL, TN) \
+  {kS16, H_, NB, CIN, TAIL, TH, TW, NW, "c3k2_fused<s16," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w" TN ">", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, TAIL, EltS>, 0, 0}
+#define C3K2XS(H_, TH, TW, NB, CIN, NW, D, CPRE, CX) \
+  {kS16, H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<s16," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w,s2conv " #CPRE ">", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0, EltS, CPRE, CX>, CPRE, CX}
 #define C3K2I(H_, TH, TW, NB, CIN, NW, D) \
   {kI8, H_, NB, CIN, 0, TH, TW, NW, "c3k2_fused<i8," #H_ "," #TH "x" #TW "," #NB "," #CIN "," #NW "w>", c3k2_fused_kernel<H_, TH, TW, NB, CIN, NW, D, 0, EltI8>, 0, 0}
 const Class kClasses[] = {
@@ -98,6 +103,19 @@ const Class kClasses[] = {
     C3K2IP(128, 4, 4, 2, 256, 8, 8),   // backbone.stage3_c3k2 + backbone.sppf.cv1
     C3K2I(128, 4, 4, 1, 384, 8, 8),    // neck.pan_c3k2_2
     C3K2I(128, 4, 4, 1, 512, 8, 8),    // graph (B) fpn_c3k2_1
+    // STRICT engines: the same seven blocks of graph (A) on split-fp16 tensors
+    C3K2X(32, 8, 8, 1, 64, 8, 4, 0, ""),            // backbone.stage1_block
+    C3K2XS(32, 8, 8, 1, 64, 8, 4, 32, 64),          // backbone.stage1_conv + backbone.stage1_block
+    C3K2XS(64, 4, 8, 1, 192, 8, 4, 64, 64),         // neck.down1 + neck.pan_c3k2_1
+    C3K2XS(128, 4, 4, 1, 384, 8, 8, 128, 128),      // neck.down2 + neck.pan_c3k2_2
+    C3K2X(32, 8, 8, 1, 128, 8, 4, 0, ""),           // neck.fpn_c3k2_2
+    C3K2X(64, 4, 8, 2, 128, 8, 4, 0, ""),           // backbone.stage2_c3k2
+    C3K2X(64, 4, 8, 1, 256, 8, 4, 0, ""),           // neck.fpn_c3k2_1
+    C3K2X(64, 4, 8, 1, 256, 8, 4, 1, ",lat"),       // neck.fpn_c3k2_1 + neck.lateral_p2 (+ x2 upsample)
+    C3K2X(64, 4, 8, 1, 192, 8, 4, 0, ""),           // neck.pan_c3k2_1
+    C3K2X(128, 4, 4, 2, 256, 8, 8, 0, ""),          // backbone.stage3_c3k2
+    C3K2X(128, 4, 4, 2, 256, 8, 8, 2, ",+1x1"),     // backbone.stage3_c3k2 + backbone.sppf.cv1
+    C3K2X(128, 4, 4, 1, 384, 8, 8, 0, ""),          // neck.pan_c3k2_2
 };
 #undef C3K2
 #undef C3K2T
@@ -107,6 +125,8 @@ const Class kClasses[] = {
 #undef C3K2P
 #undef C3K2IL
 #undef C3K2IP
+#undef C3K2X
+#undef C3K2XS
 const Class* find_class(int hid, int nb, int cin, int tail, int dtype, int cpre = 0, int cx = 0) {
   for (const Class& c : kClasses)
     if (c.dtype == dtype && c.hid == hid && c.nb == nb && c.cin == cin && c.tail == tail && c.cpre == cpre && (!cpre || c.cx == cx)) return &c;
@@ -174,6 +194,11 @@ bool c3k2_layout(C3k2Params* p) {
   int yr = y_bytes > tail_bytes ? y_bytes : tail_bytes;
   yr = yr > p_bytes ? yr : p_bytes;
   off += align_up(yr, 1024);
+  p->lds_lo = 0;
+  if (p->dtype == kS16) {   // every image has a lo twin: the whole image area once more behind itself
+    p->lds_lo = off - p->off_x;
+    off += p->lds_lo;
+  }
   p->smem_bytes = off;
   return off <= kMaxLds;
 }
@@ -187,13 +212,14 @@ void block_pack(const C3k2Conv* convs, int nconv, std::vector<unsigned char>* st
   for (int ci = 0; ci < nconv; ++ci) {
     const C3k2Conv& cv = convs[ci];
     const int ns = (cv.n[0] + cv.n[1]) / 16, kbn = cv.K / (dtype == kI8 ? 64 : 32);
+    const size_t wblk = dtype == kS16 ? 2048 : 1024;   // split fp16: a block is the (hi | lo) pair
     const size_t base = stream->size();
-    stream->resize(base + (size_t)kbn * ns * 1024, 0);
+    stream->resize(base + (size_t)kbn * ns * wblk, 0);
     for (int kb = 0; kb < kbn; ++kb)
       for (int s = 0; s < ns; ++s) {
         const int seg = s * 16 < cv.n[0] ? 0 : 1;
         const int ls = seg ? s - cv.n[0] / 16 : s;
-        memcpy(stream->data() + base + ((size_t)kb * ns + s) * 1024, cv.w[seg] + ((size_t)ls * kbn + kb) * 1024, 1024);
+        memcpy(stream->data() + base + ((size_t)kb * ns + s) * wblk, cv.w[seg] + ((size_t)ls * kbn + kb) * wblk, wblk);
       }
     for (int seg = 0; seg < 2; ++seg)
       for (int i = 0; i < cv.n[seg]; ++i) bias->push_back(cv.bias[seg][i]);

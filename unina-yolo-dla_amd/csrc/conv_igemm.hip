@@ -97,18 +97,11 @@ template <> struct Elem<half_t> {
 };
 // split fp16 (kS16): a fragment is the pair (hi, lo) of 16-byte fragments; its LDS / block image keeps the lo plane `lo_off`
 // bytes behind the hi plane (the next 1-KiB block of a staged block pair). Three MFMAs per k block, small terms first.
-struct half8x2 {
-  half8 h, l;
-};
 template <> struct Elem<s16_t> {
   static constexpr int kChunk = 8, kBlockK = 32, kPlanes = 2;
   typedef half8x2 frag;
   typedef floatx4 acc_t;
-  static __device__ __forceinline__ acc_t mma(const frag& a, const frag& b, acc_t c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, b.h, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.l, c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.h, c, 0, 0, 0);
-  }
+  static __device__ __forceinline__ acc_t mma(const frag& a, const frag& b, acc_t c) { return mfma_split(a, b, c); }
   static __device__ __forceinline__ floatx4 to_float(const acc_t& c) { return c; }
   static __device__ __forceinline__ frag lds(const unsigned char* at, int lo_off) {
     return frag{*reinterpret_cast<const half8*>(at), *reinterpret_cast<const half8*>(at + lo_off)};
@@ -821,8 +814,9 @@ template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, bool STEM =
 __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, int nwg, const StemParams* sp = nullptr) {
   typedef Elem<T> E;
   typedef typename E::frag frag;
-  typedef typename std::conditional<sizeof(T) == 1, EltI8, EltH>::type PE;   // block_pipeline.h element traits of T
-  static_assert(!STEM || sizeof(T) == 2, "the stem patch is fp16");
+  constexpr bool SPLIT = E::kPlanes == 2;
+  typedef typename std::conditional<sizeof(T) == 1, EltI8, typename std::conditional<SPLIT, EltS, EltH>::type>::type PE;   // block_pipeline.h element traits of T
+  static_assert(!STEM || (sizeof(T) == 2 && !SPLIT), "the stem patch is fp16");
   // S = stride (1 or 2): the patch is the (S*TH + 2 or S*TH + 1) x (...) input footprint of the tile
   constexpr int BM = TH * TW, R0W = S * (TW - 1) + 3, R0H = S * (TH - 1) + 3, NT = NW * 64, CB = CIN / E::kBlockK, KB = 9 * CB;
   static_assert(CIN % E::kBlockK == 0, "a weight block must not straddle a tap");
@@ -850,19 +844,25 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
   for (int j = 0; j < WN; ++j) {
     int nsub = (nb0 >> 4) + wn * WN + j;
     nsub = nsub * 16 < n_pad ? nsub : (n_pad >> 4) - 1;
-    wptr[j] = static_cast<const unsigned char*>(sg.w) + (size_t)nsub * KB * 1024 + (4 * l15 + (lq ^ swz_g(l15))) * 16;
+    wptr[j] = static_cast<const unsigned char*>(sg.w) + (size_t)nsub * KB * PE::WBLK + (4 * l15 + (lq ^ swz_g(l15))) * 16;
   }
   frag q[D];
   auto fetch = [&](auto gc) {
     constexpr int g = decltype(gc)::value;
-    if constexpr (g < KB * WN) q[g % D] = *reinterpret_cast<const frag*>(wptr[g % WN] + (g / WN) * 1024);
+    if constexpr (g < KB * WN) q[g % D] = PE::ldw(wptr[g % WN] + (g / WN) * PE::WBLK);
   };
+  // split fp16: the lo image of the patch lies LDS_LO bytes behind the hi image
+  constexpr int LDS_LO = SPLIT ? ((R0H * R0W * CIN * 2 + 1023) / 1024) * 1024 + 1024 : 0;
 
   constexpr Img X = make_img(0, CIN / E::kChunk);
   if constexpr (STEM) {
     static_for<0, D>(fetch);   // weights first: they are in flight while the stem patch is computed
     constexpr int PATCH = ((R0H * R0W * CIN * 2 + 1023) / 1024) * 1024;
     stem_patch<R0H, R0W, CIN, NT>(conv_smem, conv_smem + PATCH, *sp, S * ty0 - 1, S * tx0 - 1);
+  } else if constexpr (SPLIT) {   // both planes by LDS-DMA (twice the registers of a register-staged patch would not fit)
+    load_patch<R0H, R0W, CIN, NT, PE>(conv_smem, static_cast<const T*>(p.src) + sg.src_coff, p.src_ld, p.H, p.W, S * ty0 - 1,
+                                      S * tx0 - 1, p.zeros, wid, lane, p.src_lo, LDS_LO);
+    static_for<0, D>(fetch);
   } else if constexpr (kPatchViaRegs) {
     PatchRegs<R0H, R0W, CIN, NT, PE> pr;
     if constexpr (UNINA_PATCH_VIA_REGS == 2)
@@ -879,8 +879,8 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
   }
   EpiConsts<WN> ec;
   load_epi_consts<WN>(sg, nb0 + wn * (WN * 16), lq, ec);
-  if constexpr (STAMPS && (STEM || !kPatchViaRegs)) stamp_b(p, 1, bid, nwg);
-  if constexpr (STEM || !kPatchViaRegs) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
+  if constexpr (STAMPS && (STEM || SPLIT || !kPatchViaRegs)) stamp_b(p, 1, bid, nwg);
+  if constexpr (STEM || SPLIT || !kPatchViaRegs) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
   lds_barrier();
   if constexpr (STAMPS) stamp_b(p, 2, bid, nwg);
 
@@ -901,7 +901,7 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
   for (int i = 0; i < WM_T; ++i) {
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[j][i] = typename E::acc_t{0, 0, 0, 0};
-    b[0][i] = *reinterpret_cast<const frag*>(conv_smem + baddr(i, std::integral_constant<int, 0>{}));
+    b[0][i] = PE::ld(conv_smem + baddr(i, std::integral_constant<int, 0>{}), LDS_LO);
   }
   static_for<0, KB>([&](auto kc) {
     constexpr int kb = decltype(kc)::value;
@@ -911,7 +911,7 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
     static_for<0, WN>([&](auto jc) { fetch(std::integral_constant<int, kb * WN + decltype(jc)::value + D>{}); });
     if constexpr (kb + 1 < KB) {
 #pragma unroll
-      for (int i = 0; i < WM_T; ++i) b[(kb + 1) & 1][i] = *reinterpret_cast<const frag*>(conv_smem + baddr(i, std::integral_constant<int, kb + 1>{}));
+      for (int i = 0; i < WM_T; ++i) b[(kb + 1) & 1][i] = PE::ld(conv_smem + baddr(i, std::integral_constant<int, kb + 1>{}), LDS_LO);
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j)
@@ -1150,6 +1150,11 @@ __global__ __launch_bounds__(512, 4) void conv_dual_head3x3_i8(const ConvParams 
   if ((int)blockIdx.x < na) conv3x3_regq_body<8, 16, 64, 128, 8, 8, 1, false, 1, signed char>(pa, (int)blockIdx.x, na);
   else conv3x3_regq_body<8, 8, 64, 256, 8, 8, 1, false, 1, signed char>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
 }
+// STRICT engines: the same pair on split-fp16 tensors (hi / lo patch images: one workgroup per CU)
+__global__ __launch_bounds__(512) void conv_dual_head3x3_s16(const ConvParams pa, const ConvParams pb, int na) {
+  if ((int)blockIdx.x < na) conv3x3_regq_body<8, 16, 64, 128, 8, 8, 1, false, 1, s16_t>(pa, (int)blockIdx.x, na);
+  else conv3x3_regq_body<8, 8, 64, 256, 8, 8, 1, false, 1, s16_t>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
+}
 // Twice the pixels per workgroup (16x16 | 8x16): 100 + 104 workgroups at 640^2 -- ONE per CU instead of up to two, so the
 // busiest CU streams one workgroup's weights (147 / 295 KB) instead of two's, with a full-depth queue.
 __global__ __launch_bounds__(512) void conv_dual_head3x3_big(const ConvParams pa, const ConvParams pb, int na) {
@@ -1218,6 +1223,12 @@ constexpr size_t smem_of() {
 #define REGQI2(TH, TW, BN, CIN, NW, D)                                                               \
   {(TH) * (TW), BN, 32, 3, "conv3x3_regq<i8," #TH "x" #TW "," #BN "," #CIN "," #NW "w,s2>",              \
    conv3x3_regq<TH, TW, BN, CIN, NW, D, 2, 1, signed char>, 0, TH, TW, CIN, (NW) * 64, 2}
+#define REGQS(TH, TW, BN, CIN, NW, D)                                                                \
+  {(TH) * (TW), BN, 32, 3, "conv3x3_regq<s16," #TH "x" #TW "," #BN "," #CIN "," #NW "w>",                \
+   conv3x3_regq<TH, TW, BN, CIN, NW, D, 1, 1, s16_t>, 0, TH, TW, CIN, (NW) * 64, 1}
+#define REGQS2(TH, TW, BN, CIN, NW, D)                                                               \
+  {(TH) * (TW), BN, 32, 3, "conv3x3_regq<s16," #TH "x" #TW "," #BN "," #CIN "," #NW "w,s2>",             \
+   conv3x3_regq<TH, TW, BN, CIN, NW, D, 2, 1, s16_t>, 0, TH, TW, CIN, (NW) * 64, 2}
 #define WS(TH, CIN, NW)                                                                              \
   {(TH) * 16, (NW) * 16, 32, 3, "conv3x3_ws<f16," #TH "x16," #CIN "," #NW "w>",                          \
    conv3x3_ws<TH, CIN, NW>, 0, TH, 16, CIN, (NW) * 64, 1, true}
@@ -1383,8 +1394,22 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         NOCFG,                                      // kCfg64x64k64s6
         NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,   // halo kernels
         NOCFG, NOCFG,                               // kCfg32x64k128, kCfg64x64k128
-        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
-        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
+        // register-queue 3x3: hi / lo patch images in LDS, (hi | lo) weight block pairs through the queue (D pairs = 2 D KiB in flight)
+        REGQS(8, 16, 64, 128, 8, 8),                // kCfgRegq8x16n64c128   (P3 head layers)
+        REGQS(8, 8, 64, 128, 8, 8),                 // kCfgRegq8x8n64c128
+        REGQS(8, 8, 64, 256, 8, 8),                 // kCfgRegq8x8n64c256    (P4 head layers)
+        NOCFG,                                      // kCfgRegq8x8n32c256
+        REGQS(8, 16, 64, 64, 8, 8),                 // kCfgRegq8x16n64c64    (P2 head layers)
+        NOCFG,                                      // kCfgRegq8x16n32c128
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
+        REGQS2(8, 8, 64, 64, 8, 8),                 // kCfgRegqS2_8x8n64c64     (stage2_conv, down1)
+        NOCFG,                                      // kCfgRegqS2_8x16n64c64
+        REGQS2(8, 8, 64, 128, 8, 8),                // kCfgRegqS2_8x8n64c128    (stage3_conv, down2)
+        REGQS2(4, 8, 64, 128, 8, 8),                // kCfgRegqS2_4x8n64c128
+        REGQS2(8, 16, 64, 32, 8, 8),                // kCfgRegqS2_8x16n64c32    (stage1_conv)
+        NOCFG,                                      // kCfgRegqS2_8x8n32c128
+        NOCFG, NOCFG,
+        NOCFG, NOCFG,
         NOCFG, NOCFG,
     },
 };
@@ -1398,6 +1423,8 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
 #undef NOCFG
 #undef WS
 #undef WSI
+#undef REGQS
+#undef REGQS2
 
 inline int block_k(int dtype) { return dtype == kF32 ? 16 : (dtype == kI8 ? 64 : 32); }   // (kS16: 32 per plane)
 inline int kstep_of(const ConvParams& p, const CfgInfo& c) { return (c.bk / 32) * block_k(p.dtype); }
@@ -1408,6 +1435,7 @@ inline size_t smem_for(const ConvParams& p, const CfgInfo& c) {
     const size_t ph = c.stride * (c.th - 1) + 3, pw = c.stride * (c.tw - 1) + 3;
     const size_t patch = ((ph * pw * c.cin * esize(p) + 1023) & ~(size_t)1023) + 1024;
     if (c.ws) return ph * pw * (c.cin * esize(p) + 32);   // padded pixel pitch, no swizzle (conv3x3_ws_body)
+    if (p.dtype == kS16) return 2 * patch;                // hi and lo images; accumulators are stored straight from registers
     return max_sz(patch, stage_bytes((c.bm + 15) & ~15, c.bn));
   }
   const size_t patch = (size_t)(c.th + 2) * (c.tw + 2) * p.Cin * esize(p);
@@ -1425,7 +1453,7 @@ int n_tiles(const ConvParams& p, int bn) {
 
 hipError_t conv_init() {
   for (const void* f : {reinterpret_cast<const void*>(conv_dual_head3x3), reinterpret_cast<const void*>(conv_dual_head1x1),
-                        reinterpret_cast<const void*>(conv_dual_head3x3_i8),
+                        reinterpret_cast<const void*>(conv_dual_head3x3_i8), reinterpret_cast<const void*>(conv_dual_head3x3_s16),
                         reinterpret_cast<const void*>(conv_dual_head3x3_big), reinterpret_cast<const void*>(conv_dual_head3x3_big_i8),
                         reinterpret_cast<const void*>(conv_dual_head3x3_big_stamped),
                         reinterpret_cast<const void*>(conv_dual_head3x3_ws), reinterpret_cast<const void*>(conv_dual_head3x3_ws_stamped),
@@ -1582,7 +1610,7 @@ struct DualKind {
   const char* name;
   void (*fn)(const ConvParams, const ConvParams, int);
 };
-enum { kDualRegq = 0, kDual1x1, kDualRegqI8, kDualBig, kDualBigI8, kDualWs, kDualWsI8, kDualKinds };
+enum { kDualRegq = 0, kDual1x1, kDualRegqI8, kDualBig, kDualBigI8, kDualWs, kDualWsI8, kDualRegqS16, kDualKinds };
 const DualKind kDual[kDualKinds] = {
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3<regq 8x16,64,128 | regq 8x8,64,256>", conv_dual_head3x3},
     {kCfg128x16k64, kCfg128x16k64, 256, "conv_dual_head1x1<glds 128,16,64 x2>", conv_dual_head1x1},
@@ -1591,6 +1619,7 @@ const DualKind kDual[kDualKinds] = {
     {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big_i8<regq i8,16x16,64,128 | regq i8,8x16,64,256>", conv_dual_head3x3_big_i8},
     {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws<ws 16x16,64,128 | ws 8x16,64,256>", conv_dual_head3x3_ws},
     {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws_i8<ws i8,16x16,64,128 | ws i8,8x16,64,256>", conv_dual_head3x3_ws_i8},
+    {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3_s16<regq s16,8x16,64,128 | regq s16,8x8,64,256>", conv_dual_head3x3_s16},
 };
 }  // namespace
 
@@ -1608,6 +1637,7 @@ int conv_dual_match(const ConvParams& a, const ConvParams& b) {
     if (big && fits(kDualBigI8)) return kDualBigI8;
     return fits(kDualRegqI8) ? kDualRegqI8 : -1;
   }
+  if (a.dtype == kS16 && b.dtype == kS16) return fits(kDualRegqS16) ? kDualRegqS16 : -1;
   if (a.dtype != kF16 || b.dtype != kF16) return -1;
   // the weights-stationary pair: default for fp16 (same-box A/B against the register-queue pair: +2-3 % frames/s at 2 frames in
   // flight, serial latency equal within noise; workgroup lives 9-11 us against 12-15). UNINA_DUAL_WS=0 falls back.

@@ -50,8 +50,11 @@ __global__ __launch_bounds__(NW * 64) void conv_pair_kernel(const PairParams p) 
   typedef StepTable<PL, NW> ST;
   static_assert(ST::valid(), "wave roles");
   static_assert(C0 % E::KBLK == 0 && C1 % E::KBLK == 0, "K blocks");
+  static_assert(!E::SPLIT || (!POOL && !UNINA_BLOCK_PATCH_REGS), "split fp16: the pools run as their own launch (the halo'd x image and its vertical maxima do not fit LDS twice)");
   constexpr int PT = TH * TW, NT = NW * 64, ESZ = E::ESZ;
+  constexpr int NPL = E::SPLIT ? 2 : 1;
   unsigned char* smem = pair_smem;
+  const int lds_lo = E::SPLIT ? p.lds_lo : 0;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(NW * 64) void conv_pair_kernel(const PairParams p) 
   if constexpr (POOL)
     load_patch<RH, RW, CXP, NT, E>(smem + p.off_r, p.src, p.src_ld, p.H, p.W, ty0 - 6, tx0 - 6, p.zeros, wid, lane);
   else
-    load_patch<TH, TW, C0, NT, E>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0, tx0, p.zeros, wid, lane);
+    load_patch<TH, TW, C0, NT, E>(smem + p.off_x, p.src, p.src_ld, p.H, p.W, ty0, tx0, p.zeros, wid, lane, p.src_lo, lds_lo);
   static_for<0, D>([&](auto gc) { wq_fetch<ST, D, decltype(gc)::value>(q, wbase, wid); });
   consts_issue<NT>(cregs, p.bias, p.n_bias);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(NW * 64) void conv_pair_kernel(const PairParams p) 
 #endif
 
   const Img Xi = Img{p.off_x, X.nch, X.sh, X.mask};
-  if constexpr (POOL) {
+  if constexpr (POOL && !E::SPLIT) {
     typedef typename E::frag frag;
     constexpr Img R0 = make_img(0, NCX);
     const Img R = Img{p.off_r, R0.nch, R0.sh, R0.mask};
@@ -146,16 +149,17 @@ __global__ __launch_bounds__(NW * 64) void conv_pair_kernel(const PairParams p) 
       [&](int sub, auto kc) { return Xi.addr(pixel(sub), decltype(kc)::value * 4 + lq); },
       [&](int sub, int n, const acc_t& acc) {
         const int pp = sub * 16 + l15;
-        if (pp < PT) store4<E, C1>(stage + pp * ROWB + n * ESZ, act_relu<E, C1>(acc, c0, n), c0, n);
-      });
+        if (pp < PT) store4<E, C1>(stage + pp * ROWB + n * ESZ, act_relu<E, C1>(acc, c0, n), c0, n, lds_lo);
+      }, lds_lo);
   constexpr int CPR = C1 * ESZ / 16;
   unsigned char* dst = static_cast<unsigned char*>(p.dst);
-  for (int c = threadIdx.x; c < PT * CPR; c += NT) {
-    const int pp = c / CPR, ch = c - pp * CPR;
+  for (int c = threadIdx.x; c < NPL * PT * CPR; c += NT) {
+    const int pl = NPL == 1 ? 0 : c / (PT * CPR), cc = c - pl * (PT * CPR);   // (split: the hi tile, then the lo tile)
+    const int pp = cc / CPR, ch = cc - pp * CPR;
     const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
     if (oy < p.H && ox < p.W)
-      *reinterpret_cast<vec16*>(dst + ((size_t)(oy * p.W + ox) * p.dst_ld) * ESZ + ch * 16) =
-          *reinterpret_cast<const vec16*>(stage + pp * ROWB + ch * 16);
+      *reinterpret_cast<vec16*>(dst + (NPL == 1 ? 0 : pl * p.dst_lo) + ((size_t)(oy * p.W + ox) * p.dst_ld) * ESZ + ch * 16) =
+          *reinterpret_cast<const vec16*>(stage + pl * lds_lo + pp * ROWB + ch * 16);
   }
 
   // ---- step 1: z = ReLU(W1 y + b1) -> output tile -> HBM (x2 nearest upsample in the store when UP2) ----
@@ -167,16 +171,18 @@ __global__ __launch_bounds__(NW * 64) void conv_pair_kernel(const PairParams p) 
       [&](int sub, auto kc) { return YS.addr(pixel(sub), decltype(kc)::value * 4 + lq); },
       [&](int sub, int n, const acc_t& acc) {
         const int pp = sub * 16 + l15;
-        if (pp < PT) store4<E, C2>(tout + pp * ROWT + n * ESZ, act_relu<E, C2>(acc, c1, n), c1, n);
-      });
+        if (pp < PT) store4<E, C2>(tout + pp * ROWT + n * ESZ, act_relu<E, C2>(acc, c1, n), c1, n, lds_lo);
+      }, lds_lo);
   constexpr int CPT = C2 * ESZ / 16;
-  unsigned char* dst2 = static_cast<unsigned char*>(p.dst2);
+  unsigned char* dst2b = static_cast<unsigned char*>(p.dst2);
   const size_t px = (size_t)p.dst2_ld * ESZ, row = (size_t)(2 * p.W) * px;
-  for (int c = threadIdx.x; c < PT * CPT; c += NT) {
-    const int pp = c / CPT, ch = c - pp * CPT;
+  for (int c = threadIdx.x; c < NPL * PT * CPT; c += NT) {
+    const int pl = NPL == 1 ? 0 : c / (PT * CPT), cc = c - pl * (PT * CPT);
+    const int pp = cc / CPT, ch = cc - pp * CPT;
     const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
     if (oy >= p.H || ox >= p.W) continue;
-    const vec16 v = *reinterpret_cast<const vec16*>(tout + pp * ROWT + ch * 16);
+    const vec16 v = *reinterpret_cast<const vec16*>(tout + pl * lds_lo + pp * ROWT + ch * 16);
+    unsigned char* dst2 = dst2b + (NPL == 1 ? 0 : pl * p.dst2_lo);
     if constexpr (UP2) {
       unsigned char* d = dst2 + ((size_t)(2 * oy) * (2 * p.W) + 2 * ox) * px + ch * 16;
       *reinterpret_cast<vec16*>(d) = v;
@@ -204,6 +210,8 @@ const PClass kPairClasses[] = {
     {kF16, 512, 256, 128, 1, 4, 4, 8, "conv_pair<pool5x3,512,256,128,4x4,8w,up2>", conv_pair_kernel<512, 256, 128, 4, 4, 8, 16, 1, EltH, 1>, 1},
     {kI8, 512, 256, 128, 1, 4, 4, 8, "conv_pair<i8,512,256,128,4x4,8w,up2>", conv_pair_kernel<512, 256, 128, 4, 4, 8, 8, 1, EltI8>, 0},
     {kI8, 512, 256, 128, 1, 4, 4, 8, "conv_pair<i8,pool5x3,512,256,128,4x4,8w,up2>", conv_pair_kernel<512, 256, 128, 4, 4, 8, 8, 1, EltI8, 1>, 1},
+    // STRICT engines (split fp16): the pair only; the SPPF pools stay their own launch (sppf_pool_split_kernel)
+    {kS16, 512, 256, 128, 1, 4, 4, 8, "conv_pair<s16,512,256,128,4x4,8w,up2>", conv_pair_kernel<512, 256, 128, 4, 4, 8, 8, 1, EltS>, 0},
 };
 const PClass* find_pclass(int dtype, int c0, int c1, int c2, int up2, int pool = 0) {
   for (const PClass& c : kPairClasses)
@@ -244,6 +252,11 @@ bool pair_layout(PairParams* p) {
     const int cx = p->c0 / 4, rh = c->th + 12, rw = c->tw + 12;
     p->off_r = off; off += align_up(rh * rw * cx * esz, 1024) + 1024;
     p->off_v = off; off += align_up(3 * c->th * rw * cx * esz, 1024);
+  }
+  p->lds_lo = 0;
+  if (p->dtype == kS16) {   // every image has a lo twin: the whole image area once more behind itself
+    p->lds_lo = off - p->off_x;
+    off += p->lds_lo;
   }
   p->smem_bytes = off;
   return off <= 160 * 1024;

@@ -465,6 +465,7 @@ int plan(unina_engine* e) {
       f.dst2 = static_cast<char*>(out.ptr) + z.seg[0].dst_coff * esz;
       f.dst2_ld = (int)out.d.c;
       f.up2 = (z.seg[0].flags & kSegUp2) ? 1 : 0;
+      f.src_lo = lo_plane(src.d); f.dst_lo = lo_plane(mid.d); f.dst2_lo = lo_plane(out.d);
       f.pool = op.fuse_pre;
       f.wstream = reinterpret_cast<const unsigned char*>(blob + op.stream_off);
       f.bias = reinterpret_cast<const float*>(blob + op.fbias_off);
@@ -474,13 +475,13 @@ int plan(unina_engine* e) {
       if (op.fuse_pre) {   // the pool op is the group's head: the infos of cv2 move onto it
         unina_op_info& ai = e->ops[i + 1].info;
         op.info.flops = ai.flops;
-        op.info.bytes = ai.bytes - (double)esz * f.H * f.W * 3 * (f.c0 / 4);   // the pooled maps are formed in LDS
+        op.info.bytes = ai.bytes - dtype_bytes(f.dtype) * f.H * f.W * 3 * (f.c0 / 4);   // the pooled maps are formed in LDS
         op.info.m = ai.m; op.info.n = ai.n;
         ai.flops = 0; ai.bytes = 0; ai.grid = 0;
         snprintf(ai.kernel, sizeof ai.kernel, "(fused into op %zu)", i);
       }
       op.info.flops += zb.info.flops;
-      op.info.bytes += zb.info.bytes - (double)esz * f.H * f.W * f.c1;     // the second conv reads the first's output from LDS
+      op.info.bytes += zb.info.bytes - dtype_bytes(f.dtype) * f.H * f.W * f.c1;     // the second conv reads the first's output from LDS
       op.info.grid = f.tiles_x * f.tiles_y;
       op.info.block = pair_block_threads(f);
       op.info.k = 0;
@@ -544,6 +545,7 @@ int plan(unina_engine* e) {
     memset(&f, 0, sizeof f);
     f.dtype = act_dtype_of(src.d.dtype);
     const size_t fesz = dtype_size(f.dtype);
+    const double fb = dtype_bytes(f.dtype);
     f.src = static_cast<const char*>(src.ptr) + in.seg[0].src_coff * fesz;
     f.src_ld = (int)src.d.c;
     if (op.fuse_pre) {
@@ -554,7 +556,10 @@ int plan(unina_engine* e) {
       const Buffer& xb = e->bufs[a.src_buf];   // the rest of the block's input (a concat's other part) still comes from HBM
       f.src2 = static_cast<const char*>(xb.ptr) + (a.seg[0].src_coff + f.cx) * fesz;
       f.src2_ld = (int)xb.d.c;
+      f.src2_lo = lo_plane(xb.d);
     }
+    f.src_lo = lo_plane(src.d);
+    f.dst_lo = lo_plane(dst.d);
     f.Cin = (int)a.cin;
     f.H = (int)a.in_h;
     f.W = (int)a.in_w;
@@ -575,6 +580,7 @@ int plan(unina_engine* e) {
       f.tail = op.tail_kind;
       f.dst2 = static_cast<char*>(tb.ptr) + ts.dst_coff * (op.tail_kind == 3 ? 2 : fesz);
       f.dst2_ld = (int)tb.d.c;
+      f.dst2_lo = lo_plane(tb.d);
     }
     if (op.quant_op >= 0) {
       const Buffer& qb = e->bufs[e->ops[op.quant_op].d.seg[0].dst_buf];
@@ -596,7 +602,7 @@ int plan(unina_engine* e) {
     const int last_op = op.tail_op >= 0 ? op.tail_op : op.group_last;
     for (int k = (int)i; k <= last_op; ++k) {
       flops += e->ops[k].info.flops;
-      wbytes += (double)fesz * e->ops[k].info.n * e->ops[k].info.k + 4.0 * e->ops[k].info.n;
+      wbytes += fb * e->ops[k].info.n * e->ops[k].info.k + 4.0 * e->ops[k].info.n;
       if (k > (int)i) {
         unina_op_info& ai = e->ops[k].info;
         ai.flops = 0;
@@ -606,8 +612,8 @@ int plan(unina_engine* e) {
       }
     }
     info.flops = flops;
-    info.bytes = (f.cpre ? (double)fesz * (f.preH * f.preW * f.cpre + f.H * f.W * (f.Cin - f.cx)) : (double)fesz * f.H * f.W * f.Cin) + wbytes + (double)fesz * f.H * f.W * 2 * f.hid +   // input once, weights once, output once
-                 (f.tail ? (double)fesz * (f.tail == 1 ? 4 : 1) * f.H * f.W * f.hid : 0.0);            // (+ the tail conv's output)
+    info.bytes = (f.cpre ? fb * (f.preH * f.preW * f.cpre + f.H * f.W * (f.Cin - f.cx)) : fb * f.H * f.W * f.Cin) + wbytes + fb * f.H * f.W * 2 * f.hid +   // input once, weights once, output once
+                 (f.tail ? fb * (f.tail == 1 ? 4 : 1) * f.H * f.W * f.hid : 0.0);            // (+ the tail conv's output)
     info.n = 2 * f.hid;
     info.k = 0;
     info.grid = f.tiles_x * f.tiles_y;
@@ -864,9 +870,9 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     const OpDesc& a = e->ops[i].d;
     // fp16 block, or (INT8 engines) a block whose input, output and intermediates are all int8 code tensors
     const uint32_t bdt = e->bufs[a.src_buf].d.dtype;
-    if (bdt != kBufF16Nhwc && bdt != kBufI8Nhwc) continue;
+    if (bdt != kBufF16Nhwc && bdt != kBufI8Nhwc && bdt != kBufS16Nhwc) continue;
     const bool i8 = bdt == kBufI8Nhwc;
-    const int dt = i8 ? kI8 : kF16;
+    const int dt = i8 ? kI8 : (bdt == kBufS16Nhwc ? kS16 : kF16);
     const uint32_t al = i8 ? 16 : 8;   // channels per 16-byte chunk
     if (!is_plain_conv(a, 1, 2, i8) || a.res_buf >= 0) continue;
     const uint32_t h = a.seg[0].n_count;
@@ -906,8 +912,8 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
       if (t.kind == kOpConv && t.ksize == 1 && t.stride == 1 && t.relu && t.nseg == 1 && t.res_buf < 0 && t.seg[0].flags == kSegUp2 &&
           !t.seg[0].m_off && t.seg[0].n_pad == t.seg[0].n_count && t.cin == 2 * h && t.seg[0].n_count == h &&
           t.src_buf == z.seg[0].dst_buf && t.seg[0].src_coff == z.seg[0].dst_coff &&
-          e->bufs[t.seg[0].dst_buf].d.dtype == kBufF16Nhwc && t.seg[0].dst_coff % 8 == 0 && e->bufs[t.seg[0].dst_buf].d.c % 8 == 0 &&
-          t.seg[0].dst_buf != z.seg[0].dst_buf && c3k2_supported((int)h, nb, (int)a.cin, 1))
+          e->bufs[t.seg[0].dst_buf].d.dtype == bdt && t.seg[0].dst_coff % 8 == 0 && e->bufs[t.seg[0].dst_buf].d.c % 8 == 0 &&
+          t.seg[0].dst_buf != z.seg[0].dst_buf && c3k2_supported((int)h, nb, (int)a.cin, 1, dt))
         jt = j + 1;
     }
     // ... or by a plain 1x1 ConvBlock 2h -> h on its output (stage3_c3k2 -> sppf.cv1, model.py:215-216), fp16 or int8
@@ -936,7 +942,7 @@ void find_c3k2_groups(unina_engine* e, std::vector<char>* blob) {
     }
     // INT8 engines: an fp16 block whose output gets an int8 twin from the QUANT op that follows (mixed readers)
     int quant_op = -1;
-    if (!i8 && jt + 1 < n) {
+    if (!i8 && dt == kF16 && jt + 1 < n) {
       const OpDesc& qd = e->ops[jt + 1].d;
       if (qd.kind == kOpQuant && qd.src_buf == z.seg[0].dst_buf && z.seg[0].dst_coff == 0 && e->bufs[z.seg[0].dst_buf].d.c == 2 * h &&
           qd.nseg == 1 && qd.seg[0].dst_coff == 0 && e->bufs[qd.seg[0].dst_buf].d.dtype == kBufI8Nhwc &&
@@ -1064,7 +1070,7 @@ void find_pair_groups(unina_engine* e, std::vector<char>* blob) {
       if (ok) pool = 1;
     }
     const uint32_t bdt = e->bufs[a.src_buf].d.dtype;
-    if (bdt != kBufF16Nhwc && bdt != kBufI8Nhwc) continue;
+    if (bdt != kBufF16Nhwc && bdt != kBufI8Nhwc && bdt != kBufS16Nhwc) continue;
     const bool i8 = bdt == kBufI8Nhwc;
     const uint32_t al = i8 ? 16 : 8;
     if (!is_plain_conv(a, 1, 1, i8) || a.res_buf >= 0) continue;
@@ -1075,7 +1081,7 @@ void find_pair_groups(unina_engine* e, std::vector<char>* blob) {
     if (a.seg[0].src_coff % al || e->bufs[a.src_buf].d.c % al || a.seg[0].dst_coff % al || e->bufs[a.seg[0].dst_buf].d.c % al ||
         z.seg[0].dst_coff % al || e->bufs[z.seg[0].dst_buf].d.c % al) continue;
     if (z.seg[0].dst_buf == a.seg[0].dst_buf || z.seg[0].dst_buf == a.src_buf || a.seg[0].dst_buf == a.src_buf) continue;
-    const int dt = i8 ? kI8 : kF16, up2 = (z.seg[0].flags & kSegUp2) ? 1 : 0;
+    const int dt = i8 ? kI8 : (bdt == kBufS16Nhwc ? kS16 : kF16), up2 = (z.seg[0].flags & kSegUp2) ? 1 : 0;
     if (pool && !pair_supported(dt, (int)a.cin, (int)a.seg[0].n_count, (int)z.seg[0].n_count, up2, 1)) pool = 0;
     if (!pair_supported(dt, (int)a.cin, (int)a.seg[0].n_count, (int)z.seg[0].n_count, up2, pool)) continue;
     C3k2Conv cv[2];
@@ -1536,7 +1542,7 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   }
   // fusable groups: their packed weight streams are appended to the blob before upload. The matchers accept all-fp16
   // groups (in an INT8 engine: the carved-out P2 head, train.py:779) and, for C3k2 blocks, all-int8 groups
-  if (e->h.precision == kFp16 || e->h.precision == kInt8) {
+  if (e->h.precision == kFp16 || e->h.precision == kInt8 || e->h.precision == kSplit16) {
     find_c3k2_groups(e, &blob);
     find_head_groups(e, &blob);
     find_pair_groups(e, &blob);

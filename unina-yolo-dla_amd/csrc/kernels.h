@@ -106,8 +106,10 @@ hipError_t conv_dual_launch(int kind, const ConvParams& a, const ConvParams& b, 
 // every intermediate tensor are int8 codes -- same per-tensor scales and epilogue arithmetic as the per-op table.
 // ------------------------------------------------------------------------------------------------
 struct C3k2Params {
-  int dtype;                     // kF16 or kI8: element type of src, dst and every tensor in between
+  int dtype;                     // kF16, kI8 or kS16: element type of src, dst and every tensor in between
   const void* src;               // block input, channel offset applied
+  long long src_lo, src2_lo, dst_lo, dst2_lo;   // kS16: byte distance hi plane -> lo plane of src / src2 / dst / dst2
+  int lds_lo;                    // kS16 (filled by c3k2_layout): byte distance from an LDS image to its lo twin
   int src_ld, Cin;
   int H, W;                      // spatial size (input == output)
   void* dst;                     // block output (cv3), channel offset applied
@@ -187,8 +189,10 @@ int head_block_threads(int c);
 
 // Two consecutive 1x1 ConvBlocks (SPPF cv2 -> FPN lateral, + x2 upsample store) in ONE launch (conv_pair.hip).
 struct PairParams {
-  int dtype;                     // kF16 or kI8: element type of src, dst and dst2
+  int dtype;                     // kF16, kI8 or kS16: element type of src, dst and dst2
   const void* src;               // input, channel offset applied
+  long long src_lo, dst_lo, dst2_lo;   // kS16: byte distance hi plane -> lo plane of src / dst / dst2
+  int lds_lo;                    // kS16 (filled by pair_layout): byte distance from an LDS image to its lo twin
   int src_ld;
   int c0, c1, c2;                // channels: input, first conv's output, second conv's output
   int H, W;

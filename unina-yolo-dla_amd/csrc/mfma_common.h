@@ -9,6 +9,17 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// split fp16 (kS16, the STRICT precision mode): a fragment is the pair (hi, lo) of 16-byte fp16 fragments
+struct half8x2 {
+  half8 h, l;
+};
+// three MFMAs per k block into one fp32 accumulator, small terms first (the lo*lo term is below fp32 resolution)
+__device__ __forceinline__ floatx4 mfma_split(const half8x2& a, const half8x2& b, floatx4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, b.h, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.l, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.h, c, 0, 0, 0);
+}
+
 // In-block swizzle of a 1-KiB fragment block: the 16-byte slot of (row r, k-chunk c) is 4*r + (c ^ G[r>>2]), G = {0,2,3,1}
 __device__ __forceinline__ int swz_g(int r16) { return (0x78 >> (2 * (r16 >> 2))) & 3; }
 
