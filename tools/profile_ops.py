@@ -17,14 +17,14 @@ ap.add_argument("--sweep", action="store_true")
 ap.add_argument("--size", type=int, default=640)
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--autotune", action="store_true")
-ap.add_argument("--precision", choices=["fp16", "fp32", "int8"], default="fp16")
+ap.add_argument("--precision", choices=["fp16", "fp32", "int8", "strict"], default="fp16")
 a = ap.parse_args()
 
 from unina_yolo_dla_amd import export
 from unina_yolo_dla_amd.engine import calibrate_amax
 g = u.graph.Graph(in_h=a.size, in_w=a.size)
 sd = u.synth.make_state_dict(7, g)
-prec = {"fp32": export.FP32, "int8": export.INT8}.get(a.precision, export.FP16)
+prec = {"fp32": export.FP32, "int8": export.INT8, "strict": export.STRICT}.get(a.precision, export.FP16)
 amax = calibrate_amax(sd, g, [u.rng.frame(5000 + i, a.size, a.size) for i in range(8)]) if a.precision == "int8" else None
 e = Engine.from_state_dict(sd, g, precision=prec, amax=amax)
 x = torch.from_numpy(u.rng.frame(1234, a.size, a.size)).cuda()

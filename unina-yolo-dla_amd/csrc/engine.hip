@@ -265,7 +265,7 @@ void find_fold_ops(unina_engine* e) {
     const PlannedOp& op = e->ops[i];
     if (op.d.kind != kOpConv || (e->fuse && op.fuse_role)) continue;
     const ConvParams& c = op.cp;
-    if (c.dtype != kF16 || c.ksize != 1 || c.stride != 1 || c.relu || c.res || c.nseg != 2 || (c.Cin & 31)) continue;
+    if ((c.dtype != kF16 && c.dtype != kS16) || c.ksize != 1 || c.stride != 1 || c.relu || c.res || c.nseg != 2 || (c.Cin & 31)) continue;
     for (int h = 0; h < 3; ++h) {
       const void* pc = e->bufs[e->out_buf[2 * h]].ptr;
       const void* pr = e->bufs[e->out_buf[2 * h + 1]].ptr;
@@ -1425,6 +1425,7 @@ int fill_post_params(unina_engine* e, PostParams* pp, float conf, float iou, flo
       if (e->fold_op[h] < 0) continue;
       const ConvParams& c = e->ops[e->fold_op[h]].cp;
       pp->h1[h] = c.src;
+      pp->h1_lo[h] = c.dtype == kS16 ? c.src_lo : 0;
       pp->h1_ld[h] = c.src_ld;
       pp->h1_c[h] = c.Cin;
       for (int k = 0; k < 2; ++k) {

@@ -333,6 +333,7 @@ struct PostParams {
   // the same MFMA / K order / bias add as the conv kernels (bit-identical logits), straight into the decode -- the fp32
   // planes of such a head are neither written nor read. h1[h] == nullptr: head h is read from its planes cls[h] / reg[h].
   const void* h1[3];         // hidden tensor of head h: fp16 NHWC
+  long long h1_lo[3];        // != 0: a split-fp16 tensor (STRICT engines): byte distance to its lo plane; w2 then holds (hi | lo) block pairs
   int h1_ld[3], h1_c[3];     // channels per pixel of that buffer; input channels of each output conv (multiple of 32)
   int h1_coff[3][2];         // channel offset of the cls / reg branch's input
   const unsigned char* w2[3][2];  // packed 1-KiB fragment blocks [1][C/32] (16 rows) of the cls / reg output conv

@@ -835,6 +835,28 @@ __global__ __launch_bounds__(kPost2Block) void post_decode_kernel(const PostPara
       pix = pix < ncell ? pix : ncell - 1;           // tail subtiles: any valid pixel (never decoded)
       const _Float16* x0 = h1 + (size_t)pix * ld + 8 * lq;
       dev::floatx4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      const long long xlo = p.h1_lo[h];
+      if (xlo) {   // STRICT engines (wave-uniform): split-fp16 hidden tensor and (hi | lo) weight block pairs, three MFMAs per k block
+        for (int kb0 = 0; kb0 < kblocks; kb0 += 4) {
+          dev::half8x2 av[2][4], bv[2][4];
+#pragma unroll
+          for (int br = 0; br < 2; ++br)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int kb = kb0 + k < kblocks ? kb0 + k : kblocks - 1;
+              const unsigned char* wa = p.w2[h][br] + slot + (size_t)kb * 2048;
+              const _Float16* xa = x0 + p.h1_coff[h][br] + kb * 32;
+              av[br][k] = dev::half8x2{*reinterpret_cast<const dev::half8*>(wa), *reinterpret_cast<const dev::half8*>(wa + 1024)};
+              bv[br][k] = dev::half8x2{*reinterpret_cast<const dev::half8*>(xa),
+                                       *reinterpret_cast<const dev::half8*>(reinterpret_cast<const unsigned char*>(xa) + xlo)};
+            }
+#pragma unroll
+          for (int br = 0; br < 2; ++br)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (kb0 + k < kblocks) acc[br] = dev::mfma_split(av[br][k], bv[br][k], acc[br]);
+        }
+      } else
       // every operand of up to 8 k blocks of BOTH branches is requested before the first MFMA waits for one: the hidden
       // tensor was written a launch ago by other CUs, each load is a trip to another XCD's side of the chip
       for (int kb0 = 0; kb0 < kblocks; kb0 += 8) {
