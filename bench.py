@@ -38,13 +38,42 @@ FLOPS_PER_FRAME = {640: 35_664_691_200, 1280: 142_658_764_800}
 # priced against the fp16 peak on ALGORITHMIC flops (the kernels execute 3 fp16 MFMAs per algorithmic one)
 PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "i8": 5000.0, "f16x2": 2500.0}
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")   # tools/pmc_traffic.sh (rocprofv3 --pmc passes) at HEAD
-N_FRAMES = 16            # distinct synthetic frames cycled through
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")   # tools/pmc_traffic.sh: {config key: {kernel: bytes}} from rocprofv3 --pmc passes
+N_FRAMES = 2048          # distinct synthetic frames in the stream (>= 2 000), generated on the device
+N_SEEDED = 16            # the first of them are the seeded host frames (seeds 1234..) every parity test uses
 IN_FLIGHT = int(os.environ.get("UNINA_IN_FLIGHT", "2"))   # engine handles per GPU = frames in flight
 GATHER_EVERY = 16        # frames per RCCL all-gather of detection slots
 GATHER_BANKS = 3         # slot banks of the ring (>= 2: the gather of one bank overlaps inference into the next)
 MIN_BLOCK_S = 0.5        # a timed --steps block shorter than this is repeated (median reported)
 MAX_REPEATS = 400
+
+
+def launcher_command(n_gpus, argv, port):
+    """The command that starts `n_gpus` ranks of this script on one node (one process per GPU, RCCL rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` without a launcher around it (no WORLD_SIZE in the environment): start the N ranks here, as
+    children, BEFORE anything in this process touches the GPU (a process that has initialised HIP must not be replaced or
+    forked), relay their output (rank 0 prints the JSON line) and return their exit status. Fails loudly when the node has
+    fewer than N GPUs instead of silently measuring one."""
+    import socket
+    import subprocess
+    import torch
+    backend = os.environ.get("UNINA_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()          # (does not initialise the runtime on this image)
+    if backend == "nccl" and have < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} needs {n_gpus} visible GPUs, this node has {have}; nothing was measured "
+              f"(UNINA_BENCH_BACKEND=gloo rehearses the N-rank control flow on one GPU)", file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(launcher_command(n_gpus, argv, port), env=env)
 
 
 def main():
@@ -67,6 +96,11 @@ def main():
     ap.add_argument("--tune-cache", default=os.environ.get("UNINA_TUNE_CACHE", ""), help="tactic cache file (JSON)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE')} ranks")
+
     if args.streams > 0:
         os.environ["UNINA_STREAMS"] = str(args.streams)
     import torch
@@ -87,7 +121,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    assert world == args.gpus, (world, args.gpus)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     S = args.size
@@ -107,7 +141,16 @@ def main():
     engines = [Engine(path, device=local) for _ in range(IN_FLIGHT)]
     os.unlink(path)
     streams = [torch.cuda.Stream(device=dev) for _ in range(IN_FLIGHT)]
-    frames = [torch.from_numpy(u.rng.frame(1234 + i + 100 * rank, S, S)).to(dev) for i in range(N_FRAMES)]
+    # the input stream: N_FRAMES distinct N(0,1) frames resident in HBM (10 GB at 640^2 of the 288). The first N_SEEDED are the
+    # package's seeded frames (rng.frame: what every test and the latency loop use), the rest come from a seeded device generator
+    n_frames = max(N_SEEDED, min(N_FRAMES, int(11e9 // (12 * S * S))))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + 100 * rank)
+    stream_buf = torch.empty((n_frames, 1, 3, S, S), dtype=torch.float32, device=dev)
+    stream_buf.normal_(generator=gen)
+    for i in range(N_SEEDED):
+        stream_buf[i].copy_(torch.from_numpy(u.rng.frame(1234 + i + 100 * rank, S, S)))
+    frames = [stream_buf[i] for i in range(n_frames)]
     slot_words = 8 + 8 * MAX_DETECTIONS
     results = torch.zeros((GATHER_EVERY, slot_words), dtype=torch.int32, device=dev)
     conf = (0.5 if S == 640 else 0.6) if args.variant == "A" else 0.75   # keeps the seeded synthetic heads under MAX_DETECTIONS
@@ -128,7 +171,7 @@ def main():
 
     def infer_into(i, k, slot):
         with torch.cuda.stream(streams[k]):
-            engines[k].infer_async(frames[i % N_FRAMES], conf, 0.45, 0.1, out=slot, stream=streams[k])
+            engines[k].infer_async(frames[i % n_frames], conf, 0.45, 0.1, out=slot, stream=streams[k])
 
     def run(n_frames):
         """n_frames frames, IN_FLIGHT of them overlapping on separate streams; N > 1: detections gathered with RCCL
@@ -181,7 +224,7 @@ def main():
         for i in range(20 + 100):
             torch.cuda.synchronize()
             a = time.perf_counter()
-            engines[0].infer_async(frames[i % N_FRAMES], conf, 0.45, 0.1, out=one[0])
+            engines[0].infer_async(frames[i % n_frames], conf, 0.45, 0.1, out=one[0])
             gather.gather_slots(one, out=allr)
             torch.cuda.synchronize()
             if i >= 20:
@@ -194,7 +237,7 @@ def main():
         lat = []
         e0 = engines[0]
         for i in range(20 + args.latency_frames):
-            f = frames[i % N_FRAMES]
+            f = frames[i % N_SEEDED]
             torch.cuda.synchronize()
             a = time.perf_counter()
             e0.infer(f, conf, 0.45, 0.1)
@@ -204,7 +247,7 @@ def main():
         # the same serial loop timed INSIDE the C ABI (unina_serial_latency): what a C / C++ caller of the drop-in library sees.
         # The ctypes call above adds ~12 us per frame of binding cost (argument conversion, record copy into a fresh array).
         torch.cuda.synchronize()
-        lat = e0.serial_latency(frames, 20 + args.latency_frames, conf, 0.45, 0.1)[20:]
+        lat = e0.serial_latency(frames[:N_SEEDED], 20 + args.latency_frames, conf, 0.45, 0.1)[20:]
 
         # ---- roofline of the dominant kernel: live HIP-event timing of every op on the launch stream ----
         ops = e0.profile_ops(iters=20)
@@ -229,7 +272,7 @@ def main():
             "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 3),
             "flops_per_launch": dom["flops"] / dom["launches"],
             "achieved": round(achieved_tf, 2), "peak": PEAK_TFLOPS[dname], "unit": "TFLOP/s",
-            "frac": round(achieved_tf / PEAK_TFLOPS[dname], 4), "traffic": pmc_traffic(dom_name),
+            "frac": round(achieved_tf / PEAK_TFLOPS[dname], 4), "traffic": pmc_traffic(f"{args.variant}:{args.precision}:{S}", dom_name),
             "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
             "algorithmic_gbs": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
             "sum_of_ops_ms": round(total_ms, 4), "post_process_ms": [round(post_ms[0], 4), round(post_ms[1], 4)],
@@ -272,6 +315,7 @@ def main():
             "vs_baseline": None, "dtype": dname, "data": "synthetic",
             "config": {"workload": f"unina-yolo-dla-m graph {args.variant} {args.precision}, batch=1, {S}x{S}, NMS on-GPU" + (" (BASELINE configs[1])" if args.variant == "A" and S == 640 and args.precision == "fp16" else ""),
                        "frames_in_flight_per_gpu": IN_FLIGHT, "parallelism": f"replica x{world}, RCCL all-gather of detection slots every {GATHER_EVERY} frames on a comm stream ({GATHER_BANKS} banks)" if world > 1 else "1 GPU",
+                       "distinct_frames": n_frames,
                        "thresholds": {"conf": conf, "iou": 0.45, "conformal_q": 0.1}, "detections_last_frame": n_det},
             "latency_ms": {"p50": round(float(np.percentile(lat, 50)), 4), "p99": round(float(np.percentile(lat, 99)), 4),
                            "mean": round(float(lat.mean()), 4), "frames": len(lat),
@@ -312,13 +356,17 @@ def _kernel_key(name: str):
     return fn, tuple(int(x) for x in re.findall(r"\d+", re.sub(r"\bf16\b|\bf32\b|\bi8\b", "", args)))
 
 
-def pmc_traffic(kernel: str):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary (FETCH_SIZE x2 + WRITE_SIZE,
-    MI355X_MICROARCH.md HBM section), or None. Names are matched on (function, leading template integers)."""
+def pmc_traffic(config: str, kernel: str):
+    """HBM-side bytes per launch of `kernel` IN THE CONFIGURATION `config` ("variant:precision:size") from the committed
+    rocprofv3 PMC summary (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section; tools/pmc_traffic.sh), or None when
+    that configuration was not profiled -- a kernel name alone does not identify the launch (the same instantiation runs on
+    other shapes in other configs). Names are matched on (function, leading template integers)."""
     try:
         with open(PMC_TRAFFIC) as f:
-            table = json.load(f)
+            table = json.load(f).get("configs", {}).get(config)
     except (OSError, ValueError):
+        return None
+    if not table:
         return None
     fn, nums = _kernel_key(kernel)
     for k, v in table.items():
@@ -340,20 +388,20 @@ def cpu_baseline(u, sd, S, conf, budget_s, variant="A"):
     ncpu = oracle.usable_cpus()          # affinity + cgroup quota, not the host's count
     x = u.rng.frame(1234, S, S)
 
-    def timed(threads, max_frames, seconds):
+    def timed(threads, max_frames, seconds, min_frames=1):
         def one():
             o = oracle.forward(osd, x, nthreads=threads, variant=variant)
             oracle.postprocess([o[n] for n in u.graph.OUTPUT_NAMES], conf, 0.45, 0.1)
         one()                                           # warm-up (scratch growth, thread pool)
         times = []
         t_end = time.perf_counter() + seconds
-        while len(times) < max_frames and (not times or time.perf_counter() < t_end):
+        while len(times) < max_frames and (len(times) < min_frames or time.perf_counter() < t_end):
             a = time.perf_counter()
             one()
             times.append(time.perf_counter() - a)
         return np.array(times)
 
-    one_core = timed(1, 3, 0.15 * budget_s)
+    one_core = timed(1, 10, 0.25 * budget_s, min_frames=10 if S <= 640 else 3)      # (~0.2 s per frame at 640^2)
     sweep = {}
     for t in sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 64)}):
         sweep[t] = timed(t, 5, 0.1 * budget_s)

@@ -38,6 +38,8 @@ def test_header_and_library_agree(lib):
     for name in declared:
         assert hasattr(lib, name), f"libunina_mi355.so does not export {name}"
     assert b"gfx950" in lib.unina_version()
+    from unina_yolo_dla_amd import build
+    assert lib.unina_version().endswith(b"src:" + build.source_hash().encode())   # built from THIS tree (build.py hashes csrc/ + include/)
 
 
 def test_reference_postprocess_symbols_present(lib):

@@ -66,7 +66,12 @@ def _frame(pkg, torch, seed, s):
 
 
 def test_library_is_the_hip_engine(eng64):
-    assert b"gfx950" in eng64.L.unina_version()
+    """The loaded binary is the HIP engine AND was built from the sources under test: unina_version() carries the hash of
+    csrc/ + include/ at build time (the .so travels to the GPU box as a file; nothing else ties it to the tree)."""
+    from unina_yolo_dla_amd import build
+    v = eng64.L.unina_version()
+    assert b"gfx950" in v
+    assert v.endswith(b"src:" + build.source_hash().encode()), (v, build.source_hash())
     assert len(eng64.op_infos()) == 52
 
 
