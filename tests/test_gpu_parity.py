@@ -446,30 +446,51 @@ def test_int8_engine_matches_integer_emulation_and_reports_drift(pkg, sd7, oracl
     finally:
         e.close()
     # ---- drift at the benchmark size (PARITY UNPINNED: the reference pins no quantised result and its quantisation
-    # library is absent; bounds = the measured drift of the chosen calibrator, profiles/r02/int8_drift_table.txt:
-    # histogram + mse, 97.6 % matched, median IoU 0.9934, median |dscore| 0.0067, head rms 3.4 % of std -- plus a margin) ----
+    # library is absent; bounds = the measured drift of the chosen calibrator, profiles/r03/int8_drift_table.txt, 8 frames:
+    # histogram + mse, 97.6 % matched, IoU median 0.9934 / p5 0.9871, |dscore| median 0.0067 / p95 0.022 / max 0.10, 5.5 % of
+    # the engine's detections without a partner, head rms 3.4 % of std -- plus a margin). The table also says what the tail IS:
+    # every matched pair below IoU 0.9 (11 of 3 677; the "IoU min 0.51") and 198 of the 208 partnerless detections carry a box
+    # that equals (IoU >= 0.97) some PRE-NMS oracle candidate of the class -- a keep / suppress decision inside a cluster of
+    # overlapping cells fell the other way because two scores swapped order; the geometry itself does not drift. Asserted below. ----
     frames = [pkg.rng.frame(5000 + i, 640, 640) for i in range(8)]
     amax = calibrate_amax(sd7, None, frames, method="mse")
     e = Engine.from_state_dict(sd7, precision=export.INT8, amax=amax)
     try:
-        x = pkg.rng.frame(1234, 640, 640)
-        heads = {k: v.copy() for k, v in e.forward(torch_cuda.from_numpy(x).cuda()).items()}   # (unina_infer computes the P3 / P4
-        got = e.infer(torch_cuda.from_numpy(x).cuda(), 0.5, 0.45, 0.1)                          # output convs inside the decode launch)
-        o = oracle_mod.forward(oracle_sd7, x)
-        want, _ = oracle_mod.postprocess([o[n] for n in pkg.graph.OUTPUT_NAMES], 0.5, 0.45, 0.1)
-        for n in pkg.graph.OUTPUT_NAMES:
-            err = float(np.sqrt(((heads[n] - o[n]) ** 2).mean()))
-            assert err < 0.08 * max(float(o[n].std()), 0.3), (n, err)
         from detcmp import iou_matrix
-        m = iou_matrix(got, want)
-        m = np.where(got["class_id"][:, None] == want["class_id"][None, :], m, 0.0)
-        j = m.argmax(1)
-        matched = m.max(1) > 0.5
-        print("INT8 drift: dets", len(got), "vs", len(want), "matched", int(matched.sum()),
-              "median IoU %.4f" % np.median(m.max(1)[matched]),
-              "median |dscore| %.4f" % np.median(np.abs(got["confidence"] - want["confidence"][j])[matched]))
-        assert matched.sum() >= 0.94 * len(want) and np.median(m.max(1)[matched]) > 0.985
-        assert np.median(np.abs(got["confidence"] - want["confidence"][j])[matched]) < 0.012
+        ious, dss, n_got, n_want, n_matched, n_low, n_low_flip, n_extra, n_extra_flip = [], [], 0, 0, 0, 0, 0, 0, 0
+        for seed in (1234, 1235, 1236):
+            x = pkg.rng.frame(seed, 640, 640)
+            heads = {k: v.copy() for k, v in e.forward(torch_cuda.from_numpy(x).cuda()).items()}   # (unina_infer computes the P3 / P4
+            got = e.infer(torch_cuda.from_numpy(x).cuda(), 0.5, 0.45, 0.1)                          # output convs inside the decode launch)
+            o = oracle_mod.forward(oracle_sd7, x)
+            want, _ = oracle_mod.postprocess([o[n] for n in pkg.graph.OUTPUT_NAMES], 0.5, 0.45, 0.1)
+            cand, _ = oracle_mod.postprocess([o[n] for n in pkg.graph.OUTPUT_NAMES], 0.45, 1.0, 0.1)    # every candidate, no suppression
+            for n in pkg.graph.OUTPUT_NAMES:
+                err = float(np.sqrt(((heads[n] - o[n]) ** 2).mean()))
+                assert err < 0.08 * max(float(o[n].std()), 0.3), (n, err)
+            m = iou_matrix(got, want)
+            m = np.where(got["class_id"][:, None] == want["class_id"][None, :], m, 0.0)
+            j = m.argmax(1)
+            matched = m.max(1) > 0.5
+            mc = iou_matrix(got, cand)
+            mc = np.where(got["class_id"][:, None] == cand["class_id"][None, :], mc, 0.0).max(1)
+            low = matched & (m.max(1) < 0.9)
+            ious += list(m.max(1)[matched]); dss += list(np.abs(got["confidence"] - want["confidence"][j])[matched])
+            n_got += len(got); n_want += len(want); n_matched += int(matched.sum())
+            n_low += int(low.sum()); n_low_flip += int((low & (mc >= 0.97)).sum())
+            n_extra += int((~matched).sum()); n_extra_flip += int(((~matched) & (mc >= 0.97)).sum())
+        ious, dss = np.array(ious), np.array(dss)
+        print("INT8 drift: dets", n_got, "vs", n_want, "matched", n_matched, "IoU median %.4f p5 %.4f min %.4f" % (np.median(ious), np.percentile(ious, 5), ious.min()),
+              "|dscore| median %.4f p95 %.4f max %.4f" % (np.median(dss), np.percentile(dss, 95), dss.max()),
+              "IoU<0.9:", n_low, "(flips:", n_low_flip, ") partnerless:", n_extra, "(flips:", n_extra_flip, ")")
+        assert n_matched >= 0.94 * n_want and np.median(ious) > 0.985
+        assert np.median(dss) < 0.012
+        # the tail, bounded: measured p5 0.9871, |dscore| p95 0.022 / max 0.10, partnerless 5.5 % of the oracle's count
+        assert np.percentile(ious, 5) > 0.975 and np.percentile(dss, 95) < 0.04 and dss.max() < 0.2
+        assert n_extra <= 0.10 * n_want and abs(n_got - n_want) <= 0.08 * n_want
+        # ... and explained: a poorly matched box is a cluster decision, not geometry (every one of them; >= 85 % of the partnerless)
+        assert n_low <= 0.01 * n_matched and n_low_flip == n_low, (n_low, n_low_flip)
+        assert n_extra_flip >= 0.85 * n_extra, (n_extra, n_extra_flip)
     finally:
         e.close()
 
