@@ -212,6 +212,11 @@ int unina_debug_dual_stamps(unina_engine_t *e, int op_index, long long *out16, h
 /* Debug: the same launch with every workgroup's start / end on the 100 MHz wall clock (out[2*i], out[2*i+1]); returns the
    grid size or a negative error code. */
 int unina_debug_dual_timeline(unina_engine_t* e, int op_index, long long* out, int cap, hipStream_t stream);
+/* Debug: the fused C3k2 block led by op `op_index` run once as a stamped twin (after the ops in front of it): out16[k] =
+ * shader-clock stamp of its mid workgroup after step k (0 entry, 1 patch landed, 2 pre-conv, 3 cv1|cv2, 4 b0.cv1, 5 b0.cv2,
+ * 6 b1.cv1, 7 last bottleneck, 8 cv3, 9 output stored, 10 tail conv, 11 drained), [14] / [15] = 100 MHz clock at end / entry.
+ * Only the 40x40-level blocks have twins (UNINA_ERR_HIP otherwise). */
+int unina_debug_block_stamps(unina_engine_t *e, int op_index, long long *out16, hipStream_t stream);
 
 /* Library/build identification: "unina_mi355 <version> gfx950". */
 const char *unina_version(void);

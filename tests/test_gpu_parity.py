@@ -158,6 +158,47 @@ def test_postprocess_exact_on_reference_heads(pkg, eng640, oracle_mod, torch_cud
     assert np.all(got["valid"] == 1) and np.all(got["_pad"] == 0)
 
 
+@pytest.mark.parametrize("case", ["all_equal", "untrained", "saturated", "two_values"])
+def test_postprocess_overflow_selection_on_degenerate_heads(pkg, eng640, oracle_mod, torch_cuda, case):
+    """More than MAX_DETECTIONS candidates whose confidences crowd into ONE histogram bin -- what an untrained network
+    produces (every logit ~ 0, all 33 600 cells pass 0.5): the selection must split the bin again
+    (by key, and once the keys are equal by enumeration index) and still return exactly the oracle's 1024 best, ties by
+    enumeration order."""
+    rng = np.random.default_rng(11)
+    heads = []
+    for s in (160, 80, 40):
+        if case == "all_equal":           # one confidence for every cell: the cut is decided by the enumeration index alone
+            cls = np.zeros((4, s, s), np.float32)
+            cls[1:] = -1.0
+        elif case == "untrained":         # logits ~ 0 +- 1e-3: half the frame inside one 1/4096-wide confidence bin
+            cls = rng.normal(0.0, 1e-3, (4, s, s)).astype(np.float32)
+        elif case == "saturated":         # confidences pile up at 1.0 (the last bin, its upper end)
+            cls = np.where(rng.random((4, s, s)) < 0.6, 30.0, rng.normal(12.0, 1.0, (4, s, s))).astype(np.float32)
+        else:                             # two distinct confidences, thousands of cells each
+            cls = np.full((4, s, s), -2.0, np.float32)
+            cls[0] = np.where(rng.random((s, s)) < 0.5, 0.25, 0.125).astype(np.float32)
+        # small boxes on a lattice: nothing overlaps, so the NMS keeps all 1024 and the comparison sees the selection itself
+        reg = np.full((4, s, s), 0.2, np.float32)
+        heads += [cls, reg]
+    for n, h in zip(pkg.graph.OUTPUT_NAMES, heads):
+        eng640.outputs[n].copy_(torch_cuda.from_numpy(h)[None])
+    thr = 0.5 if case != "two_values" else 0.52
+    got = eng640.postprocess(thr, 0.45, 0.0)
+    want, ncand = oracle_mod.postprocess(heads, thr, 0.45, 0.0)
+    assert ncand > 4000 and len(want) == 1024 and len(got) == 1024, (ncand, len(want), len(got))
+    np.testing.assert_allclose(np.sort(got["confidence"]), np.sort(want["confidence"]), atol=2e-7, rtol=0)
+    ka = np.lexsort((got["y2"], got["x2"], got["y1"], got["x1"], got["class_id"]))
+    kb = np.lexsort((want["y2"], want["x2"], want["y1"], want["x1"], want["class_id"]))
+    if case in ("all_equal", "two_values"):   # exact ties: the SAME cells must be chosen (enumeration order), in the same output order
+        for f in ("x1", "y1", "x2", "y2", "class_id"):
+            assert np.array_equal(got[f], want[f]), f
+    else:                                 # (an ulp of expf may move a cell across the cut: compare all but a handful)
+        a = set(zip(got["x1"][ka].tolist(), got["y1"][ka].tolist(), got["class_id"][ka].tolist()))
+        b = set(zip(want["x1"][kb].tolist(), want["y1"][kb].tolist(), want["class_id"][kb].tolist()))
+        assert len(a ^ b) <= 16, len(a ^ b)
+    assert np.all(np.diff(got["confidence"]) <= 0) and np.all(got["_pad"] == 0) and np.all(got["valid"] == 1)
+
+
 def test_postprocess_heavy_overlap_nms(pkg, eng640, oracle_mod, torch_cuda):
     """Synthetic heads where most candidates overlap (big boxes, two classes): exercises the suppression masks."""
     rng = np.random.default_rng(5)

@@ -11,7 +11,7 @@ e = Engine.from_state_dict(u.synth.make_state_dict(7))
 frames = [torch.from_numpy(u.rng.frame(1234 + i, 640, 640)).cuda() for i in range(4)]
 e.autotune(frames[0], iters=5)
 order = [7, 0, 3, 1, 2, 4, 8, 9, 5, 6]
-names = ["K1 start", "decode done(wg0)", "K2 start", "counts scanned(wg0)", "rows gathered(wg0)", "tiles done", "loaded", "lists", "scan", "output"]
+names = ["K1 start", "decode done(wg0)", "K2 start", "list length read(wg0)", "rows fetched(wg0)", "tiles done", "loaded", "lists", "scan", "output"]
 for conf in (0.5, 0.3, 0.05):
     rows = []
     for it in range(40):

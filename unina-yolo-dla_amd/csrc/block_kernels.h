@@ -48,8 +48,19 @@ struct C3k2Plan {
 // compiler's counted s_waitcnt vmcnt keeps D loads in flight across every step boundary.
 // E = EltH (fp16 engines and carve-outs) or EltI8 (INT8 engines: every tensor of the block is an int8 code image with
 // its per-tensor scale; the epilogues re-quantise exactly as the per-op kernels do, conv_igemm.hip conv_epilogue).
-template <int H_, int TH, int TW, int NB, int CIN, int NW, int D, int TAIL = 0, typename E = EltH, int CPRE = 0, int CX = CIN>
+template <int H_, int TH, int TW, int NB, int CIN, int NW, int D, int TAIL = 0, typename E = EltH, int CPRE = 0, int CX = CIN, bool STAMPS = false>
 __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, unsigned char* smem) {
+  // debug twin: shader-clock stamp k of the mid workgroup (0 entry, 1 patch + first weights landed, then one per step, the
+  // output store and the tail), slot 15 = the 100 MHz wall clock at entry, 14 at the end
+  auto stamp = [&](int k) {
+    if constexpr (STAMPS) {
+      if (p.stamps && bid == ((p.tiles_x * p.tiles_y) >> 1) && threadIdx.x == 0) {
+        p.stamps[k] = __builtin_amdgcn_s_memtime();
+        if (k == 0) p.stamps[15] = wall_clock64();
+      }
+    }
+  };
+  stamp(0);
   static_assert(NB == 1 || NB == 2, "bottleneck count");
   typedef C3k2Plan<H_, NB, CIN, NW, TAIL, E::KBLK, CPRE, CX> PL;
   constexpr int PRE = PL::PRE;
@@ -128,6 +139,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
 
 #endif
 
+  stamp(1);
   const Img Xi = Img{p.off_x, X.nch, X.sh, X.mask};
   const Img XRi = Img{p.off_xr, XR.nch, XR.sh, XR.mask};
   const Img Y = make_img(p.off_y, 2 * H_ / E::CH);   // a | b on R0
@@ -160,6 +172,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           const int r = sub * 16 + l15;
           if (r < P0) store4<E, CX>(smem + img_at<E>(Xi, r, n), act_relu<E, CX>(acc, c0, n), c0, n, lds_lo);
         }, lds_lo);
+    stamp(2);
   }
 
   // ---- step 0: a | b = ReLU(W12 x + b12) on R0 --------------------------------------------------------------------
@@ -175,6 +188,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
         if (r < P0) store4<E, 2 * H_>(smem + img_at<E>(Y, r, n), act_relu<E, 2 * H_>(acc, CST(0), n), CST(0), n, lds_lo);
       });
 
+  stamp(3);
   // ---- bottleneck 0 -----------------------------------------------------------------------------------------------
   // t = ReLU(Wb1 a + b) on R0, forced to 0 outside the image (zero padding of the 3x3 that follows)
   run_step(STEP(1, P0),
@@ -190,6 +204,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
         if (!in_image(ty0 - NB + ry, tx0 - NB + rx)) v = floatx4{0.f, 0.f, 0.f, 0.f};
         store4<E, H_>(smem + img_at<E>(T, r, n), v, CST(1), n, lds_lo);
       });
+  stamp(4);
   if constexpr (NB == 1) {
     // u = ReLU(3x3(t) + b) + a on the tile
     run_step(STEP(2, PT),
@@ -224,6 +239,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           const floatx4 v = add_res<E>(act_relu<E, H_>(acc, CST(2), n), smem, Y, (py + 1) * R0W + px + 1, n, p.res_scale[0], lds_lo);
           store4<E, H_>(smem + img_at<E>(U1, pp, n), v, CST(2), n, lds_lo);
         });
+    stamp(5);
     // ---- bottleneck 1 ---------------------------------------------------------------------------------------------
     // t2 = ReLU(Wb1' u1 + b) on R1, 0 outside the image
     run_step(STEP(3, P1),
@@ -239,6 +255,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           if (!in_image(ty0 - 1 + ry, tx0 - 1 + rx)) v = floatx4{0.f, 0.f, 0.f, 0.f};
           store4<E, H_>(smem + img_at<E>(T, r, n), v, CST(3), n, lds_lo);
         });
+    stamp(6);
     // u2 = ReLU(3x3(t2) + b) + u1 on the tile
     run_step(STEP(4, PT),
         [&](int sub, auto kc) {
@@ -257,6 +274,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
         });
   }
 
+  stamp(7);
   // ---- last step: y = ReLU(W3 [u | b] + b3) on the tile -> staging image (linear rows) -> HBM ----------------------
   constexpr int ROWB = 2 * H_ * ESZ + 16;  // staged output row: 2h elements + 16 bytes of padding (bank spread)
   unsigned char* stage = smem + p.off_stage;
@@ -294,6 +312,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
     if (!p.dst_q) return;
   }
 #endif
+  stamp(8);
   typedef float vec16 __attribute__((ext_vector_type(4)));  // 16 opaque bytes
   constexpr int CPR = 2 * H_ * ESZ / 16;                    // 16-byte chunks per output pixel
   unsigned char* dst = static_cast<unsigned char*>(p.dst);
@@ -320,6 +339,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
     }
   }
 
+  stamp(9);
   if constexpr (TAIL) {
     // ---- tail: lateral 1x1 (model.py:256,259: ConvBlock 2h -> h) on the block's output, still in the staging image,
     //      then nearest x2 upsample (model.py:145-147) in the store: each pixel's h channels go to its 2x2 block ----
@@ -340,6 +360,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           if (pp >= PT) return;
           store4<TE, H_>(tout + pp * ROWT + n * TSZ, act_relu<E, H_>(acc, CST(S4), n), CST(S4), n, lds_lo);
         });
+    stamp(10);
     constexpr int CPT = H_ * TSZ / 16;
     unsigned char* dst2 = static_cast<unsigned char*>(p.dst2);
     if constexpr (TAIL == 1 || TAIL == 3) {
@@ -367,6 +388,11 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
               *reinterpret_cast<const vec16*>(tout + pl * lds_lo + pp * ROWT + ch * 16);
       }
     }
+  }
+  if constexpr (STAMPS) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(11);
+    if (p.stamps && bid == ((p.tiles_x * p.tiles_y) >> 1) && threadIdx.x == 0) p.stamps[14] = wall_clock64();
   }
 #undef STEP
 #undef CST

@@ -10,6 +10,7 @@
 // (tests/test_gpu_parity.py block-fusion tests). fp16 and int8 (EltI8) forms.
 #include "block_kernels.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace unina {

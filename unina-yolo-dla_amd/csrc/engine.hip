@@ -119,7 +119,7 @@ struct unina_engine {
   hipGraphExec_t fexec = nullptr;
   hipGraphNode_t stem_node = nullptr, post_node = nullptr, post_node2 = nullptr;
   bool post_split = true;            // post-process as two launches (UNINA_POST_SPLIT=0: everything in one workgroup)
-  int post_mode = 2;                 // 2: sort-free two-launch form (default); 1: two launches with the bitonic sort (UNINA_POST_V1=1); 0: one launch
+  int post_mode = 2;                 // 2: the two-launch form (compact candidate list, sort-free NMS); 0 (UNINA_POST_SPLIT=0): everything in one launch
   bool fold_heads = true;            // full-frame graph: the heads' output convs run inside the decode launch (UNINA_POST_FOLD=0: off)
   int fold_op[3] = {-1, -1, -1};     // per head: the output-conv op the decode launch absorbs (-1: the head is read from its planes)
   int stem_op = -1;
@@ -1616,7 +1616,6 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
   if (const char* ns = getenv("UNINA_STREAMS")) e->n_streams = atoi(ns) > 0 ? atoi(ns) : 1;
   if (const char* fg = getenv("UNINA_FULL_GRAPH")) e->full_graph = fg[0] != '0';
   if (const char* ps = getenv("UNINA_POST_SPLIT")) e->post_split = ps[0] != '0';
-  if (const char* pv = getenv("UNINA_POST_V1")) e->post_mode = pv[0] == '1' ? 1 : 2;
   if (const char* pf = getenv("UNINA_POST_FOLD")) e->fold_heads = pf[0] != '0';
   e->plan_dirty = true;
   *out = e;
@@ -1895,6 +1894,28 @@ int unina_debug_dual_stamps(unina_engine_t* e, int op_index, long long* out16, h
   HIPCHK(e, conv_dual_launch(op.dual_kind, pa, pb, stream));
   HIPCHK(e, hipStreamSynchronize(stream));
   HIPCHK(e, hipMemcpy(out16, pa.stamps, sizeof(long long) * 16, hipMemcpyDeviceToHost));
+  return UNINA_OK;
+}
+
+// Debug: the fused C3k2 block led by op `op_index`, launched once as its stamped twin right after the ops in front of it (cold
+// weights, as in a frame): out16[k] = shader-clock stamp of the mid workgroup after step k (block_kernels.h), [14] / [15] =
+// the 100 MHz wall clock at its end / entry. Only the 40^2 blocks have twins.
+int unina_debug_block_stamps(unina_engine_t* e, int op_index, long long* out16, hipStream_t stream) {
+  if (!e || !out16 || op_index < 0 || op_index >= (int)e->ops.size()) return UNINA_ERR_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (e->plan_dirty) {
+    int rc = plan(e);
+    if (rc != UNINA_OK) return rc;
+  }
+  const PlannedOp& op = e->ops[op_index];
+  if (!e->fuse || op.fuse_role != 1 || op.fuse_kind != 1) return fail(e, UNINA_ERR_ARG, "op %d does not lead a fused C3k2 block", op_index);
+  for (int i = 0; i < op_index; ++i) HIPCHK(e, launch_op(e, (size_t)i, stream));
+  C3k2Params p = op.fp;
+  p.stamps = reinterpret_cast<long long*>(e->d_result->pad_stamps);
+  HIPCHK(e, hipMemsetAsync(p.stamps, 0, sizeof(long long) * 16, stream));
+  HIPCHK(e, c3k2_launch_stamped(p, stream));
+  HIPCHK(e, hipStreamSynchronize(stream));
+  HIPCHK(e, hipMemcpy(out16, p.stamps, sizeof(long long) * 16, hipMemcpyDeviceToHost));
   return UNINA_OK;
 }
 

@@ -132,6 +132,7 @@ struct C3k2Params {
                                  // 2: a plain 1x1 ConvBlock 2h -> h; 3: as 1, int8 block whose lateral writes an fp16 tensor
   void* dst2;                    // tail output (2H x 2W pixels), channel offset applied
   int dst2_ld;
+  long long* stamps;             // debug (stamped twin kernels only): s_memtime of the mid workgroup after every step (nullptr = off)
   // filled by c3k2_layout():
   int n_bias;
   int tiles_x, tiles_y;
@@ -152,6 +153,7 @@ bool c3k2_supported(int hid, int nb, int cin, int tail = 0, int dtype = kF16, in
 bool c3k2_pack(int hid, int nb, int cin, int tail, const C3k2Conv* convs, std::vector<unsigned char>* stream, std::vector<float>* bias,
                int dtype = kF16, int cpre = 0, int cx = 0);   // with cpre: convs[0] is the pre-conv (cpre -> cx channels)
 hipError_t c3k2_launch(const C3k2Params& p, hipStream_t stream);
+hipError_t c3k2_launch_stamped(const C3k2Params& p, hipStream_t stream);   // debug twin with per-step stamps (p.stamps); InvalidValue if the class has none
 const char* c3k2_kernel_name(int hid, int nb, int cin, int tail = 0, int dtype = kF16, int cpre = 0, int cx = 0);
 int c3k2_block_threads(int hid, int nb, int cin, int tail = 0, int dtype = kF16, int cpre = 0, int cx = 0);
 
@@ -302,8 +304,8 @@ struct PostParams {
   int num_classes;
   float conf_thr, iou_thr, conformal_q;
   // workspace (engine-owned)
-  GpuDetection* cand;        // [nblocks][kPostBlock] per-block candidate segments
-  int* block_count;          // [nblocks]
+  GpuDetection* cand;        // mode 0: [nblocks][kPostBlock] per-block candidate segments; mode 2: the compact candidate list
+  int* block_count;          // mode 0: [nblocks]
   unsigned int* ticket;      // arrival counter (zero at rest)
   // outputs
   GpuDetection* out;         // [MAX_DETECTIONS]
@@ -312,23 +314,23 @@ struct PostParams {
   long long* stamps;         // optional debug: 8 wall_clock64 stamps of the last block's phases (nullptr = off)
   unsigned int* done_flag;   // optional (pinned host memory): receives done_value, system-scope release, after every output store
   unsigned int done_value;
-  // two-launch form (engine): launch 1 ends with the sorted candidates in this workspace, launch 2 builds the
-  // suppression-mask tiles on many CUs and its last block scans + compacts. All nullptr = everything in launch 1.
-  float4* ws_box;            // [MAX_DETECTIONS] sorted boxes
-  float2* ws_cc;             // [MAX_DETECTIONS] sorted (confidence, class bits)
-  int* ws_n;                 // number of sorted candidates
-  unsigned long long* ws_mask;    // upper-triangular 64x64-bit suppression tiles
-  unsigned long long* ws_tilenz;  // per tile: rows with a non-empty mask
+  // two-launch form (the engine's, mode 2; postprocess.hip): launch 1 = decode on many 256-thread workgroups, survivors appended to
+  // ONE compact candidate list (`cand`; a run per workgroup reserved with one atomic on ws_total; a record's `_pad` carries its
+  // enumeration index P2 -> P3 -> P4, row-major), confidences counted into ws_hist; launch 2 = one workgroup per 64x64 tile of
+  // the candidate pairs computes the directional suppression bits (both directions) AND every candidate's rank (number of
+  // candidates with a larger (confidence, ~enumeration index) key: a stable sort order without sorting), its last arriver runs
+  // the greedy scan in rank order (one wave per class residue) and writes the compacted output. Same results as mode 0.
+  int mode;                  // 0: everything in one launch (one workgroup gathers, sorts, scans); 2: the two-launch form
+  float4* ws_box;            // [MAX_DETECTIONS] boxes of the (selected) candidates, by list position
+  float2* ws_cc;             // [MAX_DETECTIONS] (confidence, class | enumeration index << 8)
   unsigned int* ticket2;     // arrival counter of launch 2 (zero at rest)
-  // ---- sort-free form (mode 2, the default; postprocess.hip "v2"): launch 1 = decode on many 256-thread workgroups, the
-  // last arriver gathers the candidates in ENUMERATION order; launch 2 = one workgroup per 64x64 tile of the candidate
-  // pairs computes the directional suppression bits (both directions) AND every candidate's rank (number of candidates
-  // with a larger (confidence, ~position) key: a stable sort order without sorting), its last arriver runs the greedy scan
-  // in rank order (one wave per class residue) and writes the compacted output. Same results as the other forms.
-  int mode;                  // 0: one launch; 1: two launches with a bitonic sort (v1); 2: sort-free (v2)
-  int* ws_rank;              // [MAX_DETECTIONS] rank of each candidate (zeroed by launch 1)
-  unsigned long long* ws_full;    // [MAX_DETECTIONS][16] suppression bits, row = suppressor, bit = suppressed (enumeration positions)
-  unsigned long long* ws_rownz;   // [16] rows with a non-empty mask (zeroed by launch 1)
+  int* ws_total;             // candidates in the list (zero at rest: launch 2's last arriver resets it)
+  int* ws_hist;              // [4096] histogram of the candidates' confidences, bin = floor(conf * 4096) (zero at rest)
+  uint2* ws_ke;              // [list] (confidence bit pattern, enumeration index), dense: what the > MAX_DETECTIONS selection sweeps
+  int eoff[3];               // enumeration index of each head's first cell (post_plan_blocks)
+  int* ws_rank;              // [MAX_DETECTIONS] rank of each candidate (zero at rest)
+  unsigned long long* ws_full;    // [MAX_DETECTIONS][16] suppression bits, row = suppressor, bit = suppressed (list positions)
+  unsigned long long* ws_rownz;   // [16] rows with a non-empty mask (zero at rest)
   // fold: the head's output convs (model.py:292,299: Conv2d 1x1 + bias on the hidden tensor) computed INSIDE launch 1 with
   // the same MFMA / K order / bias add as the conv kernels (bit-identical logits), straight into the decode -- the fp32
   // planes of such a head are neither written nor read. h1[h] == nullptr: head h is read from its planes cls[h] / reg[h].

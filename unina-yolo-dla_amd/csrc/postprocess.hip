@@ -498,22 +498,6 @@ __global__ __launch_bounds__(kPostBlock) void postprocess_kernel(const PostParam
   __syncthreads();
 
   if (p.stamps && tid == 0) p.stamps[2] = wall_clock64();
-  if (p.ws_box) {
-    // two-launch form: publish the sorted candidates; nms_tiles_kernel (next launch) does the rest on many CUs
-    rank_sort_records(s, n);
-    const int n64 = (n + 63) & ~63;
-    if (tid < n64) {
-      p.ws_box[tid] = s.box[tid];
-      p.ws_cc[tid] = s.cc[tid];
-    }
-    if (tid == 0) {
-      *p.ws_n = n;
-      if (p.out_candidates) *p.out_candidates = total;
-      __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-      if (p.stamps) p.stamps[3] = wall_clock64();
-    }
-    return;
-  }
   sort_and_nms(s, n, p.iou_thr, p.stamps);
 
   // ---- compaction + output ----
@@ -530,153 +514,24 @@ __global__ __launch_bounds__(kPostBlock) void postprocess_kernel(const PostParam
   signal_done(p, tid);
 }
 
-// ---- launch 2 of the two-launch form: suppression-mask tiles on many CUs, then scan + compaction by the last block ----
-// The one-block form spends ~27 of its ~42 us (n ~ 500) building the n^2/2 pair bitmap on ONE CU (VALU-bound). Here
-// every upper-triangular 64x64 tile is its own 256-thread workgroup (wave v: columns 16v..16v+15, lane = row); the
-// workgroup that draws the last arrival ticket (same release/acquire hand-off as launch 1) loads the tiles, runs the
-// sequential greedy scan on one wave and writes the compacted output. Pair arithmetic and order are unchanged.
-constexpr int kTileThreads = 256;
 constexpr int kMaxTiles = kWords * (kWords + 1) / 2;
-struct Smem2 {
-  float4 rbox[64], cbox[64];
-  float2 rcc[64], ccc[64];
-  unsigned short piece[64][4];
-  unsigned long long mask[kTriWords];
-  unsigned long long rownz[kWords];
-  unsigned long long removed[kWords];
-  unsigned long long tilenz[kMaxTiles];
-  int wave_cnt[4];
-  int is_last;
-};
-
-__global__ __launch_bounds__(kTileThreads) void nms_tiles_kernel(const PostParams p) {
-  Smem2& s = *reinterpret_cast<Smem2*>(post_smem);
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int n = *p.ws_n;
-  const int nw = (n + 63) >> 6;
-  const int ntiles = nw * (nw + 1) / 2;
-  const int t = blockIdx.x;
-  if (t < ntiles) {
-    int c = 0, rem = t;  // tile t -> (chunk row c, word w >= c)
-    while (rem >= nw - c) {
-      rem -= nw - c;
-      ++c;
-    }
-    const int w = c + rem;
-    if (tid < 64) {           // launch 1 padded the sorted arrays to a multiple of 64
-      s.rbox[tid] = p.ws_box[c * 64 + tid];
-      s.rcc[tid] = p.ws_cc[c * 64 + tid];
-    } else if (tid < 128) {
-      s.cbox[tid - 64] = p.ws_box[w * 64 + tid - 64];
-      s.ccc[tid - 64] = p.ws_cc[w * 64 + tid - 64];
-    }
-    __syncthreads();
-    const int i = c * 64 + lane;
-    const bool row_ok = i < n;
-    const float4 a = s.rbox[lane];
-    const float2 ac = s.rcc[lane];
-    const float area_a = (a.z - a.x) * (a.w - a.y);
-    unsigned int bits = 0u;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int col = wv * 16 + u;
-      const int j = w * 64 + col;
-      if (suppresses(a, ac, area_a, s.cbox[col], s.ccc[col], row_ok && j > i, p.iou_thr)) bits |= 1u << u;
-    }
-    s.piece[lane][wv] = (unsigned short)bits;
-    __syncthreads();
-    if (tid < 64) {
-      const unsigned long long word = (unsigned long long)s.piece[tid][0] | ((unsigned long long)s.piece[tid][1] << 16) |
-                                      ((unsigned long long)s.piece[tid][2] << 32) | ((unsigned long long)s.piece[tid][3] << 48);
-      p.ws_mask[tri_off(c, nw) + tid * (nw - c) + (w - c)] = word;
-      const unsigned long long nz = __ballot(word != 0ull);
-      if (tid == 0) p.ws_tilenz[t] = nz;
-    }
-  }
-  if (!arrive_and_check_last(p.ticket2, &s.is_last)) return;
-  if (p.stamps && tid == 0) p.stamps[4] = wall_clock64();
-
-  // ---- last block: scan + compaction + output ----
-  {  // tiles -> LDS, 8 independent loads in flight per thread (one load per trip costs an L2 round trip each)
-    constexpr int B = 8;
-    const int total = 64 * ntiles;
-    for (int k0 = tid; k0 < total; k0 += kTileThreads * B) {
-      unsigned long long v[B];
-#pragma unroll
-      for (int b = 0; b < B; ++b) {
-        const int k = k0 + b * kTileThreads;
-        v[b] = k < total ? p.ws_mask[k] : 0ull;
-      }
-#pragma unroll
-      for (int b = 0; b < B; ++b) {
-        const int k = k0 + b * kTileThreads;
-        if (k < total) s.mask[k] = v[b];
-      }
-    }
-  }
-  if (tid < ntiles) s.tilenz[tid] = p.ws_tilenz[tid];   // ntiles <= kMaxTiles = 136 <= kTileThreads: ONE round trip (the
-  __syncthreads();                                       // per-row OR below was up to nw dependent global loads)
-  if (tid < kWords) {
-    unsigned long long nz = 0ull;
-    if (tid < nw)
-      for (int w = tid; w < nw; ++w) nz |= s.tilenz[(tid * nw - (tid * (tid - 1)) / 2) + (w - tid)];
-    s.rownz[tid] = nz;
-  }
-  __syncthreads();
-  if (tid < 64) greedy_scan(s.mask, s.rownz, s.removed, nw, lane);
-  __syncthreads();
-  if (p.stamps && tid == 0) p.stamps[5] = wall_clock64();
-  int base = 0;
-  for (int i0 = 0; i0 < n; i0 += kTileThreads) {
-    const int i = i0 + tid;
-    const bool kept = i < n && !((s.removed[i >> 6] >> (i & 63)) & 1ull);
-    const unsigned long long b = __ballot(kept);
-    __syncthreads();  // protect wave_cnt from the previous round
-    if (lane == 0) s.wave_cnt[wv] = __popcll(b);
-    __syncthreads();
-    int off = 0, tot = 0;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      if (v < wv) off += s.wave_cnt[v];
-      tot += s.wave_cnt[v];
-    }
-    if (kept) {
-      const float4 bx = p.ws_box[i];
-      const float2 cc = p.ws_cc[i];
-      GpuDetection d;
-      d.x1 = bx.x; d.y1 = bx.y; d.x2 = bx.z; d.y2 = bx.w;
-      d.confidence = cc.x;
-      d.class_id = __float_as_int(cc.y);
-      d.valid = 1;
-      d._pad = 0;
-      p.out[base + off + __popcll(b & ((1ull << lane) - 1ull))] = d;
-    }
-    base += tot;
-  }
-  if (tid == 0) {
-    *p.out_count = base;
-    __hip_atomic_store(p.ticket2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-    if (p.stamps) p.stamps[6] = wall_clock64();
-  }
-  signal_done(p, tid);
-}
 
 
-// ================================================================================================ v2: sort-free, folded
+// ================================================================================================ the frame's form: sort-free, folded
 // Launch 1 (post_decode_kernel, 256-thread workgroups, a few hundred of them): every workgroup owns a run of consecutive
 // cells of ONE head. A head is read from its fp32 planes, or -- fold -- its output convs are computed here: wave = 16-pixel
 // subtile, B fragments (16 bytes of the NHWC hidden tensor per lane) and A fragments (the exporter's packed 1-KiB blocks)
 // straight from global memory into v_mfma_f32_16x16x32_f16, k blocks in ascending order from a zero accumulator, `acc + bias`
 // in fp32: the operations, operands and order of conv_glds / conv_epilogue, so the logits are the per-op table's bit for
-// bit; they go through LDS to the thread that decodes the cell. Survivors are appended, in order, to the workgroup's
-// segment, the count to a table -- and that is all: no ticket, no gather, no sort (the one-workgroup gather + bitonic
-// sort behind an arrival ticket were 9 of the older form's 31 us).
-// Launch 2 (post_nms_kernel, 512 threads): one workgroup per 64x64 tile of candidate pairs (I <= J). Each scans the count
-// table for itself (the enumeration order P2 -> P3 -> P4, row-major, is the order of the segments), fetches its 64 rows and
-// 64 columns by binary search (top-1024 by radix select when more cells passed), and besides the overlap test compares
-// the (confidence, ~position) keys of every pair, so a tile contributes (a) the DIRECTIONAL suppression bits of both
+// bit; they go through LDS to the thread that decodes the cell. Survivors are appended to ONE compact candidate list (a run per
+// workgroup, reserved with one atomic; each record carries its enumeration index), their confidences counted into a 4096-bin
+// histogram -- and that is all: no ticket, no gather, no sort.
+// Launch 2 (post_nms_kernel, 512 threads): one workgroup per 64x64 tile of candidate pairs (I <= J). Each reads the list
+// length and fetches its 64 rows and 64 columns straight from the list (when more than 1024 cells passed: the 1024 best by
+// histogram-guided selection, see the overflow branch), and besides the overlap test compares
+// the (confidence, ~enumeration index) keys of every pair, so a tile contributes (a) the DIRECTIONAL suppression bits of both
 // orientations -- rows of tile (I,J) per lane, rows of tile (J,I) as wave ballots -- into a full n x n bit matrix
-// indexed by enumeration position, and (b) to every candidate's RANK = number of candidates with a larger key,
+// indexed by list position, and (b) to every candidate's RANK = number of candidates with a larger key,
 // accumulated with integer atomics: the stable sort order falls out of the pair loop that the NMS needs anyway.
 // The last arriver (one ticket per TILE, not per grid slot) inverts the ranks into a permutation, and because a row only
 // ever marks candidates of strictly lower confidence (= processed later) and of its own class, the greedy scan splits by
@@ -757,54 +612,17 @@ __device__ __forceinline__ int block_rank2(bool flag, int* wave_cnt /*LDS, kW2*/
   return off + rank;
 }
 
-__device__ __forceinline__ int scan_block_counts2(const int* block_count, int nblocks, int* scan /*LDS, nblocks + 1*/) {
-  const int tid = threadIdx.x;
-  // every count in ONE round trip (a serial walk over 64-entry chunks paid an L2 latency per chunk), then a scan in LDS
-  int v[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int i = tid + q * kT2;
-    v[q] = i < nblocks ? __hip_atomic_load(block_count + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int i = tid + q * kT2;
-    if (i < nblocks) scan[i] = v[q];
-  }
-  __syncthreads();
-  if (tid < 64) {
-    int carry = 0;
-    for (int base = 0; base < nblocks; base += 64) {
-      const int i = base + tid;
-      const int c = i < nblocks ? scan[i] : 0;
-      int incl = c;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off);
-        if (tid >= off) incl += t;
-      }
-      if (i < nblocks) scan[i] = carry + incl - c;
-      carry += __shfl(incl, 63);
-    }
-    if (tid == 0) scan[nblocks] = carry;
-  }
-  __syncthreads();
-  return scan[nblocks];
+// confidence -> bin of launch 1's histogram (4096 linear bins; x 4096 is exact in binary floating point, so bin T is
+// exactly the confidences in [T / 4096, (T + 1) / 4096))
+constexpr int kBins = 4096;
+__device__ __forceinline__ int conf_bin(float c) {
+  const int b = (int)(c * (float)kBins);
+  return b > kBins - 1 ? kBins - 1 : b;
 }
-
-__device__ __forceinline__ const GpuDetection* cand_at2(const GpuDetection* cand, const int* scan, int nblocks, int e) {
-  int lo = 0, hi = nblocks - 1;  // largest b with scan[b] <= e
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (scan[mid] <= e) lo = mid; else hi = mid - 1;
-  }
-  return cand + (size_t)lo * kT2 + (e - scan[lo]);
-}
-
-__device__ __forceinline__ void put_ws(const PostParams& p, int pos, const GpuDetection* c) {
-  p.ws_box[pos] = make_float4(c->x1, c->y1, c->x2, c->y2);
-  p.ws_cc[pos] = make_float2(c->confidence, __int_as_float(c->class_id));
-}
+// (class id | enumeration index << 8) travels in the second float of a candidate's (confidence, class) pair
+__device__ __forceinline__ float pack_ce(int class_id, int eidx) { return __int_as_float((class_id & 0xFF) | (eidx << 8)); }
+__device__ __forceinline__ int ce_class(float y) { return (int)(signed char)(__float_as_int(y) & 0xFF); }
+__device__ __forceinline__ unsigned ce_eidx(float y) { return (unsigned)__float_as_int(y) >> 8; }
 
 }  // namespace
 
@@ -889,10 +707,22 @@ __global__ __launch_bounds__(kPost2Block) void post_decode_kernel(const PostPara
                          p.num_classes, p.conf_thr, p.conformal_q, idx, &d);
   }
   {
+    // survivors go to ONE compact candidate list: the workgroup reserves a run of it with a single atomic (the runs land in
+    // arrival order -- the order is immaterial, every later decision is keyed by (confidence, enumeration index), which each
+    // record carries). No per-workgroup count table, no scan, no search in launch 2. Next to the records: the confidence bit
+    // pattern and the enumeration index as dense arrays, and a 4096-bin histogram of the confidences -- what launch 2 needs to
+    // find the kMaxDet best of MORE than kMaxDet candidates in one or two coalesced sweeps.
     int total;
     const int pos = block_rank2(pass, s.wave_cnt, &total);
-    if (pass) p.cand[(size_t)b * kT2 + pos] = d;
-    if (tid == 0) p.block_count[b] = total;
+    if (tid == 0) s.misc[0] = total ? __hip_atomic_fetch_add(p.ws_total, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    __syncthreads();
+    if (pass) {
+      const int at = s.misc[0] + pos;
+      d._pad = p.eoff[h] + idx;                       // enumeration index (P2 -> P3 -> P4, row-major): the tie-break of equal confidences
+      p.cand[at] = d;
+      p.ws_ke[at] = make_uint2(__float_as_uint(d.confidence), (unsigned)d._pad);
+      atomicAdd(&p.ws_hist[conf_bin(d.confidence)], 1);
+    }
   }
   if (p.stamps && tid == 0 && b == 0) p.stamps[0] = wall_clock64();
 }
@@ -902,9 +732,8 @@ __global__ __launch_bounds__(kTN) void post_nms_kernel(const PostParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int t = blockIdx.x;
   if (p.stamps && tid == 0 && t == 0) p.stamps[3] = wall_clock64();
-  // every workgroup works out the candidate list for itself: exclusive scan of launch 1's per-workgroup counts
-  const int nblocks = p.bstart[3];
-  const int total = scan_block_counts2(p.block_count, nblocks, s.scan);
+  // launch 1 left ONE compact candidate list and its length: no count table to scan, no search per row
+  const int total = __hip_atomic_load(p.ws_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (p.stamps && tid == 0 && t == 0) p.stamps[1] = wall_clock64();
   const int n = total < kMaxDet ? total : kMaxDet;
   const int nw = (n + 63) >> 6;
@@ -917,7 +746,7 @@ __global__ __launch_bounds__(kTN) void post_nms_kernel(const PostParams p) {
       ++c;
     }
     const int w = c + rem;
-    if (tid < 128) {   // rows 64c.. (tid < 64), columns 64w.. : dummies (class -1, empty box) past the end
+    if (tid < 128) {   // rows 64c.. (tid < 64), columns 64w.. : dummies (class -1, empty box, the largest enumeration index) past the end
       const int k = tid & 63;
       if (tid < 64) {
         s.rbox[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -927,88 +756,196 @@ __global__ __launch_bounds__(kTN) void post_nms_kernel(const PostParams p) {
         s.ccc[k] = make_float2(0.f, __int_as_float(-1));
       }
     }
+    auto fetch = [&](int e, int pos) {   // list entry e is candidate `pos` of the (selected) list: into this tile's rows / columns
+      const GpuDetection* cd = p.cand + e;
+      const float4 bx = make_float4(cd->x1, cd->y1, cd->x2, cd->y2);
+      const float2 cf = make_float2(cd->confidence, pack_ce(cd->class_id, cd->_pad));
+      if ((pos >> 6) == c) { s.rbox[pos & 63] = bx; s.rcc[pos & 63] = cf; }
+      if ((pos >> 6) == w) { s.cbox[pos & 63] = bx; s.ccc[pos & 63] = cf; }
+    };
     if (total <= kMaxDet) {
       if (tid < 128) {
-        const int k = tid & 63, e = (tid < 64 ? c : w) * 64 + k;
-        if (e < n) {
-          const GpuDetection* cd = cand_at2(p.cand, s.scan, nblocks, e);
-          const float4 bx = make_float4(cd->x1, cd->y1, cd->x2, cd->y2);
-          const float2 cf = make_float2(cd->confidence, __int_as_float(cd->class_id));
-          if (tid < 64) { s.rbox[k] = bx; s.rcc[k] = cf; } else { s.cbox[k] = bx; s.ccc[k] = cf; }
-        }
+        const int e = (tid < 64 ? c : w) * 64 + (tid & 63);
+        if (e < n) fetch(e, e);
       }
     } else {
-      // overflow: the kMaxDet largest confidences, ties by enumeration order, kept in enumeration order (radix select on
-      // the bit patterns: confidences are positive floats, so the patterns order like the values). Every workgroup runs
-      // the selection for itself and keeps the selected candidates that fall into its rows / columns.
-      // The confidence bit patterns are first copied into LDS (the suppression matrix's space: it is not in use yet; four
-      // candidates per thread and round so that their look-ups and loads overlap): every pass then reads LDS instead of
-      // chasing a binary search + a dependent global load per candidate in each of the five passes (conf 0.3 on the synthetic weights:
-      // 59 -> 44 us for this phase; conf 0.05, every cell a candidate: 255 -> 124 us. Edge path: the bench's 0.5 stays below 1024).
-      unsigned int* keys = reinterpret_cast<unsigned int*>(s.mask);
-      constexpr int kKeyCap = (int)(sizeof(s.mask) / sizeof(unsigned int));
-      const bool cached = total <= kKeyCap;
-      if (cached) {
-        for (int e0 = tid; e0 < total; e0 += 4 * kTN) {
-          unsigned int k4[4];
+      // ---- overflow: the kMaxDet largest keys (confidence, then the SMALLER enumeration index) of `total` candidates ----
+      // Every tile workgroup finds the same cut element (cutkey, cuteidx) -- selected <=> key > cutkey || (key == cutkey &&
+      // eidx <= cuteidx) -- and numbers the selected candidates in list order; it fetches those that fall into its rows / columns.
+      // Launch 1's histogram gives the confidence bin T that holds the cut; as long as that bin's members are too many to rank
+      // exactly (an untrained network puts half the frame into one bin) the bin is split again -- 4096 sub-ranges of the key,
+      // and once all keys are equal, of the enumeration index -- one coalesced sweep over the dense key array per level
+      // (typically none: ~10 members). Then: one sweep that collects the members and counts the candidates above the bin per
+      // wave range, the exact ranking of the <= 1024 members in LDS, one sweep that numbers and fetches. Was: five passes with a
+      // binary search per candidate (44 us at conf 0.3, 124 us at conf 0.05 on the synthetic weights).
+      constexpr int kMemCap = 1024;
+      int* hist = reinterpret_cast<int*>(s.mask);                       // (the suppression matrix's LDS is free until the scan)
+      unsigned* mkey = reinterpret_cast<unsigned*>(hist + kBins);
+      int* meidx = reinterpret_cast<int*>(mkey + kMemCap);
+      int* mpos = meidx + kMemCap;
+      int* part = mpos + kMemCap;                                       // [kTN] partial sums of 8 bins each
+      const int R = (((total + kWN - 1) / kWN) + 63) & ~63;             // list entries per wave range (a multiple of 64)
+      const int e_lo = wv * R, e_hi = (e_lo + R) < total ? (e_lo + R) : total;
+      // a wave sweeps its range 1024 keys at a time: 16 coalesced loads in flight per lane before the first is used (with 4 a
+      // sweep of 33 600 keys paid 17 dependent round trips through a loaded L2: ~20 us)
+      constexpr int U = 16;
+      auto for_chunks = [&](auto body) {   // body(e0, ke): ke[u] = (key, enumeration index) of list entry e0 + 64 u + lane, (0, 0) past the range
+        uint2 cur[U], nxt[U];
+        auto request = [&](uint2 (&d)[U], int e0) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * kTN;
-            k4[u] = e < total ? __float_as_uint(cand_at2(p.cand, s.scan, nblocks, e)->confidence) : 0u;
-          }
+          for (int u = 0; u < U; ++u) d[u] = e0 + 64 * u + lane < e_hi ? p.ws_ke[e0 + 64 * u + lane] : make_uint2(0u, 0u);
+        };
+        request(cur, e_lo);
+        for (int e0 = e_lo; e0 < e_hi; e0 += 64 * U) {
+          request(nxt, e0 + 64 * U);          // (the next chunk is on its way while this one is processed)
+          body(e0, cur);
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (e0 + u * kTN < total) keys[e0 + u * kTN] = k4[u];
+          for (int u = 0; u < U; ++u) cur[u] = nxt[u];
         }
+      };
+      // the bin that holds the `want`-th element counted from the top (ascending == false) or from the bottom of hist[0..kBins):
+      // returns (bin, elements wanted from it, its count) through s.misc
+      auto pick_bin = [&](int want, bool ascending) {
+        int v8 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v8 += hist[8 * tid + k];
+        part[tid] = v8;
         __syncthreads();
-      }
-      auto key_of = [&](int e) { return cached ? keys[e] : __float_as_uint(cand_at2(p.cand, s.scan, nblocks, e)->confidence); };
-      unsigned int prefix = 0, pmask = 0;
-      int want = kMaxDet;
-      for (int shift = 24; shift >= 0; shift -= 8) {
-        if (tid < 256) s.hist[tid] = 0;
-        __syncthreads();
-        for (int e = tid; e < total; e += kTN) {
-          const unsigned int key = key_of(e);
-          if ((key & pmask) == prefix) atomicAdd(&s.hist[(key >> shift) & 255u], 1);
-        }
-        __syncthreads();
-        if (tid == 0) {
-          int acc = 0, bb = 255;
-          for (; bb > 0; --bb) {
-            if (acc + s.hist[bb] >= want) break;
-            acc += s.hist[bb];
+        if (wv == 0) {
+          int v = 0;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v += part[8 * lane + k];
+          int incl = v;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(incl, off);
+            if (lane >= off) incl += u;
           }
-          s.misc[0] = bb;
-          s.misc[1] = want - acc;
+          const int all = __shfl(incl, 63);
+          const int before = ascending ? incl - v : all - incl;          // elements in front of this lane's 64 bins, in walking order
+          // exactly one lane's 64 bins hold the element (all >= want); the bin inside them by a second wave-wide scan
+          const unsigned long long hit = __ballot(before < want && before + v >= want);
+          const int L = __ffsll((long long)hit) - 1;
+          const int before_l = __shfl(before, L);
+          const int bb = 64 * L + (ascending ? lane : 63 - lane);           // lane 0 = the first bin in walking order
+          const int hv = hist[bb];
+          int inc2 = hv;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(inc2, off);
+            if (lane >= off) inc2 += u;
+          }
+          const int b2 = before_l + inc2 - hv;
+          if (b2 < want && b2 + hv >= want) {
+            s.misc[0] = bb;
+            s.misc[1] = want - b2;
+            s.misc[2] = hv;
+          }
         }
         __syncthreads();
-        prefix |= (unsigned int)s.misc[0] << shift;
-        pmask |= 255u << shift;
+      };
+      for (int i = tid; i < kBins; i += kTN) hist[i] = p.ws_hist[i];
+      __syncthreads();
+      pick_bin(kMaxDet, false);
+      const int T = s.misc[0];
+      int want = s.misc[1], cnt = s.misc[2];
+      // the key range [klo, khi) of bin T (bit patterns of positive floats order like the values)
+      unsigned klo = __float_as_uint((float)T / (float)kBins);
+      unsigned khi = T == kBins - 1 ? 0x3F800001u : __float_as_uint((float)(T + 1) / (float)kBins);   // (a confidence is at most 1.0)
+      __syncthreads();
+      while (cnt > kMemCap && khi - klo > 1u) {                           // split the bin's key range 4096 ways
+        const unsigned wdt = (khi - klo + (unsigned)kBins - 1u) / (unsigned)kBins;
+        for (int i = tid; i < kBins; i += kTN) hist[i] = 0;
+        __syncthreads();
+        for_chunks([&](int e0, const uint2 (&ke)[U]) {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (e0 + 64 * u + lane < e_hi && ke[u].x >= klo && ke[u].x < khi) atomicAdd(&hist[(ke[u].x - klo) / wdt], 1);
+        });
+        __syncthreads();
+        pick_bin(want, false);
+        const unsigned nlo = klo + (unsigned)s.misc[0] * wdt;
+        khi = nlo + wdt < khi ? nlo + wdt : khi;
+        klo = nlo;
         want = s.misc[1];
+        cnt = s.misc[2];
         __syncthreads();
       }
-      const unsigned int T = prefix;  // bits of the kMaxDet-th largest confidence; take `want` of its ties
-      int base_sel = 0, base_eq = 0;
-      for (int e0 = 0; e0 < total; e0 += kTN) {
-        const int e = e0 + tid;
-        const bool live = e < total;
-        const unsigned int key = live ? key_of(e) : 0u;
-        const bool eq = live && key == T;
-        int tot_eq, tot_sel;
-        const int rank_eq = block_rank_n(eq, s.wave_cnt, &tot_eq);
-        const bool sel = live && (key > T || (eq && base_eq + rank_eq < want));
-        const int pos = base_sel + block_rank_n(sel, s.wave_cnt, &tot_sel);
-        if (sel && ((pos >> 6) == c || (pos >> 6) == w)) {   // only the selected candidates of this tile's rows / columns are fetched
-          const GpuDetection* cd = cand_at2(p.cand, s.scan, nblocks, e);
-          const float4 bx = make_float4(cd->x1, cd->y1, cd->x2, cd->y2);
-          const float2 cf = make_float2(cd->confidence, __int_as_float(cd->class_id));
-          if ((pos >> 6) == c) { s.rbox[pos & 63] = bx; s.rcc[pos & 63] = cf; }
-          if ((pos >> 6) == w) { s.cbox[pos & 63] = bx; s.ccc[pos & 63] = cf; }
-        }
-        base_sel += tot_sel;
-        base_eq += tot_eq;
+      // all keys of the bin equal and still too many: split by enumeration index (the smaller index comes first)
+      int esh = 0, ebin = -1;
+      if (cnt > kMemCap) {
+        const int emax = p.eoff[2] + p.gw[2] * p.gh[2];
+        while ((emax >> esh) >= kBins) ++esh;
+        for (int i = tid; i < kBins; i += kTN) hist[i] = 0;
+        __syncthreads();
+        for_chunks([&](int e0, const uint2 (&ke)[U]) {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (e0 + 64 * u + lane < e_hi && ke[u].x == klo) atomicAdd(&hist[(int)ke[u].y >> esh], 1);
+        });
+        __syncthreads();
+        pick_bin(want, true);
+        ebin = s.misc[0];
+        want = s.misc[1];
+        cnt = s.misc[2];                                                  // <= 2^esh <= 64 members
+        __syncthreads();
       }
+      // 2 = selected for certain, 1 = member of the last bin (ranked exactly below), 0 = out
+      auto classify = [&](unsigned key, int eidx) {
+        if (key >= khi) return 2;
+        if (key < klo) return 0;
+        if (ebin < 0) return 1;
+        const int eb = eidx >> esh;
+        return eb < ebin ? 2 : (eb == ebin ? 1 : 0);
+      };
+      if (tid == 0) s.misc[3] = 0;
+      if (tid < kWN) s.hist[tid] = 0;
+      __syncthreads();
+      // sweep: candidates selected for certain per wave range, members -> LDS
+      int sure = 0;
+      for_chunks([&](int e0, const uint2 (&ke)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int cl = e0 + 64 * u + lane < e_hi ? classify(ke[u].x, (int)ke[u].y) : 0;
+          sure += __popcll(__ballot(cl == 2));
+          if (cl == 1) {
+            const int slot = atomicAdd(&s.misc[3], 1);
+            if (slot < kMemCap) { mkey[slot] = ke[u].x; meidx[slot] = (int)ke[u].y; mpos[slot] = e0 + 64 * u + lane; }
+          }
+        }
+      });
+      if (lane == 0) s.wave_cnt[wv] = sure;
+      __syncthreads();
+      const int m = s.misc[3] < kMemCap ? s.misc[3] : kMemCap;           // (== cnt; the cap cannot bite: cnt <= kMemCap here)
+      // exact ranking of the members; the member of rank want - 1 is the cut, the members up to it are selected
+      for (int i = tid; i < m; i += kTN) {
+        const unsigned ki = mkey[i];
+        const int xi = meidx[i];
+        int r = 0;
+        for (int j = 0; j < m; ++j) r += (mkey[j] > ki || (mkey[j] == ki && meidx[j] < xi)) ? 1 : 0;
+        if (r == want - 1) { s.misc[0] = (int)ki; s.misc[1] = xi; }
+        if (r < want) atomicAdd(&s.hist[mpos[i] / R], 1);                 // selected members per wave range
+      }
+      __syncthreads();
+      const unsigned cutkey = (unsigned)s.misc[0];
+      const int cuteidx = s.misc[1];
+      int run = 0;
+      for (int v = 0; v < wv; ++v) run += s.wave_cnt[v] + s.hist[v];
+      // sweep: number the selected candidates in list order, fetch this tile's
+      for_chunks([&](int e0, const uint2 (&ke)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool sel = e0 + 64 * u + lane < e_hi && (ke[u].x > cutkey || (ke[u].x == cutkey && (int)ke[u].y <= cuteidx));
+          const unsigned long long bal = __ballot(sel);
+          const int pos = run + __popcll(bal & ((1ull << lane) - 1ull));
+          // (only the list entry is noted here: a record load inside this loop would be one serialised round trip per hit)
+          if (sel && (pos >> 6) == c) part[pos & 63] = e0 + 64 * u + lane;
+          if (sel && (pos >> 6) == w) part[64 + (pos & 63)] = e0 + 64 * u + lane;
+          run += __popcll(bal);
+        }
+      });
+      __syncthreads();
+      if (tid < 128) fetch(part[tid], (tid < 64 ? c : w) * 64 + (tid & 63));   // every slot is taken: 1024 candidates are selected
     }
     __syncthreads();
     if (p.stamps && tid == 0 && t == 0) p.stamps[2] = wall_clock64();
@@ -1029,13 +966,13 @@ __global__ __launch_bounds__(kTN) void post_nms_kernel(const PostParams p) {
       const int gj = w * 64 + col;
       const float4 bb = s.cbox[col];
       const float2 bc = s.ccc[col];
-      // key_j > key_i with key = (confidence, ~position): the stable descending order
-      const bool j_first = bc.x > ac.x || (bc.x == ac.x && gj < gi);
+      // key_j > key_i with key = (confidence, ~enumeration index): the stable descending order
+      const bool j_first = bc.x > ac.x || (bc.x == ac.x && ce_eidx(bc.y) < ce_eidx(ac.y));
       const bool i_first = gi != gj && !j_first;
       // the pair test of `suppresses` (same arithmetic; the IoU is symmetric bit for bit), once for both orientations
       const float ix1 = fmaxf(a.x, bb.x), iy1 = fmaxf(a.y, bb.y);
       const float ix2 = fminf(a.z, bb.z), iy2 = fminf(a.w, bb.w);
-      bool over = gi != gj && __float_as_int(bc.y) == __float_as_int(ac.y) && !(ix1 >= ix2 || iy1 >= iy2);
+      bool over = gi != gj && ((__float_as_int(bc.y) ^ __float_as_int(ac.y)) & 0xFF) == 0 && !(ix1 >= ix2 || iy1 >= iy2);
       if (over) {
         const float inter = (ix2 - ix1) * (iy2 - iy1);
         const float area_b = (bb.z - bb.x) * (bb.w - bb.y);
@@ -1206,18 +1143,21 @@ __global__ __launch_bounds__(kTN) void post_nms_kernel(const PostParams p) {
       GpuDetection d;
       d.x1 = bx2[q].x; d.y1 = bx2[q].y; d.x2 = bx2[q].z; d.y2 = bx2[q].w;
       d.confidence = cc2[q].x;
-      d.class_id = __float_as_int(cc2[q].y);
+      d.class_id = ce_class(cc2[q].y);
       d.valid = 1;
       d._pad = 0;
       p.out[s.list[0][rk[q]]] = d;
     }
   }
-  // the rank / row accumulators go back to zero for the next frame (they are zero at rest, like the ticket)
+  // the rank / row accumulators, the list length and the confidence histogram go back to zero for the next frame (they are
+  // zero at rest, like the ticket)
   for (int e = tid; e < nw * 64; e += kTN) p.ws_rank[e] = 0;
   if (tid < kWords) p.ws_rownz[tid] = 0ull;
+  for (int i = tid; i < kBins; i += kTN) p.ws_hist[i] = 0;
   if (tid == 0) {
     *p.out_count = base;
     if (p.out_candidates) *p.out_candidates = total;
+    __hip_atomic_store(p.ws_total, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(p.ticket2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     if (p.stamps) p.stamps[6] = wall_clock64();
   }
@@ -1229,8 +1169,9 @@ int post_num_blocks(const int gw[3], const int gh[3]) {
   return (cells + kPostBlock - 1) / kPostBlock;
 }
 
+constexpr size_t kListCap = 256 * 1024;   // candidates the compact list can hold (= cells of the largest supported frame: 1024 workgroups x 256)
 size_t post_workspace_bytes() {
-  return sizeof(float4) * kMaxDet + sizeof(float2) * kMaxDet + sizeof(unsigned long long) * (kTriWords + kMaxTiles) + 256 +
+  return sizeof(float4) * kMaxDet + sizeof(float2) * kMaxDet + 256 + sizeof(int) * kBins + sizeof(uint2) * kListCap +
          sizeof(int) * kMaxDet + sizeof(unsigned long long) * ((size_t)kMaxDet * kWords + kWords);
 }
 
@@ -1238,11 +1179,11 @@ void post_bind_workspace(PostParams* p, void* ws) {
   char* c = static_cast<char*>(ws);
   p->ws_box = reinterpret_cast<float4*>(c); c += sizeof(float4) * kMaxDet;
   p->ws_cc = reinterpret_cast<float2*>(c); c += sizeof(float2) * kMaxDet;
-  p->ws_mask = reinterpret_cast<unsigned long long*>(c); c += sizeof(unsigned long long) * kTriWords;
-  p->ws_tilenz = reinterpret_cast<unsigned long long*>(c); c += sizeof(unsigned long long) * kMaxTiles;
-  p->ws_n = reinterpret_cast<int*>(c);
+  p->ws_total = reinterpret_cast<int*>(c);
   p->ticket2 = reinterpret_cast<unsigned int*>(c + 64);
   c += 256;
+  p->ws_hist = reinterpret_cast<int*>(c); c += sizeof(int) * kBins;
+  p->ws_ke = reinterpret_cast<uint2*>(c); c += sizeof(uint2) * kListCap;
   p->ws_full = reinterpret_cast<unsigned long long*>(c); c += sizeof(unsigned long long) * (size_t)kMaxDet * kWords;
   p->ws_rownz = reinterpret_cast<unsigned long long*>(c); c += sizeof(unsigned long long) * kWords;
   p->ws_rank = reinterpret_cast<int*>(c);
@@ -1252,6 +1193,10 @@ void post_bind_workspace(PostParams* p, void* ws) {
 // subtile per wave: its hidden tensor -- 64 px x 2C x 2 bytes per workgroup -- is then spread over many CUs), or 256 when
 // the grid would not fit the 1024-entry block table.
 bool post_plan_blocks(PostParams* p) {
+  p->eoff[0] = 0;                                  // enumeration index of a head's first cell (P2 -> P3 -> P4, row-major)
+  p->eoff[1] = p->gw[0] * p->gh[0];
+  p->eoff[2] = p->eoff[1] + p->gw[1] * p->gh[1];
+  if ((size_t)p->eoff[2] + (size_t)p->gw[2] * p->gh[2] > kListCap) return false;
   for (int per = 64; per <= 256; per *= 4) {
     int tot = 0;
     for (int h = 0; h < 3; ++h) {
@@ -1285,12 +1230,7 @@ int postprocess_desc(const PostParams& p, LaunchDesc out[2]) {
   out[0].grid = dim3(nb);
   out[0].block = dim3(kPostBlock);
   out[0].shmem = (unsigned)kPostSmemBytes;
-  if (!p.ws_box) return 1;
-  out[1].func = reinterpret_cast<const void*>(&nms_tiles_kernel);
-  out[1].grid = dim3(kMaxTiles);   // n is only known on the device: tiles past the triangle just draw their ticket
-  out[1].block = dim3(kTileThreads);
-  out[1].shmem = (unsigned)sizeof(Smem2);
-  return 2;
+  return 1;
 }
 
 hipError_t postprocess_launch(const PostParams& p, hipStream_t stream) {
@@ -1386,9 +1326,7 @@ hipError_t post_init() {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPostSmemBytes);
     if (e != hipSuccess) return e;
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem2));
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(post_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemD));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(post_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemD));
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(post_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemN));
 }

@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "unina_load_engine", "unina_unload_engine", "unina_engine_input_dims", "unina_set_tensor_address",
     "unina_tensor_address", "unina_enqueue", "unina_infer", "unina_infer_bgra", "unina_infer_async", "unina_postprocess_async",
     "unina_last_error", "unina_op_count", "unina_get_op_info", "unina_profile_ops", "unina_profile_post", "unina_debug_read_buffer",
-    "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune", "unina_debug_post_stamps", "unina_debug_conv_stamps", "unina_debug_dual_stamps", "unina_debug_dual_timeline", "unina_serial_latency",
+    "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune", "unina_debug_post_stamps", "unina_debug_conv_stamps", "unina_debug_dual_stamps", "unina_debug_dual_timeline", "unina_debug_block_stamps", "unina_serial_latency",
     "unina_set_fusion", "unina_fusion_groups", "unina_debug_fusable_groups",
     "create_norm_params_imagenet", "create_norm_params", "preprocess_bgra_resize", "preprocess_bgra", "preprocess_nv12",
     "allocate_preprocess_buffer", "free_preprocess_buffer", "create_preprocess_stream", "destroy_preprocess_stream",
@@ -97,6 +97,7 @@ def load_library() -> C.CDLL:
     L.unina_debug_conv_stamps.argtypes = [vp, ci, C.POINTER(C.c_longlong), vp]
     L.unina_debug_dual_stamps.argtypes = [vp, ci, C.POINTER(C.c_longlong), vp]
     L.unina_debug_dual_timeline.argtypes = [vp, ci, C.POINTER(C.c_longlong), ci, vp]
+    L.unina_debug_block_stamps.argtypes = [vp, ci, C.POINTER(C.c_longlong), vp]
     L.unina_serial_latency.argtypes = [vp, C.POINTER(vp), ci, ci, cf, cf, cf, C.POINTER(C.c_double), vp]
     # cuda_preprocess.h drop-in symbols
     L.create_norm_params_imagenet.restype = NormParams
@@ -350,6 +351,12 @@ class Engine:
         """In-kernel phase stamps of the dual conv launch led by op `op_index`: 8 values per conv (debug)."""
         buf = (C.c_longlong * 16)()
         self._check(self.L.unina_debug_dual_stamps(self.h, op_index, buf, _stream_ptr(stream)))
+        return [int(v) for v in buf]
+
+    def block_stamps(self, op_index: int, stream=None) -> List[int]:
+        """Per-step shader-clock stamps of the fused C3k2 block led by op `op_index` (debug twin; the 40x40-level blocks)."""
+        buf = (C.c_longlong * 16)()
+        self._check(self.L.unina_debug_block_stamps(self.h, op_index, buf, _stream_ptr(stream)))
         return [int(v) for v in buf]
 
     def dual_timeline(self, op_index: int, stream=None):
