@@ -101,7 +101,14 @@ int unina_enqueue(unina_engine_t *e, hipStream_t stream);
  * into a pinned host block and then a completion word (system-scope release); the call spins on that word, so the
  * latency path has neither a D2H copy command nor a stream synchronisation. `stream` may still hold the tail of the
  * frame's launch for a few microseconds after the call returns (work submitted to it later is ordered as usual).
- * UNINA_HOST_RESULT=0 / UNINA_HOST_POLL=0 restore the device buffer + copy / hipStreamSynchronize. */
+ * UNINA_HOST_RESULT=0 / UNINA_HOST_POLL=0 restore the device buffer + copy / hipStreamSynchronize.
+ *
+ * NOTE on the six head tensors ("p2_cls" ... "p4_reg"): unina_infer / unina_infer_async / unina_infer_bgra compute the heads'
+ * output convs INSIDE the decode launch and do NOT write the fp32 planes of those heads (P3 / P4 always; P2 too unless its
+ * head runs as one fused kernel). After these calls unina_tensor_address / unina_debug_read_buffer of such a plane return
+ * whatever an earlier unina_enqueue left there (or zeros). A caller that wants the raw heads (the TensorRT-shaped path of
+ * perception_node.cpp:612-640) calls unina_enqueue, which always writes all six; UNINA_POST_FOLD=0 makes the frame path
+ * write them too. */
 int unina_infer(unina_engine_t *e, const float *d_images_nchw, float conf_threshold, float iou_threshold,
                 float conformal_q, GpuDetection *out, int *out_count, hipStream_t stream);
 

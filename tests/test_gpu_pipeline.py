@@ -181,3 +181,27 @@ def test_serial_latency_entry_point_times_unina_infer_inside_the_abi(pkg, sd7, t
         assert e.infer(frames[0], 0.5, 0.45, 0.1).tobytes() == want
     finally:
         e.close()
+
+
+def test_unaligned_frame_pointer_is_refused_after_capture(pkg, sd7, torch_cuda):
+    """The stem kernel's form (tiled, 16-byte row loads) is fixed by the SHAPE at plan time and the captured frame graph's stem
+    node is only re-pointed per frame: a frame pointer that is not 16-byte aligned must be refused by the ABI (UNINA_ERR_ARG),
+    before and after the graph exists, and must leave the engine usable."""
+    import ctypes as C
+    from unina_yolo_dla_amd.engine import Engine, EngineError, MAX_DETECTIONS
+    e = Engine.from_state_dict(sd7, pkg.graph.Graph(in_h=128, in_w=128))
+    try:
+        big = torch_cuda.zeros((3 * 128 * 128 + 64,), dtype=torch_cuda.float32, device="cuda")
+        big[:3 * 128 * 128] = torch_cuda.from_numpy(pkg.rng.frame(1234, 128, 128)).cuda().reshape(-1)
+        aligned = big[:3 * 128 * 128].reshape(1, 3, 128, 128)
+        first = e.infer(aligned, 0.3, 0.45, 0.1).tobytes()             # captures the frame graph
+        shifted = big[1:1 + 3 * 128 * 128]                             # + 4 bytes
+        shifted.copy_(aligned.reshape(-1).clone())
+        out = (C.c_byte * (32 * MAX_DETECTIONS))()
+        n = C.c_int()
+        rc = e.L.unina_infer(e.h, C.c_void_p(shifted.data_ptr()), C.c_float(0.3), C.c_float(0.45), C.c_float(0.1), out, C.byref(n), None)
+        assert rc != 0 and b"16-byte aligned" in e.L.unina_last_error(e.h)
+        big[:3 * 128 * 128] = torch_cuda.from_numpy(pkg.rng.frame(1234, 128, 128)).cuda().reshape(-1)
+        assert e.infer(aligned, 0.3, 0.45, 0.1).tobytes() == first     # the engine (and its graph) is intact
+    finally:
+        e.close()

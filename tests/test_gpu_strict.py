@@ -82,7 +82,7 @@ def test_strict_fused_equals_per_op_within_fp32_noise(pkg, sd7, torch_cuda, size
     try:
         assert e.set_fusion(True) >= 8                            # 7 C3k2 blocks + the SPPF / lateral pair
         kernels = " ".join(o["kernel"] for o in e.op_infos())
-        assert "c3k2_fused<s16" in kernels and "conv_pair<s16" in kernels and "conv_dual_head3x3_s16" in kernels, kernels
+        assert "c3k2_fused<s16" in kernels and "conv_pair<s16" in kernels and "conv_dual_head3x3_ws_s16" in kernels, kernels
         x = torch_cuda.from_numpy(pkg.rng.frame(1234, size, size)).cuda()
         fused = e.forward(x)
         # (cat_pan1 / cat_pan2 are left out: their down-sampled halves live only inside the fused PAN blocks)

@@ -154,3 +154,17 @@ def test_split_op_table_is_fp32_like(pkg, sd7, oracle_mod, oracle_sd7):
         np.testing.assert_allclose(outs[n], ref[n], atol=1e-4, rtol=0, err_msg=n)
     for bname, oname in {"backbone.stem": "backbone.stem", "neck.cat_pan2": "neck.cat_pan2", "backbone.sppf.cat": "backbone.sppf.cat"}.items():
         np.testing.assert_allclose(named[bname], ref[oname], atol=1e-4 * max(1.0, np.abs(ref[oname]).max()), rtol=0, err_msg=bname)
+
+
+def test_histogram_calibrator_survives_a_dead_first_batch():
+    """A buffer that is all zero on the first calibration frame gave the histogram the range (0, 1e-8); the next ordinary batch
+    then 'grew' it by ~1e12 bins. The calibrator must start over from the first non-zero batch and keep the zeros in bin 0."""
+    from unina_yolo_dla_amd import export
+    c = export.HistogramCalibrator()
+    c.collect(np.zeros((8, 16, 16), np.float32))
+    c.collect(np.zeros((8, 16, 16), np.float32))
+    x = np.maximum(np.random.default_rng(0).normal(0, 1, (8, 16, 16)).astype(np.float32), 0)
+    c.collect(x)
+    assert len(c.hist) == 2048 and abs(c.edges[-1] - float(x.max())) < 1e-6
+    assert c.hist.sum() == 3 * x.size and c.hist[0] >= 2 * x.size
+    assert 0.5 < c.amax("percentile", 99.99) <= float(x.max()) + 1e-6

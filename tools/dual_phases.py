@@ -8,7 +8,9 @@ import numpy as np, torch
 import unina_yolo_dla_amd as u
 from unina_yolo_dla_amd.engine import Engine
 
-e = Engine.from_state_dict(u.synth.make_state_dict(7))
+from unina_yolo_dla_amd import export
+STRICT = "--precision" in sys.argv and sys.argv[sys.argv.index("--precision") + 1] == "strict"
+e = Engine.from_state_dict(u.synth.make_state_dict(7), precision=export.STRICT if STRICT else export.FP16)
 x = torch.from_numpy(u.rng.frame(1234, 640, 640)).cuda()
 e.forward(x)
 ops = e.profile_ops(20)

@@ -1122,6 +1122,192 @@ __global__ __launch_bounds__(256) void conv_dual_head3x3_ws_i8(const ConvParams 
   else conv3x3_ws_body<16, 128, 4, false, signed char>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
 }
 
+
+// ============================================================================================ 3x3 weights-stationary, split fp16
+// STRICT engines (kS16): the row-walking / weights-stationary scheme of conv3x3_ws_body on fp16 (hi, lo) pairs. A wave owns ONE
+// 16-channel subtile and a TH x 16 pixel tile; the fragment pair of patch row rho (kx, channel block) feeds the three output
+// rows rho, rho-1, rho-2 -- 2 ds_read_b128 per 9 MFMAs (3 taps x the 3 MFMAs of a split product), against 2 per 3 in the
+// register-queue kernel, whose LDS reads (and twice-fetched weight blocks) bound the strict engine's head layers (44 us per
+// P3 | P4 pair). A (hi | lo) weight block pair is 8 VGPRs, so the input runs in NCHUNK chunks of CC channels (64: 9 taps x 2
+// blocks = 144 VGPRs per chunk): the weights of chunk c + 1 are requested into a SECOND register set and its slice of the
+// patch (both planes) into staging registers BEFORE chunk c's K loop starts, so every ingest but the first is hidden behind
+// matrix work (with all of a 128-channel chunk in one set the P4 conv spent 2 x 4 us waiting for weights: 32 us per pair);
+// the patch slices alternate between two LDS buffers (padded pixel pitch, no swizzle: immediate-offset reads), and the TH
+// accumulators live across the chunks. (The sum order is chunk-major: the split type has no bit-identity contract between
+// kernel families, its parity is the north-star tolerance against the fp32 oracle.)
+template <int TH, int CIN, int NCHUNK, int NW, bool STAMPS = false>
+__device__ __forceinline__ void conv3x3_ws_s16_body(const ConvParams& p, int bid, int nwg) {
+  typedef half8x2 frag;
+  if constexpr (STAMPS) { stamp_b(p, 0, bid, nwg); stamp_wg(p, 0); }
+  typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+  typedef float floatx2 __attribute__((ext_vector_type(2)));
+  constexpr int TW = 16, R0W = TW + 2, R0H = TH + 2, NT = NW * 64, BN = NW * 16;
+  constexpr int CB = CIN / 32, CC = CIN / NCHUNK, CBC = CC / 32, KBC = 9 * CBC;
+  constexpr int STEPS = R0H * 3 * CBC, PF = 4;
+  constexpr int PITCH = CC * 2 + 32;
+  constexpr int PLANE = R0H * R0W * PITCH;                   // one plane of a patch chunk; the lo image lies right behind the hi image
+  constexpr int BUF = 2 * PLANE;                             // one LDS buffer (hi + lo); chunks alternate between two
+  static_assert(CIN % (32 * NCHUNK) == 0 && KBC * 16 <= 320 && PLANE % 16 == 0, "chunking: two weight sets must fit the registers");
+  static_assert((R0H * R0W + 2) * PITCH < 65536, "ds_read immediate offsets");
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  int bx, by;
+  tile_of_block(p, bid, nwg, &bx, &by);
+  const int sidx = (p.nseg > 1 && by >= p.seg[1].tile0) ? 1 : 0;
+  const ConvSeg& sg = p.seg[sidx];
+  const int n_pad = (sg.n_count + 15) & ~15;
+  const int nb0 = (by - sg.tile0) * BN;
+  const int tiles_x = (p.Wo + TW - 1) / TW;
+  const int tyi = fast_div(bx, p.tx_magic), txi = bx - tyi * tiles_x;
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+
+  int nsub = (nb0 >> 4) + wid;
+  nsub = nsub * 16 < n_pad ? nsub : (n_pad >> 4) - 1;   // tail subtile: clamp (never stored)
+  const unsigned char* wptr = static_cast<const unsigned char*>(sg.w) + (size_t)nsub * (9 * CB) * 2048 + (4 * l15 + (lq ^ swz_g(l15))) * 16;
+  const int n = nb0 + wid * 16 + lq * 4;                // slice-relative first channel of this lane's 4 outputs
+  const bool n_ok = n < sg.n_count;
+  const floatx4 bias = *reinterpret_cast<const floatx4*>(sg.bias + (n_ok ? n : 0));
+
+  // source planes through buffer descriptors: a slot outside the image (the conv's zero padding) or past the patch gets an
+  // out-of-range offset and reads zeros -- no branch around a load
+  const int src_bytes = p.H * p.W * p.src_ld * 2;
+  const __amdgpu_buffer_rsrc_t srs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srs_l =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(static_cast<const unsigned char*>(p.src) + p.src_lo), 0, src_bytes, 0x00020000);
+  constexpr int nchx = CC * 2 / 16, nslots = R0H * R0W * nchx, PITER = (nslots + NT - 1) / NT;
+
+  // destination planes: lanes outside the image / past the slice get an out-of-range offset and their stores are dropped
+  const unsigned rowb = (unsigned)(p.Wo * sg.dst_ld * 2);
+  const __amdgpu_buffer_rsrc_t drs_h = __builtin_amdgcn_make_buffer_rsrc(sg.dst, 0, (int)((unsigned)p.Ho * rowb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t drs_l =
+      __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned char*>(sg.dst) + sg.dst_lo, 0, (int)((unsigned)p.Ho * rowb), 0x00020000);
+  const bool lane_ok = n_ok && tx0 + l15 < p.Wo;
+  const unsigned voff0 = lane_ok ? (unsigned)(((ty0 * p.Wo + tx0 + l15) * sg.dst_ld + n) * 2) : 0x40000000u;
+
+  floatx4 acc[TH];
+  auto store_row = [&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    const floatx4 v = acc[r] + bias;
+    half4 hv, lv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = v[e] > 0.f ? v[e] : 0.f;
+      hv[e] = (half_t)a;
+      lv[e] = (half_t)(a - (float)hv[e]);
+    }
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs_h, voff0 + (unsigned)r * rowb, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, lv), drs_l, voff0 + (unsigned)r * rowb, 0, 0);
+  };
+
+  frag wA[KBC], wB[KBC];
+  uintx4 pvh[PITER], pvl[PITER];
+  // block g of chunk ch: tap g / CBC, channel block ch * CBC + g % CBC of the tap's CB blocks
+  auto w_request = [&](frag (&w)[KBC], auto chc, auto g0c, auto g1c) {
+    static_for<decltype(g0c)::value, decltype(g1c)::value>([&](auto gc) {
+      constexpr int g = decltype(gc)::value, ch = decltype(chc)::value;
+      w[g] = EltS::ldw(wptr + (size_t)((g / CBC) * CB + ch * CBC + g % CBC) * 2048);
+      __builtin_amdgcn_sched_barrier(0);   // (issue order = order of first use: the counted waits are exact)
+    });
+  };
+  auto patch_request = [&](auto chc) {
+    constexpr int ch = decltype(chc)::value;
+#pragma unroll
+    for (int it = 0; it < PITER; ++it) {
+      const int sl = it * NT + (int)threadIdx.x;
+      const int r = sl / nchx, cs = sl - r * nchx;
+      const int ry = r / R0W, rx = r - ry * R0W;
+      const int iy = ty0 - 1 + ry, ix = tx0 - 1 + rx;
+      const bool in = sl < nslots && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const unsigned off = in ? (unsigned)(((iy * p.W + ix) * p.src_ld + sg.src_coff + ch * CC) * 2 + (cs << 4)) : 0x40000000u;
+      pvh[it] = __builtin_amdgcn_raw_buffer_load_b128(srs_h, off, 0, 0);
+      pvl[it] = __builtin_amdgcn_raw_buffer_load_b128(srs_l, off, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto patch_commit = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < PITER; ++it) {
+      const int sl = it * NT + (int)threadIdx.x;
+      const int r = sl / nchx, cs = sl - r * nchx;
+      if (sl < nslots) {
+        *reinterpret_cast<uintx4*>(conv_smem + buf * BUF + r * PITCH + cs * 16) = pvh[it];
+        *reinterpret_cast<uintx4*>(conv_smem + buf * BUF + PLANE + r * PITCH + cs * 16) = pvl[it];
+      }
+    }
+  };
+  typedef std::integral_constant<int, 0> I0;
+  // chunk 0 -- request order = order of first use: tap row ky = 0, the patch slice, tap rows ky = 1, 2
+  w_request(wA, I0{}, I0{}, std::integral_constant<int, 3 * CBC>{});
+  patch_request(I0{});
+  w_request(wA, I0{}, std::integral_constant<int, 3 * CBC>{}, std::integral_constant<int, KBC>{});
+  if constexpr (STAMPS) stamp_b(p, 1, bid, nwg);
+  patch_commit(0);
+  lds_barrier();
+  if constexpr (STAMPS) stamp_b(p, 2, bid, nwg);
+
+  static_for<0, NCHUNK>([&](auto chc) {
+    constexpr int ch = decltype(chc)::value;
+    auto& w = (ch & 1) ? wB : wA;
+    if constexpr (ch + 1 < NCHUNK) {   // the next chunk's operands are on their way during this chunk's K loop
+      w_request((ch & 1) ? wA : wB, std::integral_constant<int, ch + 1>{}, I0{}, std::integral_constant<int, KBC>{});
+      patch_request(std::integral_constant<int, ch + 1>{});
+    }
+    const unsigned lo0 = (unsigned)((ch & 1) * BUF + l15 * PITCH + lq * 16);
+    unsigned lo1 = lo0 + PLANE;                     // second base register: the lo plane (ds offsets are 16 bits)
+    asm volatile("" : "+v"(lo1));
+    auto bfrag = [&](auto sc) {
+      constexpr int s = decltype(sc)::value, rho = s / (3 * CBC), kx = (s / CBC) % 3, cbl = s % CBC;
+      constexpr int imm = (rho * R0W + kx) * PITCH + cbl * 64;
+      return frag{*reinterpret_cast<const half8*>(conv_smem + lo0 + imm), *reinterpret_cast<const half8*>(conv_smem + lo1 + imm)};
+    };
+    frag b[PF + 1];
+    static_for<0, PF>([&](auto sc) { b[decltype(sc)::value] = bfrag(sc); });
+    static_for<0, STEPS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value, rho = s / (3 * CBC), kx = (s / CBC) % 3, cbl = s % CBC;
+      if constexpr (s + PF < STEPS) b[(s + PF) % (PF + 1)] = bfrag(std::integral_constant<int, s + PF>{});
+      if constexpr (ch == 0 && kx == 0 && cbl == 0 && rho < TH) acc[rho] = floatx4{0.f, 0.f, 0.f, 0.f};
+      // term-major: the three products of a split MFMA go to the same accumulator, so the rows' MFMAs are interleaved
+      // (lo*hi of rows rho, rho-1, rho-2, then hi*lo, then hi*hi): a dependent MFMA is three issues behind its predecessor
+      static_for<0, 3>([&](auto tc) {
+        constexpr int term = decltype(tc)::value;
+        static_for<0, 3>([&](auto kyc) {
+          constexpr int ky = decltype(kyc)::value, r = rho - ky;
+          if constexpr (r >= 0 && r < TH) {
+            const frag& wv = w[(ky * 3 + kx) * CBC + cbl];
+            const frag& bv = b[s % (PF + 1)];
+            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 0 ? wv.l : wv.h, term == 1 ? bv.l : bv.h, acc[r], 0, 0, 0);
+          }
+        });
+      });
+      // last chunk: row rho-3 was completed by the previous patch row: convert and store it in the shadow of this row's MFMAs
+      if constexpr (ch == NCHUNK - 1 && kx == 1 && cbl == 0 && rho >= 3) store_row(std::integral_constant<int, rho - 3>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (ch + 1 < NCHUNK) {
+      patch_commit((ch + 1) & 1);   // (that buffer's last readers finished before the barrier that ended the previous chunk)
+      lds_barrier();
+    }
+  });
+  if constexpr (STAMPS) stamp_b(p, 3, bid, nwg);
+  store_row(std::integral_constant<int, TH - 1>{});
+  if constexpr (STAMPS) { stamp_b(p, 4, bid, nwg); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_wg(p, 1); }
+}
+
+template <int TH, int CIN, int NCHUNK, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_ws_s16(const ConvParams p) {
+  conv3x3_ws_s16_body<TH, CIN, NCHUNK, NW>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+__global__ __launch_bounds__(256) void conv_dual_head3x3_ws_s16_stamped(const ConvParams pa, const ConvParams pb, int nb) {
+  if ((int)blockIdx.x < nb) conv3x3_ws_s16_body<8, 256, 4, 4, true>(pb, (int)blockIdx.x, nb);
+  else conv3x3_ws_s16_body<8, 128, 2, 4, true>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
+}
+// STRICT engines: the P3 | P4 head pair on it (P4's workgroups take the first block ids)
+__global__ __launch_bounds__(256) void conv_dual_head3x3_ws_s16(const ConvParams pa, const ConvParams pb, int nb) {
+  if ((int)blockIdx.x < nb) conv3x3_ws_s16_body<8, 256, 4, 4>(pb, (int)blockIdx.x, nb);
+  else conv3x3_ws_s16_body<8, 128, 2, 4>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
+}
+
 #ifndef UNINA_CONV_PROBE   // (ISA probe builds stop here: tools/isa_probe.sh compiles only the kernels above)
 // backbone.stem -> backbone.stage1_conv as ONE launch: the 3x3/s2 conv's input patch is the stem's output, computed in
 // place (stem_patch) instead of being written to HBM by one launch and DMA'd back by the next (6.6 MB each way at 640^2).
@@ -1191,6 +1377,7 @@ struct CfgInfo {
   int nthreads = 256;
   int stride = 1;      // register-queue kernel: conv stride it is instantiated for
   bool ws = false;     // weights-stationary 3x3 kernel: fp16 NHWC destination, ReLU, no residual / upsample / planar output
+  int chunks = 1;      // split-fp16 weights-stationary kernel: channel chunks the patch is staged in
 };
 
 constexpr size_t stage_bytes(int bm, int bn) { return (size_t)bm * (bn * 4 + 16); }  // epilogue staging tile (fp32 worst case)
@@ -1235,6 +1422,9 @@ constexpr size_t smem_of() {
 #define WSI(TH, CIN, NW)                                                                             \
   {(TH) * 16, (NW) * 16, 32, 3, "conv3x3_ws<i8," #TH "x16," #CIN "," #NW "w>",                           \
    conv3x3_ws<TH, CIN, NW, signed char>, 0, TH, 16, CIN, (NW) * 64, 1, true}
+#define WSS(TH, CIN, NCH, NW)                                                                        \
+  {(TH) * 16, (NW) * 16, 32, 3, "conv3x3_ws<s16," #TH "x16," #CIN "/" #NCH "," #NW "w>",                 \
+   conv3x3_ws_s16<TH, CIN, NCH, NW>, 0, TH, 16, CIN, (NW) * 64, 1, true, NCH}
 #define NOCFG {0, 0, 0, 0, "n/a", nullptr, 0, 0, 0, -1, 0, 0}
 
 // [dtype][config]; BK is in fp16-equivalent k (KSUB = BK/32 fragment blocks): a K-step covers BK channels in fp16
@@ -1298,6 +1488,7 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         REGQ(8, 16, 64, 256, 8, 16),                  // kCfgRegq8x16n64c256   (P4 head layers)
         WS(16, 128, 4),                               // kCfgWs16x16n64c128    (P3 head layers, weights-stationary)
         WS(8, 256, 4),                                // kCfgWs8x16n64c256     (P4 head layers, weights-stationary)
+        NOCFG, NOCFG, NOCFG,                          // (split-fp16 weights-stationary kernels)
     },
     {
         CFG(float, "f32", 64, 64, 64, 2, 2, 4),
@@ -1331,6 +1522,7 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,     // register-queue kernels: fp16 / int8 only
         NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
         NOCFG, NOCFG,
+        NOCFG, NOCFG, NOCFG,
     },
     {
         CFG(signed char, "i8", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
@@ -1379,6 +1571,7 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         REGQI(8, 16, 64, 256, 8, 16),                 // kCfgRegq8x16n64c256
         WSI(16, 128, 4),                              // kCfgWs16x16n64c128
         WSI(8, 256, 4),                               // kCfgWs8x16n64c256
+        NOCFG, NOCFG, NOCFG,
     },
     {   // split fp16 (kS16): a K-step stages (hi, lo) block pairs -- twice the LDS per stage, hence shallower rings on the wide tiles
         CFG(s16_t, "s16", 64, 64, 64, 2, 2, 3),     // kCfg64x64k64
@@ -1411,6 +1604,9 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         NOCFG, NOCFG,
         NOCFG, NOCFG,
         NOCFG, NOCFG,
+        WSS(8, 64, 1, 4),                           // kCfgWsS8x16n64c64     (P2 head layers)
+        WSS(8, 128, 2, 4),                          // kCfgWsS8x16n64c128    (P3 head layers: two chunks of 64 channels)
+        WSS(8, 256, 4, 4),                          // kCfgWsS8x16n64c256    (P4 head layers: four chunks. 4-row tiles -- 240 workgroups of the P3 conv's size -- ran 34 us per pair against 30.6)
     },
 };
 #undef CFG
@@ -1423,6 +1619,7 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
 #undef NOCFG
 #undef WS
 #undef WSI
+#undef WSS
 #undef REGQS
 #undef REGQS2
 
@@ -1434,6 +1631,7 @@ inline size_t smem_for(const ConvParams& p, const CfgInfo& c) {
   if (c.cin) {  // register-queue kernel: patch (+ < 1 KiB overrun of its last DMA instruction) or the epilogue staging tile
     const size_t ph = c.stride * (c.th - 1) + 3, pw = c.stride * (c.tw - 1) + 3;
     const size_t patch = ((ph * pw * c.cin * esize(p) + 1023) & ~(size_t)1023) + 1024;
+    if (c.ws && p.dtype == kS16) return (c.chunks > 1 ? 2 : 1) * 2 * ph * pw * ((c.cin / c.chunks) * 2 + 32);   // hi + lo image of a channel chunk, two buffers (conv3x3_ws_s16_body)
     if (c.ws) return ph * pw * (c.cin * esize(p) + 32);   // padded pixel pitch, no swizzle (conv3x3_ws_body)
     if (p.dtype == kS16) return 2 * patch;                // hi and lo images; accumulators are stored straight from registers
     return max_sz(patch, stage_bytes((c.bm + 15) & ~15, c.bn));
@@ -1454,6 +1652,7 @@ int n_tiles(const ConvParams& p, int bn) {
 hipError_t conv_init() {
   for (const void* f : {reinterpret_cast<const void*>(conv_dual_head3x3), reinterpret_cast<const void*>(conv_dual_head1x1),
                         reinterpret_cast<const void*>(conv_dual_head3x3_i8), reinterpret_cast<const void*>(conv_dual_head3x3_s16),
+                        reinterpret_cast<const void*>(conv_dual_head3x3_ws_s16), reinterpret_cast<const void*>(conv_dual_head3x3_ws_s16_stamped),
                         reinterpret_cast<const void*>(conv_dual_head3x3_big), reinterpret_cast<const void*>(conv_dual_head3x3_big_i8),
                         reinterpret_cast<const void*>(conv_dual_head3x3_big_stamped),
                         reinterpret_cast<const void*>(conv_dual_head3x3_ws), reinterpret_cast<const void*>(conv_dual_head3x3_ws_stamped),
@@ -1516,6 +1715,11 @@ ConvLaunch conv_plan_with(const ConvParams& p, int cfg) {
 ConvLaunch conv_plan(const ConvParams& p) {
   const int override_cfg = p.force_cfg;
   if (override_cfg >= 0 && conv_config_valid(p, override_cfg)) return conv_plan_with(p, override_cfg);
+  if (p.dtype == kS16 && p.ksize == 3) {   // STRICT engines: 3x3 convs on the patch-resident kernels even without autotuning
+    for (int c : {(int)kCfgWsS8x16n64c64, (int)kCfgWsS8x16n64c128, (int)kCfgWsS8x16n64c256, (int)kCfgRegqS2_8x16n64c32, (int)kCfgRegqS2_8x8n64c64,
+                  (int)kCfgRegqS2_4x8n64c128, (int)kCfgRegq8x16n64c64, (int)kCfgRegq8x16n64c128, (int)kCfgRegq8x8n64c256})
+      if (conv_config_valid(p, c)) return conv_plan_with(p, c);
+  }
   const bool k64 = (p.Cin % (2 * block_k(p.dtype))) == 0;
   int min_npad = 1 << 30;
   for (int s = 0; s < p.nseg; ++s) {
@@ -1610,7 +1814,7 @@ struct DualKind {
   const char* name;
   void (*fn)(const ConvParams, const ConvParams, int);
 };
-enum { kDualRegq = 0, kDual1x1, kDualRegqI8, kDualBig, kDualBigI8, kDualWs, kDualWsI8, kDualRegqS16, kDualKinds };
+enum { kDualRegq = 0, kDual1x1, kDualRegqI8, kDualBig, kDualBigI8, kDualWs, kDualWsI8, kDualRegqS16, kDualWsS16, kDualKinds };
 const DualKind kDual[kDualKinds] = {
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3<regq 8x16,64,128 | regq 8x8,64,256>", conv_dual_head3x3},
     {kCfg128x16k64, kCfg128x16k64, 256, "conv_dual_head1x1<glds 128,16,64 x2>", conv_dual_head1x1},
@@ -1620,6 +1824,7 @@ const DualKind kDual[kDualKinds] = {
     {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws<ws 16x16,64,128 | ws 8x16,64,256>", conv_dual_head3x3_ws},
     {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws_i8<ws i8,16x16,64,128 | ws i8,8x16,64,256>", conv_dual_head3x3_ws_i8},
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3_s16<regq s16,8x16,64,128 | regq s16,8x8,64,256>", conv_dual_head3x3_s16},
+    {kCfgWsS8x16n64c128, kCfgWsS8x16n64c256, 256, "conv_dual_head3x3_ws_s16<ws s16,8x16,64,128/2 | ws s16,8x16,64,256/4>", conv_dual_head3x3_ws_s16},
 };
 }  // namespace
 
@@ -1637,7 +1842,10 @@ int conv_dual_match(const ConvParams& a, const ConvParams& b) {
     if (big && fits(kDualBigI8)) return kDualBigI8;
     return fits(kDualRegqI8) ? kDualRegqI8 : -1;
   }
-  if (a.dtype == kS16 && b.dtype == kS16) return fits(kDualRegqS16) ? kDualRegqS16 : -1;
+  if (a.dtype == kS16 && b.dtype == kS16) {   // STRICT engines: the weights-stationary pair (UNINA_DUAL_WS=0: the register-queue pair)
+    if (ws && fits(kDualWsS16)) return kDualWsS16;
+    return fits(kDualRegqS16) ? kDualRegqS16 : -1;
+  }
   if (a.dtype != kF16 || b.dtype != kF16) return -1;
   // the weights-stationary pair: default for fp16 (same-box A/B against the register-queue pair: +2-3 % frames/s at 2 frames in
   // flight, serial latency equal within noise; workgroup lives 9-11 us against 12-15). UNINA_DUAL_WS=0 falls back.
@@ -1665,10 +1873,10 @@ hipError_t conv_dual_launch(int kind, const ConvParams& pa_in, const ConvParams&
   if (grid_out) *grid_out = na + nb;
   auto fn = k.fn;
   if (pa.stamps || pb.stamps) {   // debug: the stamped twin (only the default fp16 pair has one)
-    if (kind != kDualBig && kind != kDualWs) return hipErrorInvalidValue;
-    fn = kind == kDualWs ? conv_dual_head3x3_ws_stamped : conv_dual_head3x3_big_stamped;
+    if (kind != kDualBig && kind != kDualWs && kind != kDualWsS16) return hipErrorInvalidValue;
+    fn = kind == kDualWs ? conv_dual_head3x3_ws_stamped : (kind == kDualWsS16 ? conv_dual_head3x3_ws_s16_stamped : conv_dual_head3x3_big_stamped);
   }
-  hipLaunchKernelGGL(fn, dim3(na + nb, 1, 1), dim3(k.threads, 1, 1), max_sz(sa, sb), stream, pa, pb, (kind == kDualWs || kind == kDualWsI8) ? nb : na);   // (the weights-stationary pairs put conv B first)
+  hipLaunchKernelGGL(fn, dim3(na + nb, 1, 1), dim3(k.threads, 1, 1), max_sz(sa, sb), stream, pa, pb, (kind == kDualWs || kind == kDualWsI8 || kind == kDualWsS16) ? nb : na);   // (the weights-stationary pairs put conv B first)
   return hipGetLastError();
 }
 

@@ -1737,6 +1737,7 @@ int unina_infer(unina_engine_t* e, const float* d_images, float conf, float iou,
   // records (system-scope release) and the host spins on that word -- the runtime's completion signal of the frame graph
   // arrives microseconds later. UNINA_HOST_POLL=0 waits with hipStreamSynchronize instead.
   static const bool host_poll = !(getenv("UNINA_HOST_POLL") && getenv("UNINA_HOST_POLL")[0] == '0');
+  bool copied = false;
   if (host_result && e->h_result_dev) {
     unsigned int seq = 0;
     if (host_poll) {
@@ -1767,7 +1768,10 @@ int unina_infer(unina_engine_t* e, const float* d_images, float conf, float iou,
     if (timing) {
       const auto tc = std::chrono::steady_clock::now();
       const int n0 = e->h_result->count;
-      if (n0 >= 0 && n0 <= MAX_DETECTIONS) memcpy(out, e->h_result->det, sizeof(GpuDetection) * (size_t)n0);
+      if (n0 >= 0 && n0 <= MAX_DETECTIONS) {
+        memcpy(out, e->h_result->det, sizeof(GpuDetection) * (size_t)n0);
+        copied = true;
+      }
       const auto td = std::chrono::steady_clock::now();
       e->t_submit_us += std::chrono::duration<double, std::micro>(tb - ta).count();
       e->t_wait_us += std::chrono::duration<double, std::micro>(tc - tb).count();
@@ -1782,7 +1786,7 @@ int unina_infer(unina_engine_t* e, const float* d_images, float conf, float iou,
   }
   int n = e->h_result->count;
   if (n < 0 || n > MAX_DETECTIONS) return fail(e, UNINA_ERR_STATE, "post-process returned count %d", n);
-  memcpy(out, e->h_result->det, sizeof(GpuDetection) * (size_t)n);
+  if (!copied) memcpy(out, e->h_result->det, sizeof(GpuDetection) * (size_t)n);   // (the UNINA_TIMING branch has copied them already)
   *out_count = n;
   return UNINA_OK;
 }
@@ -1922,9 +1926,10 @@ int unina_debug_block_stamps(unina_engine_t* e, int op_index, long long* out16, 
 namespace unina {
 __global__ void debug_stamp_kernel(long long* t) { if (threadIdx.x == 0) *t = wall_clock64(); }
 }
-// Same launch with EVERY workgroup's start / end on the 100 MHz wall clock: out[2*i], out[2*i+1] for workgroup i (conv A's
-// workgroups first), then the clock of a one-wave marker kernel enqueued right before and of one right after the launch
-// (dispatch gaps); cap >= 2 * grid + 2 values. Returns the grid size (> 0) or a negative error code.
+// Same launch with EVERY workgroup's start / end on the 100 MHz wall clock: out[2*i], out[2*i+1] for workgroup i in BLOCK-ID
+// order (the weights-stationary pairs put conv B's workgroups first, the register-queue pairs conv A's), then the clock of a
+// one-wave marker kernel enqueued right before and of one right after the launch (dispatch gaps); cap >= 2 * grid + 2
+// values. Returns the grid size (> 0) or a negative error code.
 int unina_debug_dual_timeline(unina_engine_t* e, int op_index, long long* out, int cap, hipStream_t stream) {
   if (!e || !out || op_index < 0 || op_index >= (int)e->ops.size()) return -UNINA_ERR_ARG;
   if (hipSetDevice(e->device) != hipSuccess) return -UNINA_ERR_HIP;
@@ -1935,24 +1940,33 @@ int unina_debug_dual_timeline(unina_engine_t* e, int op_index, long long* out, i
   const PlannedOp& op = e->ops[op_index];
   if (op.d.kind != kOpConv || op.fuse_role || op.dual_with < 0 || op.dual_absorbed) return -UNINA_ERR_ARG;
   ConvParams pa = op.cp, pb = e->ops[op.dual_with].cp;
+  // every workgroup writes wg_times[2 * blockIdx.x ..]: the buffer is sized from the grid, known BEFORE anything is launched
+  const int grid = e->ops[op_index].info.grid;
+  if (grid < 1 || 2 * grid + 2 > cap) return -UNINA_ERR_ARG;
   long long* d = nullptr;
-  if (hipMalloc(&d, sizeof(long long) * (18 + 2 * 4096)) != hipSuccess) return -UNINA_ERR_HIP;
-  hipMemsetAsync(d, 0, sizeof(long long) * (18 + 2 * 4096), stream);
-  long long* marks = d + 16 + 2 * 4096;
+  const size_t words = 18 + 2 * (size_t)grid;
+  if (hipMalloc(&d, sizeof(long long) * words) != hipSuccess) return -UNINA_ERR_HIP;
+  long long* marks = d + 16 + 2 * grid;
   pa.stamps = d;
   pb.stamps = d + 8;
   pa.wg_times = pb.wg_times = d + 16;
-  int grid = 0;
-  hipLaunchKernelGGL(unina::debug_stamp_kernel, dim3(1), dim3(64), 0, stream, marks);
-  hipError_t he = conv_dual_launch(op.dual_kind, pa, pb, stream, &grid);
-  hipLaunchKernelGGL(unina::debug_stamp_kernel, dim3(1), dim3(64), 0, stream, marks + 1);
+  int launched = 0;
+  hipError_t he = hipMemsetAsync(d, 0, sizeof(long long) * words, stream);
+  if (he == hipSuccess) {
+    hipLaunchKernelGGL(unina::debug_stamp_kernel, dim3(1), dim3(64), 0, stream, marks);
+    he = hipGetLastError();
+  }
+  if (he == hipSuccess) he = conv_dual_launch(op.dual_kind, pa, pb, stream, &launched);
+  if (he == hipSuccess) {
+    hipLaunchKernelGGL(unina::debug_stamp_kernel, dim3(1), dim3(64), 0, stream, marks + 1);
+    he = hipGetLastError();
+  }
   if (he == hipSuccess) he = hipStreamSynchronize(stream);
-  const bool fits = grid <= 4096 && 2 * grid + 2 <= cap;
-  if (he == hipSuccess && fits) he = hipMemcpy(out, d + 16, sizeof(long long) * 2 * grid, hipMemcpyDeviceToHost);
-  if (he == hipSuccess && fits) he = hipMemcpy(out + 2 * grid, marks, sizeof(long long) * 2, hipMemcpyDeviceToHost);
-  hipFree(d);
-  if (he != hipSuccess) return -UNINA_ERR_HIP;
-  return fits ? grid : -UNINA_ERR_ARG;
+  if (he == hipSuccess && launched != grid) he = hipErrorInvalidValue;     // (the planner's grid is the launch's)
+  if (he == hipSuccess) he = hipMemcpy(out, d + 16, sizeof(long long) * 2 * grid, hipMemcpyDeviceToHost);
+  if (he == hipSuccess) he = hipMemcpy(out + 2 * grid, marks, sizeof(long long) * 2, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  return he == hipSuccess ? grid : -UNINA_ERR_HIP;
 }
 
 int unina_op_count(const unina_engine_t* e) { return e ? (int)e->ops.size() : -1; }
@@ -2124,28 +2138,34 @@ int unina_profile_post(unina_engine_t* e, int iters, float conf, float iou, floa
   LaunchDesc d[2];
   const int npost = postprocess_desc(pp, d);
   if (npost < 1) return fail(e, UNINA_ERR_STATE, "post-process launch shape");
-  hipEvent_t ev[3];
-  for (auto& x : ev) HIPCHK(e, hipEventCreate(&x));
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   ms2[0] = ms2[1] = 0.f;
-  for (int it = 0; it < iters; ++it) {
-    int rc = launch_all(e, stream);
-    if (rc != UNINA_OK) return rc;
-    for (int k = 0; k < npost; ++k) {
-      PostParams copy = pp;
-      void* args[] = {&copy};
-      HIPCHK(e, hipEventRecord(ev[k], stream));
-      HIPCHK(e, hipLaunchKernel(d[k].func, d[k].grid, d[k].block, args, d[k].shmem, stream));
+  // (the events are destroyed on every path out of here)
+  auto run = [&]() -> int {
+    for (auto& x : ev) HIPCHK(e, hipEventCreate(&x));
+    for (int it = 0; it < iters; ++it) {
+      int rc = launch_all(e, stream);
+      if (rc != UNINA_OK) return rc;
+      for (int k = 0; k < npost; ++k) {
+        PostParams copy = pp;
+        void* args[] = {&copy};
+        HIPCHK(e, hipEventRecord(ev[k], stream));
+        HIPCHK(e, hipLaunchKernel(d[k].func, d[k].grid, d[k].block, args, d[k].shmem, stream));
+      }
+      HIPCHK(e, hipEventRecord(ev[npost], stream));
+      HIPCHK(e, hipEventSynchronize(ev[npost]));
+      for (int k = 0; k < npost; ++k) {
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+        ms2[k] += ms / (float)iters;
+      }
     }
-    HIPCHK(e, hipEventRecord(ev[npost], stream));
-    HIPCHK(e, hipEventSynchronize(ev[npost]));
-    for (int k = 0; k < npost; ++k) {
-      float ms = 0.f;
-      HIPCHK(e, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
-      ms2[k] += ms / (float)iters;
-    }
-  }
-  for (auto& x : ev) (void)hipEventDestroy(x);
-  return UNINA_OK;
+    return UNINA_OK;
+  };
+  const int rc = run();
+  for (auto& x : ev)
+    if (x) (void)hipEventDestroy(x);
+  return rc;
 }
 
 int unina_debug_read_buffer(unina_engine_t* e, const char* name, float* host_out, size_t capacity, int* c, int* h, int* w) {

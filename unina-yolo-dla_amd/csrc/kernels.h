@@ -82,6 +82,7 @@ enum ConvConfig : int {
   kCfgRegqW8x16n128c128, kCfgRegqW8x8n128c256,
   kCfgRegq16x16n64c128, kCfgRegq8x16n64c256,
   kCfgWs16x16n64c128, kCfgWs8x16n64c256,
+  kCfgWsS8x16n64c64, kCfgWsS8x16n64c128, kCfgWsS8x16n64c256,   // split fp16 (STRICT engines): weights-stationary, row-walking, channel-chunked
   kCfgCount
 };
 struct ConvLaunch {

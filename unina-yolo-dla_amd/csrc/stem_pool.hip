@@ -315,7 +315,11 @@ hipError_t stem_desc(const StemParams& p, LaunchDesc* out) {
   if (!p.wt) return hipErrorInvalidValue;
   out->block = dim3(256);
   static const bool legacy = getenv("UNINA_STEM_V1") && getenv("UNINA_STEM_V1")[0] == '1';   // the one-thread-per-pixel form
-  if (!legacy && (p.W & 3) == 0 && ((uintptr_t)p.src & 15) == 0 && p.dst_ld == p.Co) {
+  // The form depends on the SHAPE only, never on the pointer of the frame at hand: the captured frame graph's stem node is
+  // re-pointed per frame (hipGraphExecKernelNodeSetParams) and must keep its function, grid and block. The tiled kernel's aligned
+  // 16-byte row loads need W % 4 == 0 and a 16-byte aligned tensor -- which unina_set_tensor_address / unina_infer guarantee
+  // (they refuse any other address with UNINA_ERR_ARG).
+  if (!legacy && (p.W & 3) == 0 && p.dst_ld == p.Co) {
     out->block = dim3(kStemNT);
     out->grid = dim3(((p.Ho + kStemTH - 1) / kStemTH) * ((p.Wo + kStemTW - 1) / kStemTW));
     if (p.Co == 32 && p.dtype == kF16) { out->func = reinterpret_cast<const void*>(&stem_tile_kernel<half_t, 32>); out->shmem = stem_tile_smem<half_t, 32>(); }

@@ -150,7 +150,10 @@ class Engine:
         self._check(self.L.unina_engine_input_dims(self.h, C.byref(w), C.byref(h), C.byref(nc)))
         self.width, self.height, self.num_classes = w.value, h.value, nc.value
         dev = torch.device("cuda", device)
-        # the caller (this wrapper) owns the I/O buffers, as the node does (perception_node.cpp:696-707)
+        # the caller (this wrapper) owns the I/O buffers, as the node does (perception_node.cpp:696-707).
+        # self.outputs holds the six raw head tensors as enqueue() / forward() write them. infer() / infer_async() do NOT
+        # update them (the heads' output convs run inside the decode launch, include/unina_mi355.h at unina_infer): after
+        # an infer call they still hold the previous forward()'s values.
         self.outputs: Dict[str, "torch.Tensor"] = {}
         for name, s in zip(OUTPUT_NAMES, (4, 4, 8, 8, 16, 16)):
             c = nc.value if name.endswith("cls") else 4

@@ -600,10 +600,18 @@ class HistogramCalibrator:
     def collect(self, x: np.ndarray) -> None:
         a = np.abs(np.asarray(x, dtype=np.float32)).reshape(-1)
         amax = float(a.max()) if a.size else 0.0
+        if self.hist is not None and self.edges[-1] <= 1e-6 and amax > self.edges[-1]:
+            # everything seen so far was (numerically) zero -- a dead buffer on the first frames: its range (0, 1e-8) must not be
+            # GROWN by whole bins (1e12 of them for an ordinary activation); start over from this batch, the zeros go to bin 0
+            zeros = float(self.hist.sum())
+            self.hist = None
+        else:
+            zeros = 0.0
         if self.hist is None:
             amax = max(amax, 1e-8)
             self.hist, self.edges = np.histogram(a, bins=self.num_bins, range=(0.0, amax))
             self.hist = self.hist.astype(np.float64)
+            self.hist[0] += zeros
             return
         if amax > self.edges[-1]:                      # grow the range by whole bins of the same width
             width = self.edges[1] - self.edges[0]
