@@ -92,7 +92,6 @@ def main():
     ap.add_argument("--calibrator", choices=["max", "percentile", "entropy", "mse"], default="mse", help="INT8 activation range selection")
     ap.add_argument("--variant", choices=["A", "B"], default="A",
                     help="A = model.py's graph (BASELINE configs); B = qat.py's topology (stride-32 stage, third FPN level)")
-    ap.add_argument("--streams", type=int, default=0, help="parallel graph paths per engine (0 = library default)")
     ap.add_argument("--tune-cache", default=os.environ.get("UNINA_TUNE_CACHE", ""), help="tactic cache file (JSON)")
     args = ap.parse_args()
 
@@ -101,8 +100,6 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE')} ranks")
 
-    if args.streams > 0:
-        os.environ["UNINA_STREAMS"] = str(args.streams)
     import torch
     import torch.distributed as dist
     import unina_yolo_dla_amd as u

@@ -700,30 +700,6 @@ def test_frame_graph_and_tiled_nms_match_the_plain_forms(pkg, sd7, torch_cuda, m
     assert len(fast[3]) > len(fast[0]) and fast[0] == fast[4] and fast[0] != fast[1]
 
 
-def test_opt_in_stem_fusion_is_bit_identical(pkg, sd7, torch_cuda, monkeypatch):
-    """UNINA_STEM_FUSE=1: backbone.stem computed inside stage1_conv's launch (same fp32 fma chain into the LDS patch).
-    In the default graph stage1_conv now runs as the first step of stage1_block's kernel, so the stem + conv kernel only
-    applies to the lite_p2 variant (model.py:184-190: stage1 is a plain ConvBlock there)."""
-    from unina_yolo_dla_amd.engine import Engine
-    x = _frame(pkg, torch_cuda, 1234, 640)
-    gl = pkg.graph.Graph(lite_p2=True)
-    sdl = pkg.synth.make_state_dict(7, gl)
-
-    def run():
-        e = Engine.from_state_dict(sdl, gl)
-        try:
-            return e.infer(x).tobytes(), e.forward(x), e.L.unina_fusion_groups(e.h)
-        finally:
-            e.close()
-
-    d0, h0, g0 = run()
-    monkeypatch.setenv("UNINA_STEM_FUSE", "1")
-    d1, h1, g1 = run()
-    assert (g0, g1) == (8, 9) and d0 == d1
-    for k in h0:
-        assert np.array_equal(h0[k], h1[k]), k
-
-
 def test_async_result_layout(pkg, eng640, torch_cuda):
     x = _frame(pkg, torch_cuda, 1234, 640)
     sync = eng640.infer(x)

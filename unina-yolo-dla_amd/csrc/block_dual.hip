@@ -49,16 +49,7 @@ BLOCK_DUAL_WS(block_dual_c3k2_128x384_head64ws, 128, 4, 4, 1, 384, 8, 16, 0)
 BLOCK_DUAL_WS(block_dual_c3k2i8_128x384_head64ws, 128, 4, 4, 1, 384, 8, 8, 0, EltI8)
 #undef BLOCK_DUAL_WS
 
-// One workgroup per CU: the head on 16x16 tiles (100 workgroups at 640^2) next to the block's 100 (UNINA_HEAD_ALT=2).
-// Measured slower than the default (29.0 vs 27.2 us): kept as an A/B knob only.
-__global__ __launch_bounds__(512) void block_dual_c3k2_128x384_head64_big(const C3k2Params pc, const HeadParams ph, int nc) {
-  if ((int)blockIdx.x < nc) c3k2_fused_body<128, 4, 4, 1, 384, 8, 16, 0>(pc, (int)blockIdx.x, bd_smem);
-  else head_fused_body<64, 16, 16, 8, 16>(ph, (int)blockIdx.x - nc, bd_smem);
-}
-
 hipError_t block_dual_init() {
-  if (hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(block_dual_c3k2_128x384_head64_big),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e0 != hipSuccess) return e0;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(block_dual_c3k2_128x384_head64),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
@@ -79,7 +70,7 @@ bool block_dual_match(const C3k2Params& pc, const HeadParams& ph) {
            (pc.cpre == 0 || (pc.cpre == 128 && pc.cx == 128)) && c3k2_tile_is(pc, 4, 4);
   const bool pre_ok = pc.cpre == 0 || (pc.cpre == 128 && pc.cx == 128 && head_tile_is(ph, 8, 16));
   return (pc.dtype == kF16 || pc.dtype == kI8) && pc.hid == 128 && pc.nb == 1 && pc.Cin == 384 && pc.tail == 0 && ph.C == 64 && pre_ok &&
-         c3k2_tile_is(pc, 4, 4) && (head_tile_is(ph, 8, 16) || (head_tile_is(ph, 16, 16) && pc.dtype == kF16));
+         c3k2_tile_is(pc, 4, 4) && head_tile_is(ph, 8, 16);
 }
 
 const char* block_dual_name(int dtype, int cpre) {
@@ -107,8 +98,6 @@ hipError_t block_dual_launch(const C3k2Params& pc, const HeadParams& ph, hipStre
     hipLaunchKernelGGL(block_dual_s2c3k2i8_128x384_head64, dim3(nc + nh, 1, 1), dim3(512, 1, 1), smem, stream, pc, ph, nc);
   else if (pc.cpre)
     hipLaunchKernelGGL(block_dual_s2c3k2_128x384_head64, dim3(nc + nh, 1, 1), dim3(512, 1, 1), smem, stream, pc, ph, nc);
-  else if (head_tile_is(ph, 16, 16))
-    hipLaunchKernelGGL(block_dual_c3k2_128x384_head64_big, dim3(nc + nh, 1, 1), dim3(512, 1, 1), smem, stream, pc, ph, nc);
   else if (pc.dtype == kI8)
     hipLaunchKernelGGL(block_dual_c3k2i8_128x384_head64, dim3(nc + nh, 1, 1), dim3(512, 1, 1), smem, stream, pc, ph, nc);
   else

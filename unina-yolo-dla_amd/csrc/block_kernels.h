@@ -294,24 +294,8 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
       [&](int sub, int n, const acc_t& acc) {
         const int pp = sub * 16 + l15;
         if (pp >= PT) return;
-#if UNINA_BLOCK_DIRECT_STORE
-        if constexpr (!TAIL && !E::I8) {
-          if (!p.dst_q) {   // fp16 block without a tail step or an int8 twin: 8 bytes per lane straight to HBM, no staging pass
-            const int oy = ty0 + pp / TW, ox = tx0 + pp % TW;
-            if (oy < p.H && ox < p.W)
-              store4<E, 2 * H_>(static_cast<unsigned char*>(p.dst) + ((size_t)(oy * p.W + ox) * p.dst_ld + n) * ESZ,
-                                act_relu<E, 2 * H_>(acc, CST(S3), n), CST(S3), n, p.dst_lo);
-            return;
-          }
-        }
-#endif
         store4<E, 2 * H_>(stage + pp * ROWB + n * ESZ, act_relu<E, 2 * H_>(acc, CST(S3), n), CST(S3), n, lds_lo);
       });
-#if UNINA_BLOCK_DIRECT_STORE
-  if constexpr (!TAIL && !E::I8) {
-    if (!p.dst_q) return;
-  }
-#endif
   stamp(8);
   typedef float vec16 __attribute__((ext_vector_type(4)));  // 16 opaque bytes
   constexpr int CPR = 2 * H_ * ESZ / 16;                    // 16-byte chunks per output pixel

@@ -9,12 +9,6 @@
 #pragma once
 #include <type_traits>
 
-#ifndef UNINA_BLOCK_FAKE_ADDR
-#define UNINA_BLOCK_FAKE_ADDR 0   // timing experiments (results invalid): 1 = run_step reads its fragments at lane base + immediate (no
-                                  // address arithmetic: -0.2..-1.3 us per block kernel, -4.6 us per frame at most); 2 = no weight loads after
-                                  // the first D blocks of a wave
-#endif
-
 #include "mfma_common.h"
 
 namespace unina {
@@ -120,11 +114,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Element G of this wave's flat weight sequence -> queue slot G % D. wbase = stream + this lane's 16 bytes of a block.
 template <typename ST, int D, int G, typename FRAG>
 __device__ __forceinline__ void wq_fetch(FRAG (&q)[D], const unsigned char* wbase, int wid) {
-#if UNINA_BLOCK_FAKE_ADDR == 2   // timing experiment only (results invalid): no weight loads after the first D blocks
-  if constexpr (G < D) {
-#else
   if constexpr (G < ST::total()) {
-#endif
     constexpr int s = ST::step_of(G), e = G - ST::first(s), wnt = ST::wnt(s), kb = e / wnt, j = e - kb * wnt, ns = ST::ns(s);
     const int nsub = (wid % ST::waves_n(s)) * wnt + j;
     constexpr int WBLK = (int)sizeof(FRAG) * 64;   // 1 KiB, or the 2-KiB (hi | lo) pair of the split type
@@ -156,12 +146,7 @@ __device__ __forceinline__ void run_step(typename E::frag (&q)[D], const unsigne
   const int wm = wid / WVN, wn = wid % WVN, lq = lane >> 4;
   acc_t acc[WN_T][WM_T];
   frag b[2][WM_T];
-#if UNINA_BLOCK_FAKE_ADDR == 1   // timing experiment only (results invalid): fragment reads at lane base + immediate, no address arithmetic
-  const int fake_base = lane * 16;
-  auto baddr_t = [&](int sub, auto kc) { return fake_base + (((sub % WM_T) * KB + decltype(kc)::value) * 1024) % 32768; };
-#else
   auto& baddr_t = baddr;
-#endif
 #pragma unroll
   for (int i = 0; i < WM_T; ++i) {
 #pragma unroll
@@ -337,9 +322,6 @@ __device__ __forceinline__ void load_patch(unsigned char* lds_img, const void* s
                                    // A/B at 2 frames in flight: 8 270-8 470 frames/s with LDS-DMA against 8 130-8 200 through registers;
                                    // the register-queue 3x3 kernels (conv_igemm.hip) go the other way: 8 240-8 360 against 8 130-8 170)
 #endif
-#ifndef UNINA_BLOCK_DIRECT_STORE
-#define UNINA_BLOCK_DIRECT_STORE 0
-#endif
 // The same patch through REGISTERS: plain 16-byte global loads (all requested back to back: ~16 cycles of issue each, against
 // the 60-185 cycles an LDS-DMA piece costs the issuing wave), then ds_write_b128 once they have landed -- the compiler's
 // counted s_waitcnt vmcnt leaves whatever was requested after them (the weight queue) in flight. Same LDS image.
@@ -348,32 +330,6 @@ struct PatchRegs {
   static constexpr int nchx = CIN / E::CH, nslots = RH * RW * nchx, ITER = (nslots + NT - 1) / NT;
   floatx4 v[ITER];
 };
-// Index arithmetic kept short: 32-bit offsets, the chunk index is the same in every iteration (NT is a multiple of the
-// chunks per pixel), and no branch -- a pixel outside the image is loaded from a clamped address and zeroed by a select
-// (with a branch per load and 64-bit pointer arithmetic this prologue was ~770 instructions per wave: 2.5 us before the
-// first weight block was requested).
-template <int RH, int RW, int CIN, int NT, typename E = EltH>
-__device__ __forceinline__ void patch_issue_nobranch(PatchRegs<RH, RW, CIN, NT, E>& pr, const void* src_, int src_ld, int H, int W, int y0,
-                                            int x0, int wid, int lane) {
-  typedef PatchRegs<RH, RW, CIN, NT, E> PR;
-  constexpr Img X = make_img(0, CIN / E::CH);
-  static_assert(NT % PR::nchx == 0, "the chunk index must not depend on the iteration");
-  const unsigned char* src = static_cast<const unsigned char*>(src_);
-  const int ls = wid * 64 + lane;
-  const int cs = ls % PR::nchx, r0 = ls / PR::nchx;
-  const int pitch = src_ld * E::ESZ;                    // bytes per pixel
-#pragma unroll
-  for (int it = 0; it < PR::ITER; ++it) {
-    const int r = r0 + it * (NT / PR::nchx);
-    const int ry = r / RW, rx = r - ry * RW;
-    const int iy = y0 + ry, ix = x0 + rx;
-    const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && r < RH * RW;
-    const int iyc = iy < 0 ? 0 : (iy < H ? iy : H - 1), ixc = ix < 0 ? 0 : (ix < W ? ix : W - 1);
-    const unsigned off = (unsigned)((iyc * W + ixc) * pitch + ((cs ^ X.key(r)) << 4));
-    const floatx4 v = *reinterpret_cast<const floatx4*>(src + off);
-    pr.v[it] = inside ? v : floatx4{0.f, 0.f, 0.f, 0.f};
-  }
-}
 // The form in use: a branch around each load (out-of-image pixels are not fetched). Same-box A/B (tools/ab_run.sh, regq head
 // pairs): LDS-DMA 19.8 us, this 18.9 us, the branch-free clamped form above 20.5 us per pair.
 template <int RH, int RW, int CIN, int NT, typename E = EltH>

@@ -737,70 +737,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo(const ConvParams p) {
 // the weight-heavy head layers at 80^2 / 40^2 (590 KB / 2.4 MB of weights per launch) are bound by exactly that.
 // fp16 only; Cin is a template parameter (the K loop is unrolled at compile time so queue slots are registers).
 // Same MFMA, same K order (tap-major, 32 channels per block), same epilogue as the other kernels: bit-identical.
-// The fp32 stem (model.py:175: ConvBlock(3, c1, 3, stride 2) on the NCHW frame) computed straight into the patch image:
-// every patch pixel that lies inside the stem's output is the same sequential fma chain (k = 0..26 from the bias) as
-// stem_conv_kernel, two threads per pixel (half of the CO channels each, v_pk_fma_f32), ReLU, fp16 -- what the stem would
-// have stored to HBM; pixels outside are the conv's zero padding. `img` = LDS patch image of CO channels per pixel.
-template <int RH, int RW, int CO, int NT>
-__device__ __forceinline__ void stem_patch(unsigned char* smem, unsigned char* wlds, const StemParams& sp, int y0, int x0) {
-  typedef float floatx2 __attribute__((ext_vector_type(2)));
-  constexpr int CH = CO / 2;
-  constexpr Img X = make_img(0, CO / 8);
-  float* sw = reinterpret_cast<float*>(wlds);   // [27][CO] then [CO] biases
-  float* sb = sw + 27 * CO;
-  for (int i = threadIdx.x; i < CO * 27; i += NT) sw[(i % 27) * CO + (i / 27)] = sp.w[i];
-  for (int i = threadIdx.x; i < CO; i += NT) sb[i] = sp.bias[i];
-  __syncthreads();
-  const size_t plane = (size_t)sp.H * sp.W;
-  for (int g = threadIdx.x; g < 2 * RH * RW; g += NT) {
-    const int r = g >> 1, c0 = (g & 1) * CH;
-    const int ry = r / RW, rx = r - ry * RW;
-    const int oy = y0 + ry, ox = x0 + rx;        // stem-output coordinates of this patch pixel
-    floatx2 acc[CH / 2];
-    const bool inside = (unsigned)oy < (unsigned)sp.Ho && (unsigned)ox < (unsigned)sp.Wo;
-    if (inside) {
-      float x[27];
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int iy = oy * 2 + kh - 1;
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int ix = ox * 2 + kw - 1;
-            const bool ok = iy >= 0 && iy < sp.H && ix >= 0 && ix < sp.W;
-            x[(c * 3 + kh) * 3 + kw] = ok ? sp.src[c * plane + (size_t)iy * sp.W + ix] : 0.f;
-          }
-        }
-#pragma unroll
-      for (int q = 0; q < CH / 2; ++q) acc[q] = *reinterpret_cast<const floatx2*>(&sb[c0 + 2 * q]);
-#pragma unroll
-      for (int k = 0; k < 27; ++k) {
-        const floatx2 xk = {x[k], x[k]};
-#pragma unroll
-        for (int q = 0; q < CH / 2; q += 2) {
-          const float4 w4 = *reinterpret_cast<const float4*>(&sw[k * CO + c0 + 2 * q]);
-          acc[q] = __builtin_elementwise_fma(xk, floatx2{w4.x, w4.y}, acc[q]);
-          acc[q + 1] = __builtin_elementwise_fma(xk, floatx2{w4.z, w4.w}, acc[q + 1]);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < CH / 2; ++q) acc[q] = floatx2{0.f, 0.f};
-    }
-#pragma unroll
-    for (int ch = 0; ch < CH / 8; ++ch) {
-      half8 hv;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float a = acc[(ch * 8 + e) >> 1][(ch * 8 + e) & 1];
-        hv[e] = (half_t)(a > 0.f ? a : 0.f);
-      }
-      *reinterpret_cast<half8*>(smem + X.addr(r, c0 / 8 + ch)) = hv;
-    }
-  }
-}
-
 // WN = 16-channel subtiles per wave (each activation fragment then feeds WN MFMAs: halves the LDS reads per MFMA at 2).
 // T = half_t, or signed char (INT8 engines: int8 patch image, 64-k weight blocks, v_mfma_i32_16x16x64_i8).
 #ifndef UNINA_PATCH_VIA_REGS
@@ -810,13 +746,12 @@ constexpr bool kPatchViaRegs = UNINA_PATCH_VIA_REGS != 0;   // input patch: 16-b
 // STAMPS (debug instantiations only: a branch around the loads would change the schedule of the product kernels): phase
 // stamps of the conv's mid workgroup -- 0 start, 1 patch DMA + first weight blocks issued, 2 patch landed (barrier passed),
 // 3 K loop done, 4 stores issued.
-template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, bool STEM = false, int WN = 1, typename T = half_t, bool STAMPS = false>
-__device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, int nwg, const StemParams* sp = nullptr) {
+template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, int WN = 1, typename T = half_t, bool STAMPS = false>
+__device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, int nwg) {
   typedef Elem<T> E;
   typedef typename E::frag frag;
   constexpr bool SPLIT = E::kPlanes == 2;
   typedef typename std::conditional<sizeof(T) == 1, EltI8, typename std::conditional<SPLIT, EltS, EltH>::type>::type PE;   // block_pipeline.h element traits of T
-  static_assert(!STEM || (sizeof(T) == 2 && !SPLIT), "the stem patch is fp16");
   // S = stride (1 or 2): the patch is the (S*TH + 2 or S*TH + 1) x (...) input footprint of the tile
   constexpr int BM = TH * TW, R0W = S * (TW - 1) + 3, R0H = S * (TH - 1) + 3, NT = NW * 64, CB = CIN / E::kBlockK, KB = 9 * CB;
   static_assert(CIN % E::kBlockK == 0, "a weight block must not straddle a tap");
@@ -855,20 +790,13 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
   constexpr int LDS_LO = SPLIT ? ((R0H * R0W * CIN * 2 + 1023) / 1024) * 1024 + 1024 : 0;
 
   constexpr Img X = make_img(0, CIN / E::kChunk);
-  if constexpr (STEM) {
-    static_for<0, D>(fetch);   // weights first: they are in flight while the stem patch is computed
-    constexpr int PATCH = ((R0H * R0W * CIN * 2 + 1023) / 1024) * 1024;
-    stem_patch<R0H, R0W, CIN, NT>(conv_smem, conv_smem + PATCH, *sp, S * ty0 - 1, S * tx0 - 1);
-  } else if constexpr (SPLIT) {   // both planes by LDS-DMA (twice the registers of a register-staged patch would not fit)
+  if constexpr (SPLIT) {   // both planes by LDS-DMA (twice the registers of a register-staged patch would not fit)
     load_patch<R0H, R0W, CIN, NT, PE>(conv_smem, static_cast<const T*>(p.src) + sg.src_coff, p.src_ld, p.H, p.W, S * ty0 - 1,
                                       S * tx0 - 1, p.zeros, wid, lane, p.src_lo, LDS_LO);
     static_for<0, D>(fetch);
   } else if constexpr (kPatchViaRegs) {
     PatchRegs<R0H, R0W, CIN, NT, PE> pr;
-    if constexpr (UNINA_PATCH_VIA_REGS == 2)
-      patch_issue_nobranch<R0H, R0W, CIN, NT, PE>(pr, static_cast<const T*>(p.src) + sg.src_coff, p.src_ld, p.H, p.W, S * ty0 - 1, S * tx0 - 1, wid, lane);
-    else
-      patch_issue<R0H, R0W, CIN, NT, PE>(pr, static_cast<const T*>(p.src) + sg.src_coff, p.src_ld, p.H, p.W, S * ty0 - 1, S * tx0 - 1, wid, lane);
+    patch_issue<R0H, R0W, CIN, NT, PE>(pr, static_cast<const T*>(p.src) + sg.src_coff, p.src_ld, p.H, p.W, S * ty0 - 1, S * tx0 - 1, wid, lane);
     static_for<0, D>(fetch);
     if constexpr (STAMPS) stamp_b(p, 1, bid, nwg);
     patch_commit<R0H, R0W, CIN, NT, PE>(pr, conv_smem, wid, lane);
@@ -879,8 +807,8 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
   }
   EpiConsts<WN> ec;
   load_epi_consts<WN>(sg, nb0 + wn * (WN * 16), lq, ec);
-  if constexpr (STAMPS && (STEM || SPLIT || !kPatchViaRegs)) stamp_b(p, 1, bid, nwg);
-  if constexpr (STEM || SPLIT || !kPatchViaRegs) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
+  if constexpr (STAMPS && (SPLIT || !kPatchViaRegs)) stamp_b(p, 1, bid, nwg);
+  if constexpr (SPLIT || !kPatchViaRegs) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the patch has landed
   lds_barrier();
   if constexpr (STAMPS) stamp_b(p, 2, bid, nwg);
 
@@ -931,7 +859,7 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
 
 template <int TH, int TW, int BN, int CIN, int NW, int D, int S = 1, int WN = 1, typename T = half_t>
 __global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
-  conv3x3_regq_body<TH, TW, BN, CIN, NW, D, S, false, WN, T>(p, (int)blockIdx.x, (int)gridDim.x);
+  conv3x3_regq_body<TH, TW, BN, CIN, NW, D, S, WN, T>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ============================================================================================ 3x3 weights-stationary kernel
@@ -944,10 +872,6 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
 // accumulators are live (a row is converted and stored while the next ones are being accumulated). Each output row still
 // receives its products in the order ky, kx, cb from a zero accumulator, i.e. the K order of every other conv kernel:
 // results are bit-identical.
-#ifndef UNINA_WS_STORE_AUX
-#define UNINA_WS_STORE_AUX 0   // cache policy bits of the output stores. 16 = sc1 (write-through: no dirty L2 lines at the kernel boundary) was
-                               // tried: the launch itself 17.4 vs 17.8-18.0 us event-timed, serial latency and frames/s unchanged (same-box A/B)
-#endif
 template <int TH, int CIN, int NW, bool STAMPS = false, typename T = half_t>
 __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, int nwg) {
   typedef Elem<T> E;     // half_t, or signed char (INT8 engines: int8 patch, 64-k weight blocks, exact int32 accumulators)
@@ -1055,7 +979,7 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
 #pragma unroll
       for (int e = 0; e < 4; ++e) hv[e] = (half_t)(v[e] > 0.f ? v[e] : 0.f);
       typedef float floatx2 __attribute__((ext_vector_type(2)));
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs, voff0 + (unsigned)r * rowb, 0, UNINA_WS_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs, voff0 + (unsigned)r * rowb, 0, 0);
     } else {   // the per-op kernels' int8 epilogue operation for operation (conv_epilogue): fma, ReLU, then fp16 or rint(y / s_out), clamp
       const floatx4 c = E::to_float(acc[r & 3]);
       float v[4];
@@ -1069,7 +993,7 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
 #pragma unroll
         for (int e = 0; e < 4; ++e) hv[e] = (half_t)v[e];
         typedef float floatx2 __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs, voff0 + (unsigned)r * rowb, 0, UNINA_WS_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs, voff0 + (unsigned)r * rowb, 0, 0);
       } else {
         unsigned q = 0;
 #pragma unroll
@@ -1078,7 +1002,7 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
           t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
           q |= ((unsigned)(int)t & 0xFFu) << (8 * e);
         }
-        __builtin_amdgcn_raw_buffer_store_b32(q, drs, voff0 + (unsigned)r * rowb, 0, UNINA_WS_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(q, drs, voff0 + (unsigned)r * rowb, 0, 0);
       }
     }
   };
@@ -1309,16 +1233,6 @@ __global__ __launch_bounds__(256) void conv_dual_head3x3_ws_s16(const ConvParams
 }
 
 #ifndef UNINA_CONV_PROBE   // (ISA probe builds stop here: tools/isa_probe.sh compiles only the kernels above)
-// backbone.stem -> backbone.stage1_conv as ONE launch: the 3x3/s2 conv's input patch is the stem's output, computed in
-// place (stem_patch) instead of being written to HBM by one launch and DMA'd back by the next (6.6 MB each way at 640^2).
-struct StemConvParams {
-  StemParams stem;
-  ConvParams conv;
-};
-__global__ __launch_bounds__(512, 2) void stem_conv3x3s2_kernel(const StemConvParams p) {
-  conv3x3_regq_body<8, 16, 64, 32, 8, 8, 2, true>(p.conv, (int)blockIdx.x, (int)gridDim.x, &p.stem);
-}
-
 // ================================================================================================ dual launches
 // Two INDEPENDENT convs of the same kernel family in ONE grid: workgroups [0, na) run conv A, the rest conv B. The P3
 // and P4 head layers (model.py:361-365) are such pairs: each alone half-fills the chip (200 workgroups) and sits on the
@@ -1333,31 +1247,13 @@ __global__ __launch_bounds__(512, 4) void conv_dual_head3x3(const ConvParams pa,
 }
 // INT8 engines: the same pair on int8 inputs (P3 | P4 head layers .0 and .1 are int8 convs there)
 __global__ __launch_bounds__(512, 4) void conv_dual_head3x3_i8(const ConvParams pa, const ConvParams pb, int na) {
-  if ((int)blockIdx.x < na) conv3x3_regq_body<8, 16, 64, 128, 8, 8, 1, false, 1, signed char>(pa, (int)blockIdx.x, na);
-  else conv3x3_regq_body<8, 8, 64, 256, 8, 8, 1, false, 1, signed char>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
+  if ((int)blockIdx.x < na) conv3x3_regq_body<8, 16, 64, 128, 8, 8, 1, 1, signed char>(pa, (int)blockIdx.x, na);
+  else conv3x3_regq_body<8, 8, 64, 256, 8, 8, 1, 1, signed char>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
 }
 // STRICT engines: the same pair on split-fp16 tensors (hi / lo patch images: one workgroup per CU)
 __global__ __launch_bounds__(512) void conv_dual_head3x3_s16(const ConvParams pa, const ConvParams pb, int na) {
-  if ((int)blockIdx.x < na) conv3x3_regq_body<8, 16, 64, 128, 8, 8, 1, false, 1, s16_t>(pa, (int)blockIdx.x, na);
-  else conv3x3_regq_body<8, 8, 64, 256, 8, 8, 1, false, 1, s16_t>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
-}
-// Twice the pixels per workgroup (16x16 | 8x16): 100 + 104 workgroups at 640^2 -- ONE per CU instead of up to two, so the
-// busiest CU streams one workgroup's weights (147 / 295 KB) instead of two's, with a full-depth queue.
-__global__ __launch_bounds__(512) void conv_dual_head3x3_big(const ConvParams pa, const ConvParams pb, int na) {
-  if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 16, 1>(pa, (int)blockIdx.x, na);
-  else conv3x3_regq_body<8, 16, 64, 256, 8, 16, 1>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
-}
-// (Tried on these tiles and dropped, same-box A/B in DESIGN.md 7: four waves with two channel subtiles each, 30 us per pair;
-// a 32-deep weight queue, 21-22 us; two subtiles per wave for the P3 conv only, 21 us; 128-channel workgroup tiles, slower
-// than the 64-channel ones. The weights-stationary pair below replaced the search.)
-// debug twin of conv_dual_head3x3_big with in-kernel phase stamps (unina_debug_dual_stamps)
-__global__ __launch_bounds__(512) void conv_dual_head3x3_big_stamped(const ConvParams pa, const ConvParams pb, int na) {
-  if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 16, 1, false, 1, half_t, true>(pa, (int)blockIdx.x, na);
-  else conv3x3_regq_body<8, 16, 64, 256, 8, 16, 1, false, 1, half_t, true>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
-}
-__global__ __launch_bounds__(512) void conv_dual_head3x3_big_i8(const ConvParams pa, const ConvParams pb, int na) {
-  if ((int)blockIdx.x < na) conv3x3_regq_body<16, 16, 64, 128, 8, 16, 1, false, 1, signed char>(pa, (int)blockIdx.x, na);
-  else conv3x3_regq_body<8, 16, 64, 256, 8, 16, 1, false, 1, signed char>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
+  if ((int)blockIdx.x < na) conv3x3_regq_body<8, 16, 64, 128, 8, 8, 1, 1, s16_t>(pa, (int)blockIdx.x, na);
+  else conv3x3_regq_body<8, 8, 64, 256, 8, 8, 1, 1, s16_t>(pb, (int)blockIdx.x - na, (int)gridDim.x - na);
 }
 __global__ __launch_bounds__(256) void conv_dual_head1x1(const ConvParams pa, const ConvParams pb, int na) {
   if ((int)blockIdx.x < na) conv_glds_body<half_t, 128, 16, 64, 4, 1, 4>(pa, (int)blockIdx.x, na);
@@ -1398,9 +1294,6 @@ constexpr size_t smem_of() {
 #define REGQ(TH, TW, BN, CIN, NW, D)                                                                 \
   {(TH) * (TW), BN, 32, 3, "conv3x3_regq<f16," #TH "x" #TW "," #BN "," #CIN "," #NW "w>",                \
    conv3x3_regq<TH, TW, BN, CIN, NW, D>, 0, TH, TW, CIN, (NW) * 64, 1}
-#define REGQW(TH, TW, BN, CIN, NW, D)                                                                \
-  {(TH) * (TW), BN, 32, 3, "conv3x3_regq<f16," #TH "x" #TW "," #BN "," #CIN "," #NW "w,wn2>",            \
-   conv3x3_regq<TH, TW, BN, CIN, NW, D, 1, 2>, 0, TH, TW, CIN, (NW) * 64, 1}
 #define REGQ2(TH, TW, BN, CIN, NW, D)                                                                \
   {(TH) * (TW), BN, 32, 3, "conv3x3_regq<f16," #TH "x" #TW "," #BN "," #CIN "," #NW "w,s2>",             \
    conv3x3_regq<TH, TW, BN, CIN, NW, D, 2>, 0, TH, TW, CIN, (NW) * 64, 2}
@@ -1433,30 +1326,21 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
     {
         CFG(half_t, "f16", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
         CFG(half_t, "f16", 64, 64, 32, 2, 2, 4),    // kCfg64x64k32
-        CFG(half_t, "f16", 128, 64, 64, 2, 2, 4),   // kCfg128x64k64
-        CFG(half_t, "f16", 128, 64, 32, 2, 2, 4),   // kCfg128x64k32
-        CFG(half_t, "f16", 128, 128, 64, 2, 2, 4),  // kCfg128x128k64
-        CFG(half_t, "f16", 128, 32, 64, 4, 1, 4),   // kCfg128x32k64
-        CFG(half_t, "f16", 128, 32, 32, 4, 1, 4),   // kCfg128x32k32
-        CFG(half_t, "f16", 128, 16, 64, 4, 1, 4),   // kCfg128x16k64
+        CFG(half_t, "f16", 128, 64, 64, 2, 2, 4),    // kCfg128x64k64
+        CFG(half_t, "f16", 128, 64, 32, 2, 2, 4),    // kCfg128x64k32
+        CFG(half_t, "f16", 128, 128, 64, 2, 2, 4),    // kCfg128x128k64
+        CFG(half_t, "f16", 128, 32, 64, 4, 1, 4),    // kCfg128x32k64
+        CFG(half_t, "f16", 128, 32, 32, 4, 1, 4),    // kCfg128x32k32
+        CFG(half_t, "f16", 128, 16, 64, 4, 1, 4),    // kCfg128x16k64
         CFG(half_t, "f16", 32, 64, 64, 1, 4, 4),    // kCfg32x64k64
         CFG(half_t, "f16", 32, 64, 64, 1, 4, 8),    // kCfg32x64k64s8  (deep pipeline for latency-bound small grids)
         CFG(half_t, "f16", 64, 64, 64, 2, 2, 6),    // kCfg64x64k64s6
         HALO(half_t, "f16", 8, 8, 64, 64, 2, 2, 4),   // kCfgHalo8x8n64
         HALO(half_t, "f16", 8, 8, 32, 64, 4, 1, 4),   // kCfgHalo8x8n32
-        HALO(half_t, "f16", 8, 16, 64, 64, 2, 2, 4),  // kCfgHalo8x16n64
-        HALO(half_t, "f16", 8, 16, 32, 64, 4, 1, 4),  // kCfgHalo8x16n32
+        HALO(half_t, "f16", 8, 16, 64, 64, 2, 2, 4),   // kCfgHalo8x16n64
+        HALO(half_t, "f16", 8, 16, 32, 64, 4, 1, 4),   // kCfgHalo8x16n32
         HALO(half_t, "f16", 8, 8, 64, 32, 2, 2, 4),   // kCfgHalo8x8n64k32
-        HALO(half_t, "f16", 8, 16, 32, 32, 4, 1, 4),  // kCfgHalo8x16n32k32
-        HALO(half_t, "f16", 16, 16, 64, 64, 2, 2, 4), // kCfgHalo16x16n64   (wave tile 128 px x 32 ch)
-        HALO(half_t, "f16", 16, 16, 32, 64, 4, 1, 4), // kCfgHalo16x16n32   (wave tile 64 px x 32 ch)
-        HALO(half_t, "f16", 8, 16, 64, 64, 4, 1, 4),  // kCfgHalo8x16n64w41 (wave tile 32 px x 64 ch)
-        HALO(half_t, "f16", 8, 8, 64, 64, 4, 1, 4),   // kCfgHalo8x8n64w41  (wave tile 16 px x 64 ch)
-        HALO(half_t, "f16", 8, 8, 32, 128, 4, 1, 4),  // kCfgHalo8x8n32k128   (K-step 128 channels)
-        HALO(half_t, "f16", 8, 8, 32, 256, 4, 1, 4),  // kCfgHalo8x8n32k256
-        HALO(half_t, "f16", 8, 8, 64, 128, 2, 2, 4),  // kCfgHalo8x8n64k128
-        HALO(half_t, "f16", 8, 16, 32, 128, 4, 1, 4), // kCfgHalo8x16n32k128
-        HALO(half_t, "f16", 8, 16, 64, 128, 2, 2, 4), // kCfgHalo8x16n64k128
+        HALO(half_t, "f16", 8, 16, 32, 32, 4, 1, 4),   // kCfgHalo8x16n32k32
         CFG(half_t, "f16", 32, 64, 128, 1, 4, 4),     // kCfg32x64k128
         CFG(half_t, "f16", 64, 64, 128, 2, 2, 4),     // kCfg64x64k128
         REGQ(8, 16, 64, 128, 8, 16),                  // kCfgRegq8x16n64c128   (P3 head layers at 640^2)
@@ -1465,15 +1349,6 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         REGQ(8, 8, 32, 256, 8, 16),                   // kCfgRegq8x8n32c256
         REGQ(8, 16, 64, 64, 8, 16),                   // kCfgRegq8x16n64c64    (P2 head layers when not fused)
         REGQ(8, 16, 32, 128, 8, 16),                  // kCfgRegq8x16n32c128
-        // row bands x ONE channel subtile: at 640^2 exactly 256 workgroups, a weight block is read by 8 / 16 CUs only
-        REGQ(5, 40, 16, 256, 4, 16),                  // kCfgRegq5x40n16c256   (P4 head layers: 40x40 maps)
-        REGQ(5, 80, 16, 128, 4, 16),                  // kCfgRegq5x80n16c128   (P3 head layers: 80x80 maps)
-        REGQ(5, 40, 32, 256, 8, 16),                  // kCfgRegq5x40n32c256
-        REGQ(10, 40, 16, 128, 4, 16),                 // kCfgRegq10x40n16c128
-        // one wave per channel subtile (no wave re-loads another's weight blocks), deeper queue
-        REGQ(8, 8, 64, 256, 4, 32),                   // kCfgRegq8x8n64c256w4
-        REGQ(8, 16, 64, 128, 4, 32),                  // kCfgRegq8x16n64c128w4
-        REGQ(8, 8, 128, 256, 8, 24),                  // kCfgRegq8x8n128c256
         // stride 2 (stage convs, PAN down-sampling convs)
         REGQ2(8, 8, 64, 64, 8, 16),                   // kCfgRegqS2_8x8n64c64     (stage2_conv, down1)
         REGQ2(8, 16, 64, 64, 8, 16),                  // kCfgRegqS2_8x16n64c64
@@ -1481,76 +1356,53 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         REGQ2(4, 8, 64, 128, 8, 16),                  // kCfgRegqS2_4x8n64c128
         REGQ2(8, 16, 64, 32, 8, 8),                   // kCfgRegqS2_8x16n64c32    (stage1_conv)
         REGQ2(8, 8, 32, 128, 8, 16),                  // kCfgRegqS2_8x8n32c128
-        // two channel subtiles per wave: each activation fragment feeds two MFMAs
-        REGQW(8, 16, 128, 128, 8, 16),                // kCfgRegqW8x16n128c128
-        REGQW(8, 8, 128, 256, 8, 16),                 // kCfgRegqW8x8n128c256
-        REGQ(16, 16, 64, 128, 8, 16),                 // kCfgRegq16x16n64c128  (P3 head layers, one workgroup per CU with the next)
-        REGQ(8, 16, 64, 256, 8, 16),                  // kCfgRegq8x16n64c256   (P4 head layers)
         WS(16, 128, 4),                               // kCfgWs16x16n64c128    (P3 head layers, weights-stationary)
         WS(8, 256, 4),                                // kCfgWs8x16n64c256     (P4 head layers, weights-stationary)
         NOCFG, NOCFG, NOCFG,                          // (split-fp16 weights-stationary kernels)
     },
     {
-        CFG(float, "f32", 64, 64, 64, 2, 2, 4),
-        CFG(float, "f32", 64, 64, 32, 2, 2, 4),
-        CFG(float, "f32", 128, 64, 64, 2, 2, 4),
-        CFG(float, "f32", 128, 64, 32, 2, 2, 4),
-        CFG(float, "f32", 128, 128, 64, 2, 2, 4),
-        CFG(float, "f32", 128, 32, 64, 4, 1, 4),
-        CFG(float, "f32", 128, 32, 32, 4, 1, 4),
-        CFG(float, "f32", 128, 16, 64, 4, 1, 4),
-        CFG(float, "f32", 32, 64, 64, 1, 4, 4),
-        CFG(float, "f32", 32, 64, 64, 1, 4, 8),
-        CFG(float, "f32", 64, 64, 64, 2, 2, 6),
-        HALO(float, "f32", 8, 8, 64, 64, 2, 2, 4),
-        HALO(float, "f32", 8, 8, 32, 64, 4, 1, 4),
-        HALO(float, "f32", 8, 16, 64, 64, 2, 2, 4),
-        HALO(float, "f32", 8, 16, 32, 64, 4, 1, 4),
-        HALO(float, "f32", 8, 8, 64, 32, 2, 2, 4),
-        HALO(float, "f32", 8, 16, 32, 32, 4, 1, 4),
-        HALO(float, "f32", 16, 16, 64, 64, 2, 2, 4),
-        HALO(float, "f32", 16, 16, 32, 64, 4, 1, 4),
-        HALO(float, "f32", 8, 16, 64, 64, 4, 1, 4),
-        HALO(float, "f32", 8, 8, 64, 64, 4, 1, 4),
-        HALO(float, "f32", 8, 8, 32, 128, 4, 1, 4),
-        HALO(float, "f32", 8, 8, 32, 256, 4, 1, 4),
-        HALO(float, "f32", 8, 8, 64, 128, 2, 2, 4),
-        HALO(float, "f32", 8, 16, 32, 128, 4, 1, 4),
-        HALO(float, "f32", 8, 16, 64, 128, 2, 2, 4),
-        CFG(float, "f32", 32, 64, 128, 1, 4, 4),
-        CFG(float, "f32", 64, 64, 128, 2, 2, 4),
-        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,     // register-queue kernels: fp16 / int8 only
-        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
+        CFG(float, "f32", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
+        CFG(float, "f32", 64, 64, 32, 2, 2, 4),    // kCfg64x64k32
+        CFG(float, "f32", 128, 64, 64, 2, 2, 4),    // kCfg128x64k64
+        CFG(float, "f32", 128, 64, 32, 2, 2, 4),    // kCfg128x64k32
+        CFG(float, "f32", 128, 128, 64, 2, 2, 4),    // kCfg128x128k64
+        CFG(float, "f32", 128, 32, 64, 4, 1, 4),    // kCfg128x32k64
+        CFG(float, "f32", 128, 32, 32, 4, 1, 4),    // kCfg128x32k32
+        CFG(float, "f32", 128, 16, 64, 4, 1, 4),    // kCfg128x16k64
+        CFG(float, "f32", 32, 64, 64, 1, 4, 4),    // kCfg32x64k64
+        CFG(float, "f32", 32, 64, 64, 1, 4, 8),    // kCfg32x64k64s8  (deep pipeline for latency-bound small grids)
+        CFG(float, "f32", 64, 64, 64, 2, 2, 6),    // kCfg64x64k64s6
+        HALO(float, "f32", 8, 8, 64, 64, 2, 2, 4),   // kCfgHalo8x8n64
+        HALO(float, "f32", 8, 8, 32, 64, 4, 1, 4),   // kCfgHalo8x8n32
+        HALO(float, "f32", 8, 16, 64, 64, 2, 2, 4),   // kCfgHalo8x16n64
+        HALO(float, "f32", 8, 16, 32, 64, 4, 1, 4),   // kCfgHalo8x16n32
+        HALO(float, "f32", 8, 8, 64, 32, 2, 2, 4),   // kCfgHalo8x8n64k32
+        HALO(float, "f32", 8, 16, 32, 32, 4, 1, 4),   // kCfgHalo8x16n32k32
+        CFG(float, "f32", 32, 64, 128, 1, 4, 4),     // kCfg32x64k128
+        CFG(float, "f32", 64, 64, 128, 2, 2, 4),     // kCfg64x64k128
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,     // register-queue / weights-stationary kernels: fp16 / int8 / split fp16 only
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
         NOCFG, NOCFG,
         NOCFG, NOCFG, NOCFG,
     },
     {
         CFG(signed char, "i8", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
         CFG(signed char, "i8", 64, 64, 32, 2, 2, 4),    // kCfg64x64k32
-        CFG(signed char, "i8", 128, 64, 64, 2, 2, 4),   // kCfg128x64k64
-        CFG(signed char, "i8", 128, 64, 32, 2, 2, 4),   // kCfg128x64k32
-        CFG(signed char, "i8", 128, 128, 64, 2, 2, 4),  // kCfg128x128k64
-        CFG(signed char, "i8", 128, 32, 64, 4, 1, 4),   // kCfg128x32k64
-        CFG(signed char, "i8", 128, 32, 32, 4, 1, 4),   // kCfg128x32k32
-        CFG(signed char, "i8", 128, 16, 64, 4, 1, 4),   // kCfg128x16k64
+        CFG(signed char, "i8", 128, 64, 64, 2, 2, 4),    // kCfg128x64k64
+        CFG(signed char, "i8", 128, 64, 32, 2, 2, 4),    // kCfg128x64k32
+        CFG(signed char, "i8", 128, 128, 64, 2, 2, 4),    // kCfg128x128k64
+        CFG(signed char, "i8", 128, 32, 64, 4, 1, 4),    // kCfg128x32k64
+        CFG(signed char, "i8", 128, 32, 32, 4, 1, 4),    // kCfg128x32k32
+        CFG(signed char, "i8", 128, 16, 64, 4, 1, 4),    // kCfg128x16k64
         CFG(signed char, "i8", 32, 64, 64, 1, 4, 4),    // kCfg32x64k64
         CFG(signed char, "i8", 32, 64, 64, 1, 4, 8),    // kCfg32x64k64s8  (deep pipeline for latency-bound small grids)
         CFG(signed char, "i8", 64, 64, 64, 2, 2, 6),    // kCfg64x64k64s6
         HALO(signed char, "i8", 8, 8, 64, 64, 2, 2, 4),   // kCfgHalo8x8n64
         HALO(signed char, "i8", 8, 8, 32, 64, 4, 1, 4),   // kCfgHalo8x8n32
-        HALO(signed char, "i8", 8, 16, 64, 64, 2, 2, 4),  // kCfgHalo8x16n64
-        HALO(signed char, "i8", 8, 16, 32, 64, 4, 1, 4),  // kCfgHalo8x16n32
+        HALO(signed char, "i8", 8, 16, 64, 64, 2, 2, 4),   // kCfgHalo8x16n64
+        HALO(signed char, "i8", 8, 16, 32, 64, 4, 1, 4),   // kCfgHalo8x16n32
         HALO(signed char, "i8", 8, 8, 64, 32, 2, 2, 4),   // kCfgHalo8x8n64k32
-        HALO(signed char, "i8", 8, 16, 32, 32, 4, 1, 4),  // kCfgHalo8x16n32k32
-        HALO(signed char, "i8", 16, 16, 64, 64, 2, 2, 4), // kCfgHalo16x16n64   (wave tile 128 px x 32 ch)
-        HALO(signed char, "i8", 16, 16, 32, 64, 4, 1, 4), // kCfgHalo16x16n32   (wave tile 64 px x 32 ch)
-        HALO(signed char, "i8", 8, 16, 64, 64, 4, 1, 4),  // kCfgHalo8x16n64w41 (wave tile 32 px x 64 ch)
-        HALO(signed char, "i8", 8, 8, 64, 64, 4, 1, 4),   // kCfgHalo8x8n64w41  (wave tile 16 px x 64 ch)
-        HALO(signed char, "i8", 8, 8, 32, 128, 4, 1, 4),  // kCfgHalo8x8n32k128   (K-step 128 channels)
-        HALO(signed char, "i8", 8, 8, 32, 256, 4, 1, 4),  // kCfgHalo8x8n32k256
-        HALO(signed char, "i8", 8, 8, 64, 128, 2, 2, 4),  // kCfgHalo8x8n64k128
-        HALO(signed char, "i8", 8, 16, 32, 128, 4, 1, 4), // kCfgHalo8x16n32k128
-        HALO(signed char, "i8", 8, 16, 64, 128, 2, 2, 4), // kCfgHalo8x16n64k128
+        HALO(signed char, "i8", 8, 16, 32, 32, 4, 1, 4),   // kCfgHalo8x16n32k32
         CFG(signed char, "i8", 32, 64, 128, 1, 4, 4),     // kCfg32x64k128
         CFG(signed char, "i8", 64, 64, 128, 2, 2, 4),     // kCfg64x64k128
         REGQI(8, 16, 64, 128, 8, 16),                 // kCfgRegq8x16n64c128   (P3 head layers)
@@ -1559,16 +1411,12 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         REGQI(8, 8, 32, 256, 8, 16),                  // kCfgRegq8x8n32c256
         NOCFG,                                        // kCfgRegq8x16n64c64    (the P2 head is an fp16 carve-out)
         REGQI(8, 16, 32, 128, 8, 16),                 // kCfgRegq8x16n32c128
-        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
         REGQI2(8, 8, 64, 64, 8, 8),                   // kCfgRegqS2_8x8n64c64     (down1)
         REGQI2(8, 16, 64, 64, 8, 8),                  // kCfgRegqS2_8x16n64c64
         REGQI2(8, 8, 64, 128, 8, 16),                 // kCfgRegqS2_8x8n64c128    (stage3_conv, down2)
         REGQI2(4, 8, 64, 128, 8, 16),                 // kCfgRegqS2_4x8n64c128
         NOCFG,                                        // kCfgRegqS2_8x16n64c32    (Cin 32 < one int8 block)
         REGQI2(8, 8, 32, 128, 8, 16),                 // kCfgRegqS2_8x8n32c128
-        NOCFG, NOCFG,
-        REGQI(16, 16, 64, 128, 8, 16),                // kCfgRegq16x16n64c128
-        REGQI(8, 16, 64, 256, 8, 16),                 // kCfgRegq8x16n64c256
         WSI(16, 128, 4),                              // kCfgWs16x16n64c128
         WSI(8, 256, 4),                               // kCfgWs8x16n64c256
         NOCFG, NOCFG, NOCFG,
@@ -1585,7 +1433,7 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         CFG(s16_t, "s16", 32, 64, 64, 1, 4, 4),     // kCfg32x64k64
         NOCFG,                                      // kCfg32x64k64s8
         NOCFG,                                      // kCfg64x64k64s6
-        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,   // halo kernels
+        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,   // halo kernels
         NOCFG, NOCFG,                               // kCfg32x64k128, kCfg64x64k128
         // register-queue 3x3: hi / lo patch images in LDS, (hi | lo) weight block pairs through the queue (D pairs = 2 D KiB in flight)
         REGQS(8, 16, 64, 128, 8, 8),                // kCfgRegq8x16n64c128   (P3 head layers)
@@ -1594,16 +1442,13 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         NOCFG,                                      // kCfgRegq8x8n32c256
         REGQS(8, 16, 64, 64, 8, 8),                 // kCfgRegq8x16n64c64    (P2 head layers)
         NOCFG,                                      // kCfgRegq8x16n32c128
-        NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
         REGQS2(8, 8, 64, 64, 8, 8),                 // kCfgRegqS2_8x8n64c64     (stage2_conv, down1)
         NOCFG,                                      // kCfgRegqS2_8x16n64c64
         REGQS2(8, 8, 64, 128, 8, 8),                // kCfgRegqS2_8x8n64c128    (stage3_conv, down2)
         REGQS2(4, 8, 64, 128, 8, 8),                // kCfgRegqS2_4x8n64c128
         REGQS2(8, 16, 64, 32, 8, 8),                // kCfgRegqS2_8x16n64c32    (stage1_conv)
         NOCFG,                                      // kCfgRegqS2_8x8n32c128
-        NOCFG, NOCFG,
-        NOCFG, NOCFG,
-        NOCFG, NOCFG,
+        NOCFG, NOCFG,                               // (the fp16 / int8 weights-stationary kernels)
         WSS(8, 64, 1, 4),                           // kCfgWsS8x16n64c64     (P2 head layers)
         WSS(8, 128, 2, 4),                          // kCfgWsS8x16n64c128    (P3 head layers: two chunks of 64 channels)
         WSS(8, 256, 4, 4),                          // kCfgWsS8x16n64c256    (P4 head layers: four chunks. 4-row tiles -- 240 workgroups of the P3 conv's size -- ran 34 us per pair against 30.6)
@@ -1613,7 +1458,6 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
 #undef HALO
 #undef REGQ
 #undef REGQ2
-#undef REGQW
 #undef REGQI
 #undef REGQI2
 #undef NOCFG
@@ -1653,11 +1497,9 @@ hipError_t conv_init() {
   for (const void* f : {reinterpret_cast<const void*>(conv_dual_head3x3), reinterpret_cast<const void*>(conv_dual_head1x1),
                         reinterpret_cast<const void*>(conv_dual_head3x3_i8), reinterpret_cast<const void*>(conv_dual_head3x3_s16),
                         reinterpret_cast<const void*>(conv_dual_head3x3_ws_s16), reinterpret_cast<const void*>(conv_dual_head3x3_ws_s16_stamped),
-                        reinterpret_cast<const void*>(conv_dual_head3x3_big), reinterpret_cast<const void*>(conv_dual_head3x3_big_i8),
-                        reinterpret_cast<const void*>(conv_dual_head3x3_big_stamped),
                         reinterpret_cast<const void*>(conv_dual_head3x3_ws), reinterpret_cast<const void*>(conv_dual_head3x3_ws_stamped),
                         reinterpret_cast<const void*>(conv_dual_head3x3_ws_i8),
-                        reinterpret_cast<const void*>(stem_conv3x3s2_kernel)}) {
+                        }) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (e != hipSuccess) return e;
   }
@@ -1776,37 +1618,6 @@ hipError_t conv_launch(const ConvParams& pin, const ConvLaunch& l, hipStream_t s
   return hipGetLastError();
 }
 
-// ---- stem + stage1_conv ----
-bool stemconv_supported(const StemParams& sp, const ConvParams& cp) {
-  if (sp.dtype != kF16 || sp.Co != 32 || cp.dtype != kF16 || cp.nseg != 1 || cp.res || cp.seg[0].up2 || cp.seg[0].dst_planar) return false;
-  if (cp.H != sp.Ho || cp.W != sp.Wo || cp.src_ld != 32 || cp.seg[0].src_coff != 0 || cp.stamps) return false;
-  return conv_config_valid(cp, kCfgRegqS2_8x16n64c32);
-}
-
-hipError_t stemconv_desc(const StemParams& sp, const ConvParams& cp_in, LaunchDesc* d, void* params_out /* StemConvParams */) {
-  StemConvParams* sc = static_cast<StemConvParams*>(params_out);
-  sc->stem = sp;
-  sc->conv = cp_in;
-  const dim3 g = conv_prepare(sc->conv, kCfgRegqS2_8x16n64c32);
-  d->func = reinterpret_cast<const void*>(&stem_conv3x3s2_kernel);
-  d->grid = dim3(g.x * g.y, 1, 1);
-  d->block = dim3(512, 1, 1);
-  const size_t patch = ((size_t)17 * 33 * 32 * 2 + 1023) / 1024 * 1024;
-  d->shmem = (unsigned)max_sz(patch + 28 * 32 * 4, stage_bytes(128, 64));
-  return hipSuccess;
-}
-
-size_t stemconv_params_bytes() { return sizeof(StemConvParams); }
-
-hipError_t stemconv_launch(const StemParams& sp, const ConvParams& cp, hipStream_t stream) {
-  StemConvParams sc;
-  LaunchDesc d;
-  hipError_t e = stemconv_desc(sp, cp, &d, &sc);
-  if (e != hipSuccess) return e;
-  void* args[] = {&sc};
-  return hipLaunchKernel(d.func, d.grid, d.block, args, d.shmem, stream);
-}
-
 // ---- dual launches (conv_dual_head3x3 / conv_dual_head1x1) ----
 namespace {
 struct DualKind {
@@ -1814,13 +1625,11 @@ struct DualKind {
   const char* name;
   void (*fn)(const ConvParams, const ConvParams, int);
 };
-enum { kDualRegq = 0, kDual1x1, kDualRegqI8, kDualBig, kDualBigI8, kDualWs, kDualWsI8, kDualRegqS16, kDualWsS16, kDualKinds };
+enum { kDualRegq = 0, kDual1x1, kDualRegqI8, kDualWs, kDualWsI8, kDualRegqS16, kDualWsS16, kDualKinds };
 const DualKind kDual[kDualKinds] = {
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3<regq 8x16,64,128 | regq 8x8,64,256>", conv_dual_head3x3},
     {kCfg128x16k64, kCfg128x16k64, 256, "conv_dual_head1x1<glds 128,16,64 x2>", conv_dual_head1x1},
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3_i8<regq i8,8x16,64,128 | regq i8,8x8,64,256>", conv_dual_head3x3_i8},
-    {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big<regq 16x16,64,128 | regq 8x16,64,256>", conv_dual_head3x3_big},
-    {kCfgRegq16x16n64c128, kCfgRegq8x16n64c256, 512, "conv_dual_head3x3_big_i8<regq i8,16x16,64,128 | regq i8,8x16,64,256>", conv_dual_head3x3_big_i8},
     {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws<ws 16x16,64,128 | ws 8x16,64,256>", conv_dual_head3x3_ws},
     {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws_i8<ws i8,16x16,64,128 | ws i8,8x16,64,256>", conv_dual_head3x3_ws_i8},
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3_s16<regq s16,8x16,64,128 | regq s16,8x8,64,256>", conv_dual_head3x3_s16},
@@ -1831,15 +1640,12 @@ const DualKind kDual[kDualKinds] = {
 int conv_dual_match(const ConvParams& a, const ConvParams& b) {
   if (a.stamps || b.stamps) return -1;   // (stamped launches go through conv_dual_launch with an explicit kind)
   auto fits = [&](int k) { return a.ksize == 3 && b.ksize == 3 && conv_config_valid(a, kDual[k].cfg_a) && conv_config_valid(b, kDual[k].cfg_b); };
-  // 16x16 | 8x16 pixel tiles (one workgroup per CU): default for fp16 (39.5 vs 41.4 us per frame for the two pairs,
-  // +2.5 % frames/s), opt-in for int8 (measured slower: 0.229 vs 0.2245 ms). UNINA_DUAL_BIG=0 / 1 overrides.
-  const char* bigenv = getenv("UNINA_DUAL_BIG");
-  const bool big = bigenv ? bigenv[0] == '1' : (a.dtype == kF16);
+  // the weights-stationary pairs are the default; UNINA_DUAL_WS=0 selects the register-queue pairs (the tile-kernel family: an
+  // independent implementation of the same convs, tests/test_gpu_pipeline.py compares the two byte for byte)
   const char* wsenv = getenv("UNINA_DUAL_WS");
-  const bool ws = !(wsenv && wsenv[0] == '0') && !bigenv;
+  const bool ws = !(wsenv && wsenv[0] == '0');
   if (a.dtype == kI8 && b.dtype == kI8) {
     if (ws && fits(kDualWsI8)) return kDualWsI8;
-    if (big && fits(kDualBigI8)) return kDualBigI8;
     return fits(kDualRegqI8) ? kDualRegqI8 : -1;
   }
   if (a.dtype == kS16 && b.dtype == kS16) {   // STRICT engines: the weights-stationary pair (UNINA_DUAL_WS=0: the register-queue pair)
@@ -1850,7 +1656,6 @@ int conv_dual_match(const ConvParams& a, const ConvParams& b) {
   // the weights-stationary pair: default for fp16 (same-box A/B against the register-queue pair: +2-3 % frames/s at 2 frames in
   // flight, serial latency equal within noise; workgroup lives 9-11 us against 12-15). UNINA_DUAL_WS=0 falls back.
   if (ws && fits(kDualWs)) return kDualWs;
-  if (big && fits(kDualBig)) return kDualBig;
   if (fits(kDualRegq)) return kDualRegq;
   auto tiny = [](const ConvParams& p) {
     for (int s = 0; s < p.nseg; ++s)
@@ -1873,8 +1678,8 @@ hipError_t conv_dual_launch(int kind, const ConvParams& pa_in, const ConvParams&
   if (grid_out) *grid_out = na + nb;
   auto fn = k.fn;
   if (pa.stamps || pb.stamps) {   // debug: the stamped twin (only the default fp16 pair has one)
-    if (kind != kDualBig && kind != kDualWs && kind != kDualWsS16) return hipErrorInvalidValue;
-    fn = kind == kDualWs ? conv_dual_head3x3_ws_stamped : (kind == kDualWsS16 ? conv_dual_head3x3_ws_s16_stamped : conv_dual_head3x3_big_stamped);
+    if (kind != kDualWs && kind != kDualWsS16) return hipErrorInvalidValue;
+    fn = kind == kDualWs ? conv_dual_head3x3_ws_stamped : conv_dual_head3x3_ws_s16_stamped;
   }
   hipLaunchKernelGGL(fn, dim3(na + nb, 1, 1), dim3(k.threads, 1, 1), max_sz(sa, sb), stream, pa, pb, (kind == kDualWs || kind == kDualWsI8 || kind == kDualWsS16) ? nb : na);   // (the weights-stationary pairs put conv B first)
   return hipGetLastError();

@@ -44,7 +44,7 @@ struct PlannedOp {
   // fused C3k2 block (c3k2_fused.hip): role 1 = first op of a fusable group (launches the whole block when fusion is
   // on), 2 = absorbed by the group's first op (no launch of its own when fusion is on), 0 = ordinary op
   int fuse_role = 0;
-  int fuse_kind = 0;        // role 1: 1 = C3k2 block (c3k2_fused.hip), 2 = DetectionHead (head_fused.hip)
+  int fuse_kind = 0;        // role 1: 1 = C3k2 block (c3k2_fused.hip), 2 = DetectionHead (head_fused.hip), 4 = conv pair (conv_pair.hip)
   HeadParams hp;
   PairParams pr;            // fuse_kind 4: two consecutive 1x1 convs (conv_pair.hip)
   int group_last = -1;      // role 1: index of the group's last op (cv3 / the head's output convs)
@@ -102,12 +102,8 @@ struct unina_engine {
   bool use_graph = true;
   bool plan_dirty = true;
   hipStream_t capture_stream = nullptr;
-  std::vector<hipStream_t> side_streams;   // extra capture streams: independent branches become parallel graph paths
-  std::vector<hipEvent_t> op_events;       // one per op (capture-time dependency edges)
-  hipEvent_t fork_event = nullptr;
   double t_submit_us = 0, t_wait_us = 0, t_copy_us = 0;   // UNINA_TIMING=1: host-side split of unina_infer (printed at unload)
   long t_calls = 0;
-  int n_streams = 1;                       // parallel graph paths (UNINA_STREAMS); measured no gain on ROCm 7.2, so 1
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   // full-frame graph (unina_infer / unina_infer_async): stem + forward + post-process as ONE hipGraphLaunch. The two
@@ -197,12 +193,6 @@ void op_regions(const unina_engine* e, size_t i, std::vector<Region>* reads, std
         writes->push_back({(int)dk.seg[s].dst_buf, (int)dk.seg[s].dst_coff, (int)(dk.seg[s].dst_coff + dk.seg[s].n_count)});
       }
     }
-    return;
-  }
-  if (e->fuse && e->ops[i].fuse_role == 1 && e->ops[i].fuse_kind == 3) {
-    const SegDesc& out = e->ops[e->ops[i].group_last].d.seg[0];
-    reads->push_back({(int)d.src_buf, 0, 3});
-    writes->push_back({(int)out.dst_buf, (int)out.dst_coff, (int)(out.dst_coff + out.n_count)});
     return;
   }
   if (e->fuse && e->ops[i].fuse_role == 1) {
@@ -423,28 +413,6 @@ int plan(unina_engine* e) {
   for (size_t i = 0; i < e->ops.size(); ++i) {
     PlannedOp& op = e->ops[i];
     if (op.fuse_role != 1) continue;
-    if (op.fuse_kind == 3) {
-      PlannedOp& cv = e->ops[op.group_last];
-      if (!stemconv_supported(op.sp, cv.cp)) {   // other channel widths / precisions: the two ops stay separate launches
-        op.fuse_role = 0;
-        cv.fuse_role = 0;
-        --e->n_groups;
-        continue;
-      }
-      if (!e->fuse) continue;
-      op.info.flops += cv.info.flops;
-      op.info.bytes = 4.0 * 3 * op.sp.H * op.sp.W + 2.0 * cv.cp.M * cv.info.n + 2.0 * cv.info.n * cv.info.k;
-      op.info.grid = (cv.cp.Ho + 7) / 8 * ((cv.cp.Wo + 15) / 16) * ((cv.info.n + 63) / 64);
-      op.info.block = 512;
-      op.info.m = cv.info.m; op.info.n = cv.info.n; op.info.k = cv.info.k;
-      snprintf(op.info.kernel, sizeof op.info.kernel, "stem_conv3x3s2_kernel<8x16,64,32>");
-      snprintf(op.info.name, sizeof op.info.name, "%s+%s", op.d.name, cv.d.name);
-      cv.info.flops = 0;
-      cv.info.bytes = 0;
-      cv.info.grid = 0;
-      snprintf(cv.info.kernel, sizeof cv.info.kernel, "(fused into op %zu)", i);
-      continue;
-    }
     if (op.fuse_kind == 4) {
       const OpDesc& a = e->ops[i + op.fuse_pre].d;
       PlannedOp& zb = e->ops[op.group_last];
@@ -739,7 +707,6 @@ hipError_t launch_op(unina_engine* e, size_t i, hipStream_t s) {
   PlannedOp& op = e->ops[i];
   if (op.dual_absorbed) return hipSuccess;
   if (e->fuse && op.fuse_role == 1 && op.dual_with >= 0) return block_dual_launch(op.fp, e->ops[op.dual_with].hp, s);
-  if (e->fuse && op.fuse_role == 1 && op.fuse_kind == 3) return stemconv_launch(op.sp, e->ops[op.group_last].cp, s);
   if (e->fuse && op.fuse_role == 1 && op.fuse_kind == 4) return pair_launch(op.pr, s);
   if (e->fuse && op.fuse_role == 1) return op.fuse_kind == 2 ? head_launch(op.hp, s) : c3k2_launch(op.fp, s);
   if (op.dual_with >= 0) return conv_dual_launch(op.dual_kind, op.cp, e->ops[op.dual_with].cp, s);
@@ -766,87 +733,20 @@ int launch_all(unina_engine* e, hipStream_t s, int which = 0 /*0 all, 1 eager on
   return UNINA_OK;
 }
 
-// preds[j] = ops i < j that j must wait for (RAW, WAR, WAW), transitively reduced only trivially
-std::vector<std::vector<int>> op_dependencies(const unina_engine* e) {
-  const size_t n = e->ops.size();
-  std::vector<std::vector<Region>> R(n), W(n);
-  for (size_t i = 0; i < n; ++i) op_regions(e, i, &R[i], &W[i]);
-  std::vector<std::vector<int>> preds(n);
-  for (size_t j = 0; j < n; ++j)
-    for (size_t i = 0; i < j; ++i) {
-      bool dep = false;
-      for (const Region& w : W[i]) {
-        for (const Region& r : R[j]) dep = dep || overlaps(w, r);
-        for (const Region& w2 : W[j]) dep = dep || overlaps(w, w2);
-      }
-      for (const Region& r : R[i])
-        for (const Region& w2 : W[j]) dep = dep || overlaps(r, w2);
-      if (dep) preds[j].push_back((int)i);
-    }
-  return preds;
-}
-
-// Captures the graph part of the forward. Ops are dealt to n_streams capture streams so that independent branches
-// (the three detection heads vs. the PAN path, C3k2 side paths) become parallel paths of the hipGraph; every
-// cross-stream dependency is an event edge. With n_streams == 1 this is a plain chain.
+// Captures the graph part of the forward as a plain chain on the capture stream. (Independent branches as parallel graph
+// paths -- heads | PAN path on side streams with event edges -- were implemented and measured in round 1: 1 821 / 2 503
+// frames/s with 2 / 3 paths against 5 837 as a chain; removed.)
 int capture(unina_engine* e) {
   drop_graph(e);
-  const size_t n = e->ops.size();
-  const int S = e->n_streams < 1 ? 1 : e->n_streams;
-  while ((int)e->side_streams.size() < S - 1) {
-    hipStream_t st;
-    HIPCHK(e, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    e->side_streams.push_back(st);
-  }
-  while (e->op_events.size() < n) {
-    hipEvent_t ev;
-    HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    e->op_events.push_back(ev);
-  }
-  if (!e->fork_event) HIPCHK(e, hipEventCreateWithFlags(&e->fork_event, hipEventDisableTiming));
-  std::vector<hipStream_t> st(S);
-  st[0] = e->capture_stream;
-  for (int k = 1; k < S; ++k) st[k] = e->side_streams[k - 1];
-  const std::vector<std::vector<int>> preds = op_dependencies(e);
-
-  HIPCHK(e, hipStreamBeginCapture(st[0], hipStreamCaptureModeThreadLocal));
-  hipError_t err = hipEventRecord(e->fork_event, st[0]);
-  for (int k = 1; k < S && err == hipSuccess; ++k) err = hipStreamWaitEvent(st[k], e->fork_event, 0);
-  std::vector<int> stream_of(n, -1), tail(S, -1);  // tail[k] = last op captured on stream k
+  HIPCHK(e, hipStreamBeginCapture(e->capture_stream, hipStreamCaptureModeThreadLocal));
   int rc = UNINA_OK;
-  for (size_t j = 0; j < n && err == hipSuccess && rc == UNINA_OK; ++j) {
+  for (size_t j = 0; j < e->ops.size() && rc == UNINA_OK; ++j) {
     if (is_eager(e, j)) continue;
-    int k = -1;
-    for (int p : preds[j])  // continue a chain where a predecessor is still the tail of its stream
-      if (stream_of[p] >= 0 && tail[stream_of[p]] == p) k = stream_of[p];
-    if (k < 0) {            // otherwise the stream whose tail is oldest (round-robin-ish)
-      k = 0;
-      for (int q = 1; q < S; ++q)
-        if (tail[q] < tail[k]) k = q;
-    }
-    for (int p : preds[j])
-      if (stream_of[p] >= 0 && stream_of[p] != k && err == hipSuccess) err = hipStreamWaitEvent(st[k], e->op_events[p], 0);
-    if (err != hipSuccess) break;
-    err = launch_op(e, j, st[k]);
-    if (err != hipSuccess) {
-      rc = fail(e, UNINA_ERR_HIP, "op %zu (%s): %s", j, e->ops[j].d.name, hipGetErrorString(err));
-      break;
-    }
-    err = hipEventRecord(e->op_events[j], st[k]);
-    stream_of[j] = k;
-    tail[k] = (int)j;
+    const hipError_t err = launch_op(e, j, e->capture_stream);
+    if (err != hipSuccess) rc = fail(e, UNINA_ERR_HIP, "op %zu (%s): %s", j, e->ops[j].d.name, hipGetErrorString(err));
   }
-  for (int k = 1; k < S && err == hipSuccess; ++k) {  // join the side streams back into the origin
-    if (tail[k] < 0) {
-      err = hipEventRecord(e->op_events[0], st[k]);  // never used: still has to be joined
-      if (err == hipSuccess) err = hipStreamWaitEvent(st[0], e->op_events[0], 0);
-      continue;
-    }
-    err = hipStreamWaitEvent(st[0], e->op_events[tail[k]], 0);
-  }
-  hipError_t end = hipStreamEndCapture(st[0], &e->graph);
+  const hipError_t end = hipStreamEndCapture(e->capture_stream, &e->graph);
   if (rc != UNINA_OK) return rc;
-  if (err != hipSuccess) return fail(e, UNINA_ERR_HIP, "graph capture: %s", hipGetErrorString(err));
   if (end != hipSuccess) return fail(e, UNINA_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(end));
   HIPCHK(e, hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0));
   return UNINA_OK;
@@ -1284,19 +1184,7 @@ int launch_full(unina_engine* e, const PostParams& pp, hipStream_t stream) {
     const StemParams& sp = so.sp;
     if (memcmp(&sp, &e->f_stem, sizeof sp)) {
       LaunchDesc d;
-      if (e->fuse && so.fuse_role == 1 && so.fuse_kind == 3) {   // the stem lives inside the stem+conv kernel
-        std::vector<unsigned char> sc(stemconv_params_bytes());
-        HIPCHK(e, stemconv_desc(sp, e->ops[so.group_last].cp, &d, sc.data()));
-        void* args[] = {sc.data()};
-        hipKernelNodeParams np;
-        memset(&np, 0, sizeof np);
-        np.func = const_cast<void*>(d.func);
-        np.gridDim = d.grid;
-        np.blockDim = d.block;
-        np.sharedMemBytes = d.shmem;
-        np.kernelParams = args;
-        HIPCHK(e, hipGraphExecKernelNodeSetParams(e->fexec, e->stem_node, &np));
-      } else {
+      {
         HIPCHK(e, stem_desc(sp, &d));
         HIPCHK(e, set_node(e->fexec, e->stem_node, d, sp));
       }
@@ -1323,9 +1211,8 @@ int launch_full(unina_engine* e, const PostParams& pp, hipStream_t stream) {
 template <typename F>
 int time_in_sequence(unina_engine* e, size_t i, int iters, hipStream_t stream, hipEvent_t a, hipEvent_t b, F launch, float* ms_out) {
   float total = 0.f;
-  static const bool warm = getenv("UNINA_PROFILE_WARM") != nullptr;   // debug: back-to-back repeats (weights and inputs L2-warm)
   for (int it = 0; it < iters; ++it) {
-    for (size_t k = 0; k < (warm && it > 0 ? 0 : i); ++k) {
+    for (size_t k = 0; k < i; ++k) {
       hipError_t err = launch_op(e, k, stream);
       if (err != hipSuccess) return fail(e, UNINA_ERR_HIP, "op %zu (%s): %s", k, e->ops[k].d.name, hipGetErrorString(err));
     }
@@ -1339,40 +1226,6 @@ int time_in_sequence(unina_engine* e, size_t i, int iters, hipStream_t stream, h
   }
   *ms_out = total / (float)iters;
   return UNINA_OK;
-}
-
-// backbone.stem followed by the 3x3/s2 conv that is its only reader: one launch (conv_igemm.hip: stem_conv3x3s2_kernel).
-// Shape support is checked at plan time (stemconv_supported); here only the wiring. OPT-IN (UNINA_STEM_FUSE=1): it is
-// bit-identical and saves a launch plus the stem's 6.6 MB round trip, but measured no faster at 640^2 (0.278 vs 0.277 ms:
-// the in-kernel stem is three rounds of latency-bound fp32 image loads per workgroup), so the separate launches stay.
-void find_stem_group(unina_engine* e) {
-  const char* sf = getenv("UNINA_STEM_FUSE");
-  if (!sf || sf[0] != '1') return;
-  for (size_t i = 0; i + 1 < e->ops.size(); ++i) {
-    const OpDesc& st = e->ops[i].d;
-    const OpDesc& cv = e->ops[i + 1].d;
-    if (st.kind != kOpStem || e->ops[i].fuse_role || e->ops[i + 1].fuse_role) continue;
-    const uint32_t sb = st.seg[0].dst_buf;
-    if (cv.kind != kOpConv || cv.ksize != 3 || cv.stride != 2 || !cv.relu || cv.nseg != 1 || cv.res_buf >= 0 || cv.seg[0].flags ||
-        cv.seg[0].m_off || cv.src_buf != sb || cv.seg[0].src_coff != 0 || st.seg[0].dst_coff != 0 || cv.cin != st.seg[0].n_count ||
-        e->bufs[sb].d.c != cv.cin || e->bufs[sb].d.dtype != kBufF16Nhwc || e->bufs[cv.seg[0].dst_buf].d.dtype != kBufF16Nhwc)
-      continue;
-    bool priv = !(e->bufs[sb].d.flags & (kBufInput | kBufOutput));
-    for (size_t k = 0; k < e->ops.size() && priv; ++k) {
-      if (k == i || k == i + 1) continue;
-      const OpDesc& o = e->ops[k].d;
-      if (o.src_buf == sb || o.res_buf == (int)sb) priv = false;
-      for (uint32_t s = 0; s < o.nseg; ++s)
-        if (o.seg[s].dst_buf == sb) priv = false;
-    }
-    if (!priv) continue;
-    e->ops[i].fuse_role = 1;
-    e->ops[i].fuse_kind = 3;
-    e->ops[i].group_last = (int)i + 1;
-    e->ops[i + 1].fuse_role = 2;
-    ++e->n_groups;
-    return;
-  }
 }
 
 int find_buffer(const unina_engine* e, const char* name) {
@@ -1547,7 +1400,6 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
     find_c3k2_groups(e, &blob);
     find_head_groups(e, &blob);
     find_pair_groups(e, &blob);
-    find_stem_group(e);
     const char* fz = getenv("UNINA_FUSE");
     e->fuse = e->n_groups > 0 && !(fz && fz[0] == '0');
   }
@@ -1613,7 +1465,6 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
 #undef LOADCHK
   const char* ng = getenv("UNINA_NO_GRAPH");
   e->use_graph = !(ng && ng[0] == '1');
-  if (const char* ns = getenv("UNINA_STREAMS")) e->n_streams = atoi(ns) > 0 ? atoi(ns) : 1;
   if (const char* fg = getenv("UNINA_FULL_GRAPH")) e->full_graph = fg[0] != '0';
   if (const char* ps = getenv("UNINA_POST_SPLIT")) e->post_split = ps[0] != '0';
   if (const char* pf = getenv("UNINA_POST_FOLD")) e->fold_heads = pf[0] != '0';
@@ -1628,9 +1479,6 @@ void unina_unload_engine(unina_engine_t* e) {
   (void)hipSetDevice(e->device);
   drop_graph(e);
   if (e->capture_stream) (void)hipStreamDestroy(e->capture_stream);
-  for (hipStream_t st : e->side_streams) (void)hipStreamDestroy(st);
-  for (hipEvent_t ev : e->op_events) (void)hipEventDestroy(ev);
-  if (e->fork_event) (void)hipEventDestroy(e->fork_event);
   void* dev[] = {e->d_blob, e->d_arena, e->d_zeros, e->d_cand, e->d_block_count, e->d_ticket, e->d_post_ws, e->d_result};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -1709,7 +1557,7 @@ int unina_infer_async(unina_engine_t* e, const float* d_images, float conf, floa
     int rc = unina_set_tensor_address(e, "images", const_cast<float*>(d_images));
     if (rc != UNINA_OK) return rc;
   }
-  if (e->full_graph && e->use_graph && e->n_streams <= 1) {
+  if (e->full_graph && e->use_graph) {
     if (!d_out || !d_out_count) return UNINA_ERR_ARG;
     HIPCHK(e, hipSetDevice(e->device));
     if (!e->bufs[e->images_buf].ptr && !e->camera_active) return fail(e, UNINA_ERR_STATE, "tensor 'images' is not bound");
@@ -1827,7 +1675,6 @@ int unina_infer_bgra(unina_engine_t* e, const uint8_t* d_bgra, int src_width, in
   for (size_t k = 0; k < e->ops.size(); ++k) {
     PlannedOp& op = e->ops[k];
     if (!is_eager(e, k) || op.d.kind != kOpStem) continue;
-    if (e->fuse && op.fuse_role == 1 && op.fuse_kind == 3) return fail(e, UNINA_ERR_UNSUPPORTED, "unina_infer_bgra with the fused stem+conv kernel");
     op.sp.src_kind = (src_width == op.sp.W && src_height == op.sp.H) ? 1 : 2;
     op.sp.cam = d_bgra;
     op.sp.cam_w = src_width;
@@ -1870,7 +1717,6 @@ int unina_debug_conv_stamps(unina_engine_t* e, int op_index, long long* out5, hi
   }
   if (e->ops[op_index].d.kind != kOpConv) return fail(e, UNINA_ERR_ARG, "op %d is not a convolution", op_index);
   ConvParams p = e->ops[op_index].cp;
-  if (const char* dm = getenv("UNINA_CONV_DEBUG_MODE")) p.debug_mode = atoi(dm);
   p.stamps = reinterpret_cast<long long*>(e->d_result->pad_stamps);
   HIPCHK(e, hipMemsetAsync(p.stamps, 0, sizeof(long long) * 8, stream));
   HIPCHK(e, conv_launch(p, e->ops[op_index].cl, stream));
@@ -2011,7 +1857,6 @@ int unina_debug_fusable_groups(const char* path) {
     find_c3k2_groups(&e, &blob);
     find_head_groups(&e, &blob);
     find_pair_groups(&e, &blob);
-    find_stem_group(&e);
   }
   return e.n_groups;
 }

@@ -43,18 +43,15 @@ struct HClass {
   bool ws = false;     // row-streaming / weights-stationary body (head_ws_body): th x 14 output pixels per workgroup
 };
 const HClass kHeadClasses[] = {
-    {64, 8, 16, 8, "head_fused<64,8x16,8w>", head_fused_kernel<64, 8, 16, 8, 16>},   // UNINA_HEAD_ALT=0 (round 1's default)
-    {64, 8, 8, 8, "head_fused<64,8x8,8w>", head_fused_kernel<64, 8, 8, 8, 16>},     // UNINA_HEAD_ALT=1 (A/B experiments)
-    {64, 16, 16, 8, "head_fused<64,16x16,8w>", head_fused_kernel<64, 16, 16, 8, 16>},  // UNINA_HEAD_ALT=2
-    {64, 16, 14, 8, "head_ws<64,16x14,8w>", head_ws_kernel<64, 16, 8>, true},          // default (UNINA_HEAD_ALT=3)
+    {64, 8, 16, 8, "head_fused<64,8x16,8w>", head_fused_kernel<64, 8, 16, 8, 16>},   // UNINA_HEAD_ALT=0: the tile form (round 1's), kept as the
+                                                                                     // independent implementation the row-streaming form is tested against
+    {64, 16, 14, 8, "head_ws<64,16x14,8w>", head_ws_kernel<64, 16, 8>, true},        // default
 };
 const HClass* find_hclass(int c) {
   // default: the row-streaming class (same-box A/B against the 8x16 tile class: the block dual 30.5 -> 23.5 us, -7 us serial
-  // latency, frames/s equal); UNINA_HEAD_ALT=0 / 1 / 2 select the tile classes
-  static const int alt = getenv("UNINA_HEAD_ALT") ? atoi(getenv("UNINA_HEAD_ALT")) : 3;
-  const int n = (int)(sizeof(kHeadClasses) / sizeof(kHeadClasses[0]));
-  if (alt >= 0 && alt < n && kHeadClasses[alt].c == c) return &kHeadClasses[alt];
-  return nullptr;
+  // latency, frames/s equal); UNINA_HEAD_ALT=0 selects the tile class
+  static const int alt = (getenv("UNINA_HEAD_ALT") && getenv("UNINA_HEAD_ALT")[0] == '0') ? 0 : 1;
+  return kHeadClasses[alt].c == c ? &kHeadClasses[alt] : nullptr;
 }
 constexpr int kMaxLds = 160 * 1024;
 int align_up(int v, int a) { return (v + a - 1) / a * a; }

@@ -62,7 +62,6 @@ struct ConvParams {
   int xcd_m_major;     // 1: an XCD owns a range of pixel tiles (input-heavy ops), 0: a range of channel tiles (weight-heavy)
   unsigned gn_magic;
   unsigned gm_magic, wo_magic, spt_magic, tx_magic;  // ceil(2^32/d) for d = grid_m, Wo, K-steps per tap, spatial tiles per row (0: d == 1), filled at launch
-  int debug_mode;      // debug ablations (results invalid): 1 = no loads inside the K loop, 2 = no LDS reads/MFMA, 3 = MFMA without LDS reads
   long long* stamps;   // debug: s_memtime stamps of workgroup (0,0) (nullptr = off): start, prologue issued, first data, loop end, end
   long long* wg_times; // debug (stamped dual kernels): [2 * blockIdx.x] = 100 MHz wall clock at the workgroup's start, [+1] at its end
 };
@@ -72,15 +71,9 @@ enum ConvConfig : int {
   kCfg64x64k64 = 0, kCfg64x64k32, kCfg128x64k64, kCfg128x64k32, kCfg128x128k64,
   kCfg128x32k64, kCfg128x32k32, kCfg128x16k64, kCfg32x64k64, kCfg32x64k64s8, kCfg64x64k64s6,
   kCfgHalo8x8n64, kCfgHalo8x8n32, kCfgHalo8x16n64, kCfgHalo8x16n32, kCfgHalo8x8n64k32, kCfgHalo8x16n32k32,
-  kCfgHalo16x16n64, kCfgHalo16x16n32, kCfgHalo8x16n64w41, kCfgHalo8x8n64w41,
-  kCfgHalo8x8n32k128, kCfgHalo8x8n32k256, kCfgHalo8x8n64k128, kCfgHalo8x16n32k128, kCfgHalo8x16n64k128,
   kCfg32x64k128, kCfg64x64k128,
   kCfgRegq8x16n64c128, kCfgRegq8x8n64c128, kCfgRegq8x8n64c256, kCfgRegq8x8n32c256, kCfgRegq8x16n64c64, kCfgRegq8x16n32c128,
-  kCfgRegq5x40n16c256, kCfgRegq5x80n16c128, kCfgRegq5x40n32c256, kCfgRegq10x40n16c128,
-  kCfgRegq8x8n64c256w4, kCfgRegq8x16n64c128w4, kCfgRegq8x8n128c256,
   kCfgRegqS2_8x8n64c64, kCfgRegqS2_8x16n64c64, kCfgRegqS2_8x8n64c128, kCfgRegqS2_4x8n64c128, kCfgRegqS2_8x16n64c32, kCfgRegqS2_8x8n32c128,
-  kCfgRegqW8x16n128c128, kCfgRegqW8x8n128c256,
-  kCfgRegq16x16n64c128, kCfgRegq8x16n64c256,
   kCfgWs16x16n64c128, kCfgWs8x16n64c256,
   kCfgWsS8x16n64c64, kCfgWsS8x16n64c128, kCfgWsS8x16n64c256,   // split fp16 (STRICT engines): weights-stationary, row-walking, channel-chunked
   kCfgCount
@@ -258,12 +251,6 @@ struct LaunchDesc {
 };
 hipError_t stem_desc(const StemParams& p, LaunchDesc* out);
 hipError_t stem_init();   // per device: dynamic-LDS limit of the tiled stem kernels
-// backbone.stem + the 3x3/s2 conv that follows it as ONE launch (conv_igemm.hip: stem_conv3x3s2_kernel)
-struct ConvParams;
-bool stemconv_supported(const StemParams& sp, const ConvParams& cp);
-size_t stemconv_params_bytes();
-hipError_t stemconv_desc(const StemParams& sp, const ConvParams& cp, LaunchDesc* d, void* params_out);
-hipError_t stemconv_launch(const StemParams& sp, const ConvParams& cp, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // SPPF pool pyramid: y1 = pool5(x), y2 = pool5(y1), y3 = pool5(y2) (== 5x5, 9x9, 13x13 clipped windows of x)
