@@ -1668,6 +1668,13 @@ int conv_dual_match(const ConvParams& a, const ConvParams& b) {
 
 const char* conv_dual_name(int kind) { return kind >= 0 && kind < kDualKinds ? kDual[kind].name : "?"; }
 
+int conv_dual_grid(int kind, const ConvParams& pa_in, const ConvParams& pb_in) {
+  if (kind < 0 || kind >= kDualKinds) return -1;
+  ConvParams pa = pa_in, pb = pb_in;
+  const dim3 ga = conv_prepare(pa, kDual[kind].cfg_a), gb = conv_prepare(pb, kDual[kind].cfg_b);
+  return (int)(ga.x * ga.y + gb.x * gb.y);
+}
+
 hipError_t conv_dual_launch(int kind, const ConvParams& pa_in, const ConvParams& pb_in, hipStream_t stream, int* grid_out) {
   if (kind < 0 || kind >= kDualKinds) return hipErrorInvalidValue;
   const DualKind& k = kDual[kind];

@@ -1787,7 +1787,7 @@ int unina_debug_dual_timeline(unina_engine_t* e, int op_index, long long* out, i
   if (op.d.kind != kOpConv || op.fuse_role || op.dual_with < 0 || op.dual_absorbed) return -UNINA_ERR_ARG;
   ConvParams pa = op.cp, pb = e->ops[op.dual_with].cp;
   // every workgroup writes wg_times[2 * blockIdx.x ..]: the buffer is sized from the grid, known BEFORE anything is launched
-  const int grid = e->ops[op_index].info.grid;
+  const int grid = conv_dual_grid(op.dual_kind, pa, pb);
   if (grid < 1 || 2 * grid + 2 > cap) return -UNINA_ERR_ARG;
   long long* d = nullptr;
   const size_t words = 18 + 2 * (size_t)grid;

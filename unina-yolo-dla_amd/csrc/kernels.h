@@ -93,6 +93,7 @@ hipError_t conv_launch(const ConvParams& p, const ConvLaunch& l, hipStream_t str
 int conv_dual_match(const ConvParams& a, const ConvParams& b);
 const char* conv_dual_name(int kind);
 hipError_t conv_dual_launch(int kind, const ConvParams& a, const ConvParams& b, hipStream_t stream, int* grid_out = nullptr);
+int conv_dual_grid(int kind, const ConvParams& a, const ConvParams& b);   // workgroups that launch will have (-1: bad kind)
 
 // ------------------------------------------------------------------------------------------------
 // Fused C3k2 block (model.py:76-110): cv1|cv2 -> n x Bottleneck(1x1, 3x3 + shortcut) -> cv3 in ONE launch, all
