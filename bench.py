@@ -301,7 +301,7 @@ def main():
             roofline["workgroups_span_note"] = str(ex)[:120]
 
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # (rank 0 at N = 1 only: at N > 1 the other ranks would wait on it)
             cpu = cpu_baseline(u, sd, S, conf, args.cpu_seconds, args.variant)
 
         line = {
