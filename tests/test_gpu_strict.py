@@ -134,3 +134,49 @@ def test_strict_engine_meets_north_star_tolerance_on_every_detection(pkg, strict
     assert total > 4000
     # the measured distance is two orders of magnitude inside the tolerance (CPU emulation: 5.5e-6 / 0.99999)
     assert worst_ds < 1e-4 and worst_iou > 0.9999, (worst_ds, worst_iou)
+
+
+def test_strict_1280_p2_head_config(pkg, sd7, torch_cuda):
+    """BASELINE configs[4] (1280x1280, P2 grid 320x320) on the STRICT engine: the reference's sampled head values within
+    fp32-like bounds, and its detections (model.py + postprocess.hpp, fixture) inside the north-star tolerance, every one."""
+    from unina_yolo_dla_amd import export
+    from unina_yolo_dla_amd.engine import Engine
+    gold = load_golden("frame1280_seed1234.npz")
+    e = Engine.from_state_dict(sd7, pkg.graph.Graph(in_h=1280, in_w=1280), precision=export.STRICT)
+    try:
+        x = torch_cuda.from_numpy(pkg.rng.frame(1234, 1280, 1280)).cuda()
+        heads = e.forward(x)
+        for name in pkg.graph.OUTPUT_NAMES:
+            flat = heads[name].reshape(-1)
+            np.testing.assert_allclose(flat[gold[f"idx/{name}"]], gold[f"vals/{name}"], atol=STRICT_HEAD_ATOL, rtol=0, err_msg=name)
+        np.testing.assert_allclose(heads["p4_cls"], gold["head/p4_cls"], atol=STRICT_HEAD_ATOL, rtol=0)
+        got = e.infer(x, 0.6, 0.45, 0.1)
+        ref = gold["ref_dets_conf0.6_q0.1"]
+        want = np.zeros(len(ref), dtype=got.dtype)
+        for f in ref.dtype.names:
+            want[f] = ref[f]
+        stats = compare(got, want, 0.6, min_iou=0.999, score_tol=1e-3, max_unmatched_frac=0.005)
+        assert stats["matched"] >= len(want) - 2 and stats["max_dscore"] < 1e-4, stats
+    finally:
+        e.close()
+
+
+def test_strict_graph_b_and_lite_p2_variants(pkg, torch_cuda, oracle_mod):
+    """The other layer tables on the STRICT engine (blocks without a split class simply stay on the per-op kernels): graph (B)
+    (qat.py's topology) and the lite_p2 variant of graph (A), heads against the fp32 oracle."""
+    from unina_yolo_dla_amd import export
+    from unina_yolo_dla_amd.engine import Engine
+    x = pkg.rng.frame(1234, 128, 128)
+    for kw in (dict(variant="B"), dict(lite_p2=True)):
+        g = pkg.graph.Graph(in_h=128, in_w=128, **kw)
+        sd = pkg.synth.make_state_dict(7, g)
+        osd = oracle_mod.StateDict(sd)
+        ref = oracle_mod.forward(osd, x, **kw)
+        osd.close()
+        e = Engine.from_state_dict(sd, g, precision=export.STRICT)
+        try:
+            heads = e.forward(torch_cuda.from_numpy(x).cuda())
+            for name in pkg.graph.OUTPUT_NAMES:
+                np.testing.assert_allclose(heads[name], ref[name], atol=STRICT_HEAD_ATOL, rtol=0, err_msg=f"{kw} {name}")
+        finally:
+            e.close()
