@@ -3,12 +3,18 @@
 // the workgroups read the SAME bytes (L2 hits after the first) or DISTINCT ones (L2 misses: Infinity Cache / HBM).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-template <int LOADS, int NT>
+// PERM: the lane -> 16-byte slot map the block / weights-stationary kernels used up to round 3 (lane (r = lane & 15, c = lane >> 4)
+// reads slot 4r + (c ^ G[r >> 2]) of its wave's 1-KiB block: the LDS-image order of the packed weights) instead of slot = lane
+template <int LOADS, int NT, bool PERM = false>
 __global__ __launch_bounds__(NT) void k(const floatx4* src, size_t wg_stride_vec, floatx4* out, long long* t) {
-  const floatx4* p = src + (size_t)blockIdx.x * wg_stride_vec + threadIdx.x;
+  const int lane = threadIdx.x & 63, r = lane & 15, c = lane >> 4;
+  const int g = (0x1320 >> (4 * (r >> 2))) & 3;   // G = (0, 2, 3, 1)
+  const int slot = PERM ? 4 * r + (c ^ g) : lane;
+  const floatx4* p = src + (size_t)blockIdx.x * wg_stride_vec + (threadIdx.x & ~63) + slot;
   floatx4 v[LOADS];
   __builtin_amdgcn_s_barrier();
   const long long t0 = __builtin_amdgcn_s_memtime();
@@ -51,7 +57,7 @@ void runbuf(const floatx4* src, floatx4* out, long long* t, int grid) {
   std::sort(h.begin(), h.end());
   printf("  BUFFER loads %2d waves x %2d KiB, %3d WGs, same bytes: median %6.0f cyc -> %5.1f B/clk/WG\n", NT / 64, LOADS, grid, (double)h[grid / 2], (double)LOADS * NT * 16 / h[grid / 2]);
 }
-template <int LOADS, int NT>
+template <int LOADS, int NT, bool PERM = false>
 void run(const floatx4* src, size_t total_vec, floatx4* out, long long* t, int grid, bool distinct, floatx4* trash, size_t trash_vec) {
   const size_t per_wg = (size_t)LOADS * NT;
   const size_t stride = distinct ? per_wg : 0;
@@ -59,13 +65,13 @@ void run(const floatx4* src, size_t total_vec, floatx4* out, long long* t, int g
   double best = 0;
   for (int rep = 0; rep < 3; ++rep) {
     if (distinct) hipMemset(trash, rep, trash_vec * 16);      // evict L2 (and part of the Infinity Cache)
-    hipLaunchKernelGGL((k<LOADS, NT>), dim3(grid), dim3(NT), 0, 0, src, stride, out, t);
+    hipLaunchKernelGGL((k<LOADS, NT, PERM>), dim3(grid), dim3(NT), 0, 0, src, stride, out, t);
     hipDeviceSynchronize();
     hipMemcpy(h.data(), t, grid * 8, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
     best = (double)per_wg * 16 / h[grid / 2];
   }
-  printf("  %2d waves x %2d KiB = %4zu KiB/WG, %3d WGs, %s: median %6.0f cyc -> %5.1f B/clk/WG (max %6lld cyc)\n", NT / 64, LOADS,
+  printf("  %s %2d waves x %2d KiB = %4zu KiB/WG, %3d WGs, %s: median %6.0f cyc -> %5.1f B/clk/WG (max %6lld cyc)\n", PERM ? "slot = 4r+(c^g)" : "slot = lane     ", NT / 64, LOADS,
          per_wg * 16 / 1024, grid, distinct ? "distinct bytes" : "same bytes    ", (double)h[grid / 2], best, h[grid - 1]);
 }
 int main() {
@@ -75,6 +81,13 @@ int main() {
   hipMalloc(&trash, total); 
   hipMalloc(&out, 1024 * 1024 * 16); hipMalloc(&t, 4096 * 8);
   for (int grid : {32, 256}) { runbuf<32, 256>(src, out, t, grid); runbuf<64, 256>(src, out, t, grid); runbuf<32, 512>(src, out, t, grid); }
+  for (int grid : {8, 100, 220}) {
+    run<32, 512, false>(src, total / 16, out, t, grid, false, trash, total / 16);
+    run<32, 512, true>(src, total / 16, out, t, grid, false, trash, total / 16);
+    run<64, 256, false>(src, total / 16, out, t, grid, false, trash, total / 16);
+    run<64, 256, true>(src, total / 16, out, t, grid, false, trash, total / 16);
+  }
+  if (getenv("PROBE_ALL"))
   for (int distinct = 0; distinct < 1; ++distinct)
     for (int grid : {8, 32, 128, 256, 512}) {
       run<32, 256>(src, total / 16, out, t, grid, distinct, trash, total / 16);

@@ -87,7 +87,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
   const int lds_lo = E::SPLIT ? p.lds_lo : 0;   // LDS distance image -> lo twin
 
   // ---- weight prefetch queue: element g of this wave's flat sequence lives in slot g % D ----
-  const unsigned char* wbase = p.wstream + (4 * l15 + (lq ^ swz_g(l15))) * 16;   // this lane's 16 bytes of any block
+  const unsigned char* wbase = p.wstream + lane * 16;   // this lane's 16 bytes of any block
   typename E::frag q[D];
   // per-channel constants of every step -> LDS
   float* bias_lds = reinterpret_cast<float*>(smem + p.off_bias);
@@ -407,7 +407,7 @@ __device__ __forceinline__ void head_fused_body(const HeadParams& p, int bid, un
   const int tyi = fast_div(bid, p.tiles_x_magic), txi = bid - tyi * p.tiles_x;
   const int ty0 = tyi * TH, tx0 = txi * TW;
 
-  const unsigned char* wbase = p.wstream + (4 * l15 + (lq ^ swz_g(l15))) * 16;
+  const unsigned char* wbase = p.wstream + lane * 16;
   half8 q[D];
 
   float* bias_lds = reinterpret_cast<float*>(smem + p.off_bias);
@@ -529,7 +529,7 @@ __device__ __forceinline__ void head_ws_body(const HeadParams& p, int bid, unsig
   const int ty0 = tyi * TH, tx0 = txi * TWO;
   const int br = wid / (C / 16);                                  // layer-1 branch of this wave's subtile: 0 = cls, 1 = reg
 
-  const unsigned char* wbase = p.wstream + (4 * l15 + (lq ^ swz_g(l15))) * 16;
+  const unsigned char* wbase = p.wstream + lane * 16;
   frag w0[KBL], w1[KBL], w2[CB];
   auto ld0 = [&](auto kc) { w0[decltype(kc)::value] = *reinterpret_cast<const frag*>(wbase + (size_t)(decltype(kc)::value * NS + wid) * 1024); __builtin_amdgcn_sched_barrier(0); };
   auto ld1 = [&](auto kc) { w1[decltype(kc)::value] = *reinterpret_cast<const frag*>(wbase + (size_t)(KBL * NS + decltype(kc)::value * NS + wid) * 1024); __builtin_amdgcn_sched_barrier(0); };

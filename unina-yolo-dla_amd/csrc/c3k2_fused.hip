@@ -224,9 +224,18 @@ bool c3k2_layout(C3k2Params* p) {
   return off <= kMaxLds;
 }
 
+void weight_block_to_lane_order(const unsigned char* in, unsigned char* out) {
+  static const int G[4] = {0, 2, 3, 1};
+  for (int r = 0; r < 16; ++r)
+    for (int c = 0; c < 4; ++c) memcpy(out + (16 * c + r) * 16, in + (4 * r + (c ^ G[r >> 2])) * 16, 16);
+}
+
 // Packs the weights of a block's convs (each given as the exporter's [n/16][K/32] 1-KiB fragment blocks, up to two
 // output slices) into the stream the block kernels read: per conv, k-block-major [K/32][N/16] blocks (the wave that
 // owns subtile j of step s reads blocks blk(s) + kb*ns + j, kb = 0..), and concatenates the biases.
+// Inside a 1-KiB block the 16-byte slots go from the file's LDS-image order to LANE order (weight_block_to_lane_order,
+// kernels.h): the kernels take weights straight into registers, lane l loading slot l -- one contiguous KiB per wave
+// instruction (tools/probes/ingest_probe: 107 against 55 bytes per clock and CU for the permuted form).
 void block_pack(const C3k2Conv* convs, int nconv, std::vector<unsigned char>* stream, std::vector<float>* bias, int dtype) {
   stream->clear();
   bias->clear();
@@ -240,7 +249,8 @@ void block_pack(const C3k2Conv* convs, int nconv, std::vector<unsigned char>* st
       for (int s = 0; s < ns; ++s) {
         const int seg = s * 16 < cv.n[0] ? 0 : 1;
         const int ls = seg ? s - cv.n[0] / 16 : s;
-        memcpy(stream->data() + base + ((size_t)kb * ns + s) * wblk, cv.w[seg] + ((size_t)ls * kbn + kb) * wblk, wblk);
+        for (size_t h = 0; h < wblk; h += 1024)
+          weight_block_to_lane_order(cv.w[seg] + ((size_t)ls * kbn + kb) * wblk + h, stream->data() + base + ((size_t)kb * ns + s) * wblk + h);
       }
     for (int seg = 0; seg < 2; ++seg)
       for (int i = 0; i < cv.n[seg]; ++i) bias->push_back(cv.bias[seg][i]);

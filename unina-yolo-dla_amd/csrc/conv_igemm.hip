@@ -779,7 +779,7 @@ __device__ __forceinline__ void conv3x3_regq_body(const ConvParams& p, int bid, 
   for (int j = 0; j < WN; ++j) {
     int nsub = (nb0 >> 4) + wn * WN + j;
     nsub = nsub * 16 < n_pad ? nsub : (n_pad >> 4) - 1;
-    wptr[j] = static_cast<const unsigned char*>(sg.w) + (size_t)nsub * KB * PE::WBLK + (4 * l15 + (lq ^ swz_g(l15))) * 16;
+    wptr[j] = static_cast<const unsigned char*>(sg.w_lane) + (size_t)nsub * KB * PE::WBLK + lane * 16;   // lane-order twin: one contiguous KiB per load
   }
   frag q[D];
   auto fetch = [&](auto gc) {
@@ -901,7 +901,7 @@ __device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, in
 
   int nsub = (nb0 >> 4) + wid;
   nsub = nsub * 16 < n_pad ? nsub : (n_pad >> 4) - 1;   // tail subtile: clamp (never stored)
-  const unsigned char* wptr = static_cast<const unsigned char*>(sg.w) + (size_t)nsub * KB * 1024 + (4 * l15 + (lq ^ swz_g(l15))) * 16;
+  const unsigned char* wptr = static_cast<const unsigned char*>(sg.w_lane) + (size_t)nsub * KB * 1024 + lane * 16;   // lane-order twin
   frag w[KB];
   const int n = nb0 + wid * 16 + lq * 4;                // slice-relative first channel of this lane's 4 outputs
   const bool n_ok = n < sg.n_count;
@@ -1088,7 +1088,7 @@ __device__ __forceinline__ void conv3x3_ws_s16_body(const ConvParams& p, int bid
 
   int nsub = (nb0 >> 4) + wid;
   nsub = nsub * 16 < n_pad ? nsub : (n_pad >> 4) - 1;   // tail subtile: clamp (never stored)
-  const unsigned char* wptr = static_cast<const unsigned char*>(sg.w) + (size_t)nsub * (9 * CB) * 2048 + (4 * l15 + (lq ^ swz_g(l15))) * 16;
+  const unsigned char* wptr = static_cast<const unsigned char*>(sg.w_lane) + (size_t)nsub * (9 * CB) * 2048 + lane * 16;   // lane-order twin
   const int n = nb0 + wid * 16 + lq * 4;                // slice-relative first channel of this lane's 4 outputs
   const bool n_ok = n < sg.n_count;
   const floatx4 bias = *reinterpret_cast<const floatx4*>(sg.bias + (n_ok ? n : 0));
@@ -1519,6 +1519,8 @@ bool conv_config_valid(const ConvParams& p, int cfg) {
   if (!c.fn) return false;
   if (c.cin) {  // register-queue kernel: 3x3 on exactly its Cin and stride (fp16 / int8 rows of the table); every slice at least one tile wide
     if (p.Cin != c.cin || p.ksize != 3 || p.stride != c.stride || p.pad != 1 || smem_for(p, c) > kMaxLds) return false;
+    for (int s = 0; s < p.nseg; ++s)
+      if (!p.seg[s].w_lane) return false;   // these kernels read the lane-order twin of the weights
     if (c.ws) {
       if (!p.relu || p.res || !p.zeros) return false;
       for (int s = 0; s < p.nseg; ++s)

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(NW * 64) void conv_pair_kernel(const PairParams p) 
   const int tyi = fast_div(bid, p.tiles_x_magic), txi = bid - tyi * p.tiles_x;
   const int ty0 = tyi * TH, tx0 = txi * TW;
 
-  const unsigned char* wbase = p.wstream + (4 * l15 + (lq ^ swz_g(l15))) * 16;
+  const unsigned char* wbase = p.wstream + lane * 16;
   typename E::frag q[D];
   float* cst = reinterpret_cast<float*>(smem + p.off_bias);
   floatx4 cregs[kConstVecs];

@@ -54,6 +54,7 @@ struct PlannedOp {
   int tail_op = -1;         // role 1, C3k2: index of the 1x1 conv that runs as the block kernel's last step
   int tail_kind = 0;        // 1: lateral 1x1 + x2 upsample store; 2: plain 1x1 ConvBlock (same resolution); 3: 1 with int8 in, fp16 out
   uint64_t wt_off = 0;      // stem: blob offset of the transposed weights [27][Co] (appended at load)
+  uint64_t w_lane_off[2] = {0, 0};   // conv: blob offset of each slice's weights in LANE order (appended at load; 0 = none)
   int fuse_pre = 0;         // role 1, C3k2: 1 = this op is the 3x3/s2 conv in front of the block (the block's cv1|cv2 is the NEXT op)
   int quant_op = -1;        // role 1, fp16 C3k2 in an INT8 engine: the QUANT op of the block's output that the kernel's store absorbs
   int hid = 0, nb = 0;      // role 1: hidden width, bottleneck count
@@ -312,6 +313,7 @@ int plan(unina_engine* e) {
         const Buffer& db = e->bufs[sd.dst_buf];
         ConvSeg& cs = p.seg[s];
         cs.w = blob + sd.w_off;
+        cs.w_lane = op.w_lane_off[s] ? blob + op.w_lane_off[s] : nullptr;
         cs.bias = reinterpret_cast<const float*>(blob + sd.b_off);
         cs.mult = sd.m_off ? reinterpret_cast<const float*>(blob + sd.m_off) : nullptr;
         if (dt == kI8 && !cs.mult) return fail(e, UNINA_ERR_FORMAT, "op %zu: int8 conv without multipliers", i);
@@ -1283,7 +1285,7 @@ int fill_post_params(unina_engine* e, PostParams* pp, float conf, float iou, flo
       pp->h1_c[h] = c.Cin;
       for (int k = 0; k < 2; ++k) {
         pp->h1_coff[h][k] = c.seg[k].src_coff;
-        pp->w2[h][k] = static_cast<const unsigned char*>(c.seg[k].w);
+        pp->w2[h][k] = static_cast<const unsigned char*>(c.seg[k].w_lane);
         pp->b2[h][k] = c.seg[k].bias;
       }
     }
@@ -1379,6 +1381,25 @@ int unina_load_engine(const char* path, int device_id, unina_engine_t** out) {
     if (e->out_buf[i] < 0) return bail(UNINA_ERR_FORMAT, "engine file lacks a head output buffer");
   }
   if (e->images_buf < 0) return bail(UNINA_ERR_FORMAT, "engine file lacks the images input buffer");
+
+  // convs: a LANE-order twin of every slice's weight blocks (kernels.h weight_block_to_lane_order) for the kernels that take
+  // weights straight into registers (conv3x3_regq / conv3x3_ws / the decode launch's output convs); the file's order stays
+  // what the LDS-DMA kernels copy into LDS
+  for (auto& op : e->ops) {
+    if (op.d.kind != kOpConv) continue;
+    const uint32_t sdt = e->bufs[op.d.src_buf].d.dtype;
+    for (uint32_t s = 0; s < op.d.nseg; ++s) {
+      const SegDesc& sd = op.d.seg[s];
+      const uint64_t wbytes = (uint64_t)sd.n_pad * op.d.ksize * op.d.ksize * op.d.cin * ((sdt == kBufF32Nhwc || sdt == kBufS16Nhwc) ? 4 : (sdt == kBufI8Nhwc ? 1 : 2));
+      if (wbytes == 0 || wbytes % 1024) continue;
+      blob.resize((blob.size() + 255) & ~(size_t)255);
+      op.w_lane_off[s] = blob.size();
+      blob.resize(blob.size() + wbytes);
+      for (uint64_t b = 0; b < wbytes; b += 1024)
+        weight_block_to_lane_order(reinterpret_cast<const unsigned char*>(blob.data()) + sd.w_off + b,
+                                   reinterpret_cast<unsigned char*>(blob.data()) + op.w_lane_off[s] + b);
+    }
+  }
 
   // stem: a [27][Co] transposed copy of its weights (wave-uniform scalar loads in stem_conv_kernel)
   for (auto& op : e->ops) {

@@ -25,6 +25,8 @@ struct s16_t { _Float16 v; };                        // one plane element of a k
 // ------------------------------------------------------------------------------------------------
 struct ConvSeg {
   const void* w;       // packed 1-KiB fragment blocks [n_pad/16][K/kb][64 slots][16 B], kb = 32 (fp16) / 16 (fp32)
+  const void* w_lane;  // the same blocks with their 16-byte slots in LANE order (engine.hip appends the twin at load): what the
+                       // register-path kernels (conv3x3_regq, conv3x3_ws*) read; nullptr if the slice has none
   const float* bias;   // [n_pad]
   void* dst;           // NHWC destination (engine dtype), channel offset already applied (unused when planar)
   float* dst_planar;   // fp32 [n][Ho*Wo] destination (head outputs), or nullptr
@@ -151,6 +153,12 @@ hipError_t c3k2_launch(const C3k2Params& p, hipStream_t stream);
 hipError_t c3k2_launch_stamped(const C3k2Params& p, hipStream_t stream);   // debug twin with per-step stamps (p.stamps); InvalidValue if the class has none
 const char* c3k2_kernel_name(int hid, int nb, int cin, int tail = 0, int dtype = kF16, int cpre = 0, int cx = 0);
 int c3k2_block_threads(int hid, int nb, int cin, int tail = 0, int dtype = kF16, int cpre = 0, int cx = 0);
+
+// One 1-KiB weight fragment block (16 rows x 4 chunks of 16 bytes) from the engine file's LDS-image order -- slot(r, c) =
+// 4r + (c ^ G[r >> 2]), G = (0,2,3,1): what the LDS-DMA kernels (conv_glds, conv3x3_halo) copy into LDS and read
+// conflict-free -- to LANE order, slot = 16c + r = the MFMA lane that holds (row r, k-chunk c): what every kernel that takes
+// weights straight into registers reads, one contiguous KiB per wave instruction.
+void weight_block_to_lane_order(const unsigned char* in, unsigned char* out);   // (c3k2_fused.hip)
 
 // Generic packer of the block kernels' weight stream: per conv, k-block-major [K/32][N/16] 1-KiB blocks (slice 0's
 // channel subtiles first), then the concatenated biases (n entries per slice).
@@ -327,7 +335,7 @@ struct PostParams {
   long long h1_lo[3];        // != 0: a split-fp16 tensor (STRICT engines): byte distance to its lo plane; w2 then holds (hi | lo) block pairs
   int h1_ld[3], h1_c[3];     // channels per pixel of that buffer; input channels of each output conv (multiple of 32)
   int h1_coff[3][2];         // channel offset of the cls / reg branch's input
-  const unsigned char* w2[3][2];  // packed 1-KiB fragment blocks [1][C/32] (16 rows) of the cls / reg output conv
+  const unsigned char* w2[3][2];  // 1-KiB fragment blocks [1][C/32] (16 rows, LANE order: ConvSeg::w_lane) of the cls / reg output conv
   const float* b2[3][2];     // [16] biases
   int bstart[4];             // launch 1 of mode 2: first workgroup of each head, total (post_plan_blocks)
   int cpb[3];                // cells per workgroup of each head: 256 (planes, or 4 pixel subtiles per wave) or 64 (1 per wave)

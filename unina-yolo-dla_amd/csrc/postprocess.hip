@@ -646,7 +646,7 @@ __global__ __launch_bounds__(kPost2Block) void post_decode_kernel(const PostPara
     const int l15 = lane & 15, lq = lane >> 4;
     const int kblocks = p.h1_c[h] >> 5, ld = p.h1_ld[h];
     const _Float16* h1 = static_cast<const _Float16*>(p.h1[h]);
-    const int slot = (4 * l15 + (lq ^ dev::swz_g(l15))) * 16;   // this lane's 16 bytes of any packed weight block
+    const int slot = lane * 16;                      // this lane's 16 bytes of any weight block of the lane-order twin
     for (int si = 0; si < nsub; ++si) {
       const int sub = wv * nsub + si;
       int pix = cell0 + sub * 16 + l15;
