@@ -309,8 +309,9 @@ def test_non_square_input_and_empty_result(pkg, sd7, oracle_mod, oracle_sd7, tor
         e.set_fusion(False)
         plain = e.forward(xd)
         for k in plain:
-            assert np.array_equal(heads[k], plain[k]), k
-        assert e.infer(xd, 0.5, 0.45, 0.1).tobytes() == got.tobytes()
+            same_head(heads[k], plain[k], k)
+        from detcmp import compare
+        compare(e.infer(xd, 0.5, 0.45, 0.1), got, 0.5, min_iou=0.999, score_tol=1e-3, max_unmatched_frac=0.005)   # (P3 / P4 heads: same_head)
     finally:
         e.close()
 
@@ -319,7 +320,7 @@ def test_non_square_input_and_empty_result(pkg, sd7, oracle_mod, oracle_sd7, tor
 def test_other_class_counts(pkg, oracle_mod, torch_cuda, nc, cls_scale, thr):
     """num_classes is a model parameter (model.py:331-333; the node hard-codes 4, perception_node.cpp:630-639): the engine
     takes it from the engine file. 1 and 7 classes (the head's output rows are padded to 16 per branch): heads and
-    detections vs the fp32 oracle, fused = per-op bit for bit."""
+    detections vs the fp32 oracle, fused = per-op (same_head)."""
     from unina_yolo_dla_amd.engine import Engine
     g = pkg.graph.Graph(num_classes=nc, in_h=256, in_w=256)
     sd = pkg.synth.make_state_dict(7, g, head_scales={n: (cls_scale if n.endswith("cls") else 2.0) for n in pkg.graph.OUTPUT_NAMES})
@@ -340,7 +341,7 @@ def test_other_class_counts(pkg, oracle_mod, torch_cuda, nc, cls_scale, thr):
         e.set_fusion(False)
         plain = e.forward(xd)
         for k in plain:
-            assert np.array_equal(heads[k], plain[k]), k
+            same_head(heads[k], plain[k], k)
     finally:
         e.close()
         osd.close()
@@ -549,7 +550,10 @@ def test_determinism_and_rebinding(pkg, eng640, torch_cuda):
 def test_tile_configs_and_autotune_are_bit_identical(pkg, sd7, torch_cuda, precision):
     """Every conv tile configuration accumulates each output's K terms in the same order (fp16) or exactly (int8), so
     forcing any fitting configuration -- im2col, halo and register-queue kernels, stride 1 and 2 -- or letting the
-    autotuner choose must not change a single bit of the outputs."""
+    autotuner choose must not change a single bit of the outputs. The one exception is the fp16 chunked weights-stationary
+    kernel (conv3x3_ws<f16,...>, conv_igemm.hip conv3x3_wsc_body): it sums chunk-major, its fp32 accumulators differ in the
+    last bits and an fp16 output flips its last place now and then -- wherever it runs the heads must agree within 5e-3
+    (the fp16 format's own noise is 3e-3 on a score)."""
     from unina_yolo_dla_amd import export
     from unina_yolo_dla_amd.engine import Engine, calibrate_amax
     g = pkg.graph.Graph(in_h=128, in_w=128)
@@ -564,7 +568,10 @@ def test_tile_configs_and_autotune_are_bit_identical(pkg, sd7, torch_cuda, preci
         e.set_fusion(False)                                   # tile configurations belong to the per-op kernels
         base = {k: v.copy() for k, v in e.forward(x).items()}
         for k in base:
-            assert np.array_equal(fused[k], base[k]), ("fusion", k)
+            if precision == "fp16":   # (the fused frame runs the P3 | P4 head pairs on the chunked kernel)
+                np.testing.assert_allclose(fused[k], base[k], atol=5e-3, rtol=0, err_msg=f"fusion {k}")
+            else:
+                assert np.array_equal(fused[k], base[k]), ("fusion", k)
         infos = e.op_infos()
         ncfg = len(e.conv_configs())
         tried = 0
@@ -574,15 +581,23 @@ def test_tile_configs_and_autotune_are_bit_identical(pkg, sd7, torch_cuda, preci
                 continue
             tried += 1
             out = e.forward(x)
+            chunked = "conv3x3_ws<f16" in e.conv_configs()[cfg]
             for k in base:
-                assert np.array_equal(out[k], base[k]), (e.conv_configs()[cfg], k)
+                if chunked:
+                    np.testing.assert_allclose(out[k], base[k], atol=5e-3, rtol=0, err_msg=f"{e.conv_configs()[cfg]} {k}")
+                else:
+                    assert np.array_equal(out[k], base[k]), (e.conv_configs()[cfg], k)
             for i in applied:
                 e.set_op_config(i, -1)
         assert tried >= 6
         e.autotune(x, iters=3)
         out = e.forward(x)
+        chunked = any("conv3x3_ws<f16" in o["kernel"] for o in e.op_infos())
         for k in base:
-            assert np.array_equal(out[k], base[k]), ("autotune", k)
+            if chunked:
+                np.testing.assert_allclose(out[k], base[k], atol=5e-3, rtol=0, err_msg=f"autotune {k}")
+            else:
+                assert np.array_equal(out[k], base[k]), ("autotune", k)
     finally:
         e.close()
 
@@ -603,11 +618,21 @@ BLOCK_OUTPUTS = ("neck.cat_fpn2", "neck.cat_fpn1", "neck.cat_pan2", "neck.cat_pa
                  "backbone.sppf.cat")    # (sppf.cv1 runs as the last step of stage3's block kernel)
 
 
+def same_head(a, b, name):
+    """fp16 engines, fused frame vs per-op table: the P2 head must agree bit for bit; the P3 / P4 heads run their two 3x3
+    layers on the chunked weights-stationary pair kernel in the fused frame (chunk-major sum order, conv_igemm.hip
+    conv3x3_wsc_body: last-bit differences of fp16 outputs) and agree within 5e-3."""
+    if name.startswith("p2_"):
+        assert np.array_equal(a, b), name
+    else:
+        np.testing.assert_allclose(a, b, atol=5e-3, rtol=0, err_msg=name)
+
+
 @pytest.mark.parametrize("size", [64, 640, 96])
 def test_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
     """Each C3k2 block (model.py:76-110) and the P2 DetectionHead (model.py:274-303) as ONE launch with its
-    intermediates in LDS (csrc/c3k2_fused.hip, head_fused.hip) vs the per-conv launches: same MFMA, same K order, same fp16 rounding points -> every block output and every head
-    must agree bit for bit. 96x96 gives 24/12/6-pixel maps: partial tiles on every level."""
+    intermediates in LDS (csrc/c3k2_fused.hip, head_fused.hip) vs the per-conv launches: same MFMA, same K order, same fp16 rounding points -> every block output and the P2
+    head must agree bit for bit (the P3 / P4 heads: same_head). 96x96 gives 24/12/6-pixel maps: partial tiles on every level."""
     from unina_yolo_dla_amd.engine import Engine
     e = Engine.from_state_dict(sd7, pkg.graph.Graph(in_h=size, in_w=size))
     try:
@@ -625,11 +650,12 @@ def test_block_fusion_is_bit_identical(pkg, sd7, torch_cuda, size):
         for b in BLOCK_OUTPUTS:
             assert np.array_equal(written(b, fused_bufs[b]), written(b, e.read_buffer(b))), b
         for k in plain:
-            assert np.array_equal(fused[k], plain[k]), k
+            same_head(fused[k], plain[k], k)
         assert e.set_fusion(True) == 9
         again = e.forward(x)
         for k in plain:
-            assert np.array_equal(again[k], plain[k]), k
+            assert np.array_equal(again[k], fused[k]), k
+            same_head(again[k], plain[k], k)
     finally:
         e.close()
 
@@ -693,11 +719,20 @@ def test_frame_graph_and_tiled_nms_match_the_plain_forms(pkg, sd7, torch_cuda, m
     assert groups == 9
     monkeypatch.setenv("UNINA_FULL_GRAPH", "0")
     monkeypatch.setenv("UNINA_POST_SPLIT", "0")
-    monkeypatch.setenv("UNINA_FUSE", "0")
     plain, groups = run()
-    assert groups == 0
+    assert groups == 9
     assert fast == plain
     assert len(fast[3]) > len(fast[0]) and fast[0] == fast[4] and fast[0] != fast[1]
+    # ... and the per-op table on top (no block kernels, no pair launches: the P3 / P4 head layers on the im2col kernels, whose
+    # sum order differs from the chunked pair kernel's in the last bits -- same_head): every detection inside the north-star tolerance
+    monkeypatch.setenv("UNINA_FUSE", "0")
+    perop, groups = run()
+    assert groups == 0
+    from detcmp import compare
+    from unina_yolo_dla_amd.engine import DET_DTYPE
+    for (s_, c, i, q), a_, b_ in zip(calls, fast, perop):
+        if c >= 0.1:   # (the 0.02 call overflows MAX_DETECTIONS: the top-1024 cut is compared exactly above)
+            compare(np.frombuffer(a_, DET_DTYPE), np.frombuffer(b_, DET_DTYPE), c, min_iou=0.999, score_tol=1e-3, max_unmatched_frac=0.005, iou_thr=i)
 
 
 def test_async_result_layout(pkg, eng640, torch_cuda):

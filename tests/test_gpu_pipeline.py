@@ -126,38 +126,63 @@ open(sys.argv[1], "w").write("\n".join(out))
 
 
 @pytest.mark.parametrize("env", [{"UNINA_DUAL_WS": "0"}, {"UNINA_HEAD_ALT": "0"}, {"UNINA_DUAL_WS": "0", "UNINA_HEAD_ALT": "0"}])
-def test_weights_stationary_kernels_match_the_tile_kernels_bit_for_bit(env, tmp_path):
-    """Round 2's weights-stationary kernels -- conv_dual_head3x3_ws for the P3 | P4 head pairs, head_ws for the P2 head (both the
-    defaults) -- accumulate every output in the K order of the tile kernels they replaced (conv_dual_head3x3_big, head_fused:
-    UNINA_DUAL_WS=0 / UNINA_HEAD_ALT=0, read once per process, hence child processes): head tensors and detections must be
-    the same bytes, at 640x640 and at a size with partial tiles / strips."""
+def test_weights_stationary_kernels_match_the_tile_kernels(env, tmp_path):
+    """The weights-stationary kernels (the defaults) against the tile-kernel family they replaced, which stays compiled in as an
+    independent implementation (UNINA_DUAL_WS=0 / UNINA_HEAD_ALT=0, read once per process, hence child processes), at 640x640 and
+    at a size with partial tiles / strips:
+      * head_ws (P2 head) accumulates every output in the K order of head_fused: the same BYTES;
+      * conv_dual_head3x3_ws (P3 | P4 head pairs) sums chunk-major -- (channel chunk, ky, kx, cb) instead of (ky, kx, cb), see
+        conv3x3_wsc_body -- so its fp32 accumulators differ in the last bits and an fp16 output flips its last place now and
+        then (two such layers, then the fp32 output convs over them): head tensors within 2e-3 of each other (measured: see the
+        printed line), detections inside a tenth of the north-star tolerance."""
+    from detcmp import compare
     code = r'''
-import sys, hashlib, numpy as np, torch
+import sys, numpy as np, torch
 sys.path.insert(0, %r)
 import unina_yolo_dla_amd as u
 from unina_yolo_dla_amd.engine import Engine
-out = []
+out = {}
 for (h, w) in ((640, 640), (224, 352)):
     g = u.graph.Graph(in_h=h, in_w=w)
     e = Engine.from_state_dict(u.synth.make_state_dict(7), g)
     for seed in (1234, 1235):
         x = torch.from_numpy(u.rng.frame(seed, h, w)).cuda()
-        heads = e.forward(x)
-        out.append(" ".join(hashlib.sha256(np.ascontiguousarray(heads[k]).tobytes()).hexdigest()[:16] for k in sorted(heads)))
-        out.append(hashlib.sha256(e.infer(x, 0.3, 0.45, 0.1).tobytes()).hexdigest())
-    out.append(",".join(sorted(set(o["kernel"].split("<")[0] for o in e.op_infos() if "head" in o["kernel"]))))
+        for k, v in e.forward(x).items():
+            out["%%dx%%d_%%d_%%s" %% (h, w, seed, k)] = np.ascontiguousarray(v)
+        out["%%dx%%d_%%d_dets" %% (h, w, seed)] = e.infer(x, 0.3, 0.45, 0.1)
+    out["%%dx%%d_kernels" %% (h, w)] = np.array(",".join(sorted(set(o["kernel"].split("<")[0] for o in e.op_infos() if "head" in o["kernel"]))))
     e.close()
-open(sys.argv[1], "w").write("\n".join(out))
+np.savez(sys.argv[1], **out)
 ''' % ROOT
     def run(extra, name):
         out = str(tmp_path / name)
         r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=280)
         assert r.returncode == 0, r.stderr[-2000:]
-        return open(out).read().split("\n")
-    base, alt = run({}, "base.txt"), run(env, "alt.txt")
-    assert len(base) == 10 and "head64ws" in base[4] and "conv_dual_head3x3_ws" in base[4]      # the defaults are the new kernels
-    assert alt[4] != base[4]                                                                        # ... and the switch selected the old ones
-    assert [l for i, l in enumerate(alt) if i % 5 != 4] == [l for i, l in enumerate(base) if i % 5 != 4]
+        return np.load(out)
+    base, alt = run({}, "base.npz"), run(env, "alt.npz")
+    kb, ka = str(base["640x640_kernels"]), str(alt["640x640_kernels"])
+    assert "head64ws" in kb and "conv_dual_head3x3_ws" in kb      # the defaults are the new kernels
+    assert ka != kb                                                 # ... and the switch selected the old ones
+    exact = "UNINA_DUAL_WS" not in env
+    worst, frac = 0.0, 0.0
+    for k in base.files:
+        if k.endswith("_kernels"):
+            continue
+        if k.endswith("_dets"):
+            if exact:
+                assert base[k].tobytes() == alt[k].tobytes(), k
+            else:
+                st = compare(base[k], alt[k], 0.3, min_iou=0.999, score_tol=1e-3, max_unmatched_frac=0.005)
+                assert st["matched"] >= len(alt[k]) - 3, (k, st)
+            continue
+        if exact or "_p2_" in k:     # (the P2 head does not run on the pair kernel)
+            assert np.array_equal(base[k], alt[k]), k
+        else:
+            d = np.abs(base[k] - alt[k])
+            worst, frac = max(worst, float(d.max())), max(frac, float((d > 0).mean()))
+    if not exact:
+        assert worst < 5e-3, f"pair kernel vs tile kernels: max |delta| {worst:.2e}, differing share {frac:.4f}"
+        print(f"pair kernel vs tile kernels: max |delta| {worst:.2e}, differing share {frac:.4f}")
 
 
 def test_serial_latency_entry_point_times_unina_infer_inside_the_abi(pkg, sd7, torch_cuda):

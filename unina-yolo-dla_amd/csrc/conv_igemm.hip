@@ -1028,18 +1028,6 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws(const ConvParams p) {
   conv3x3_ws_body<TH, CIN, NW, false, T>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
-// the pair on the weights-stationary kernel: 4 waves, ONE wave per SIMD (Cin 256 keeps 288 weight registers per lane).
-// Conv B's workgroups (P4: twice the weight bytes per workgroup, the longer life) take the FIRST block ids: they are
-// dispatched first. (Block ids only decide placement: `nb` = conv B's workgroup count.)
-__global__ __launch_bounds__(256) void conv_dual_head3x3_ws(const ConvParams pa, const ConvParams pb, int nb) {
-  if ((int)blockIdx.x < nb) conv3x3_ws_body<8, 256, 4>(pb, (int)blockIdx.x, nb);
-  else conv3x3_ws_body<16, 128, 4>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
-}
-__global__ __launch_bounds__(256) void conv_dual_head3x3_ws_stamped(const ConvParams pa, const ConvParams pb, int nb) {
-  if ((int)blockIdx.x < nb) conv3x3_ws_body<8, 256, 4, true>(pb, (int)blockIdx.x, nb);
-  else conv3x3_ws_body<16, 128, 4, true>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
-}
-
 // INT8 engines: the same pair on int8 tensors (18 / 36 weight blocks of 64 k per wave: 72 / 144 registers)
 __global__ __launch_bounds__(256) void conv_dual_head3x3_ws_i8(const ConvParams pa, const ConvParams pb, int nb) {
   if ((int)blockIdx.x < nb) conv3x3_ws_body<8, 256, 4, false, signed char>(pb, (int)blockIdx.x, nb);
@@ -1047,21 +1035,27 @@ __global__ __launch_bounds__(256) void conv_dual_head3x3_ws_i8(const ConvParams 
 }
 
 
-// ============================================================================================ 3x3 weights-stationary, split fp16
-// STRICT engines (kS16): the row-walking / weights-stationary scheme of conv3x3_ws_body on fp16 (hi, lo) pairs. A wave owns ONE
-// 16-channel subtile and a TH x 16 pixel tile; the fragment pair of patch row rho (kx, channel block) feeds the three output
-// rows rho, rho-1, rho-2 -- 2 ds_read_b128 per 9 MFMAs (3 taps x the 3 MFMAs of a split product), against 2 per 3 in the
-// register-queue kernel, whose LDS reads (and twice-fetched weight blocks) bound the strict engine's head layers (44 us per
-// P3 | P4 pair). A (hi | lo) weight block pair is 8 VGPRs, so the input runs in NCHUNK chunks of CC channels (64: 9 taps x 2
-// blocks = 144 VGPRs per chunk): the weights of chunk c + 1 are requested into a SECOND register set and its slice of the
-// patch (both planes) into staging registers BEFORE chunk c's K loop starts, so every ingest but the first is hidden behind
-// matrix work (with all of a 128-channel chunk in one set the P4 conv spent 2 x 4 us waiting for weights: 32 us per pair);
-// the patch slices alternate between two LDS buffers (padded pixel pitch, no swizzle: immediate-offset reads), and the TH
-// accumulators live across the chunks. (The sum order is chunk-major: the split type has no bit-identity contract between
-// kernel families, its parity is the north-star tolerance against the fp32 oracle.)
-template <int TH, int CIN, int NCHUNK, int NW, bool STAMPS = false>
-__device__ __forceinline__ void conv3x3_ws_s16_body(const ConvParams& p, int bid, int nwg) {
-  typedef half8x2 frag;
+// ============================================================================================ 3x3 weights-stationary, chunked
+// The row-walking / weights-stationary scheme of conv3x3_ws_body with the input channels run in NCHUNK chunks of CC channels,
+// for fp16 (the headline engine's P3 | P4 head pairs) and split fp16 (STRICT engines, kS16: (hi, lo) pairs, 3 MFMAs per product).
+// A wave owns ONE 16-channel subtile and a TH x 16 pixel tile; the fragment of patch row rho (kx, channel block) feeds the three
+// output rows rho, rho-1, rho-2. What the chunks buy: a wave's vector-memory requests cost it ~66 cycles of ISSUE each
+// (tools/probes/ingest_probe: one 1-KiB load per 66 cycles and wave, whatever is in flight), and an in-order wave issues no MFMA
+// behind a blocked request -- conv3x3_ws_body spends 7 700-8 700 cycles requesting its 72 + 24 KiB before the first MFMA of the
+// P4 conv. Here only chunk 0 (its weights and its slice of the patch: 24 requests at Cin 256) is requested up front; the
+// requests of chunk c + 1 -- weights into a SECOND register set, patch slice into staging registers -- are spread over the
+// steps of chunk c's K loop, ONE per step, so each finds the address path free and costs the wave its issue slot only. The
+// patch slices alternate between two LDS buffers (padded pixel pitch, no swizzle: immediate-offset reads); the TH accumulators
+// live across the chunks.
+// The sum order is chunk-major: (chunk, ky, kx, cb-in-chunk) instead of the (ky, kx, cb) of every other conv kernel, so this
+// kernel is NOT bit-identical to them (fp32 accumulation: the difference is the last bit of an fp16 output now and then; the
+// tests hold it to that against the register-queue pair, and to the fp32 oracle like everything else).
+template <typename T, int TH, int CIN, int NCHUNK, int NW, bool STAMPS = false>
+__device__ __forceinline__ void conv3x3_wsc_body(const ConvParams& p, int bid, int nwg) {
+  typedef Elem<T> E;
+  typedef typename E::frag frag;
+  constexpr bool SP = E::kPlanes == 2;
+  constexpr int WB = 1024 * E::kPlanes;                     // bytes of a weight block (split: the (hi | lo) pair)
   if constexpr (STAMPS) { stamp_b(p, 0, bid, nwg); stamp_wg(p, 0); }
   typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
   typedef float floatx2 __attribute__((ext_vector_type(2)));
@@ -1070,8 +1064,8 @@ __device__ __forceinline__ void conv3x3_ws_s16_body(const ConvParams& p, int bid
   constexpr int STEPS = R0H * 3 * CBC, PF = 4;
   constexpr int PITCH = CC * 2 + 32;
   constexpr int PLANE = R0H * R0W * PITCH;                   // one plane of a patch chunk; the lo image lies right behind the hi image
-  constexpr int BUF = 2 * PLANE;                             // one LDS buffer (hi + lo); chunks alternate between two
-  static_assert(CIN % (32 * NCHUNK) == 0 && KBC * 16 <= 320 && PLANE % 16 == 0, "chunking: two weight sets must fit the registers");
+  constexpr int BUF = E::kPlanes * PLANE;                    // one LDS buffer; chunks alternate between two
+  static_assert(CIN % (32 * NCHUNK) == 0 && KBC * 4 * E::kPlanes <= 160 && PLANE % 16 == 0, "chunking: two weight sets must fit the registers");
   static_assert((R0H * R0W + 2) * PITCH < 65536, "ds_read immediate offsets");
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1088,7 +1082,7 @@ __device__ __forceinline__ void conv3x3_ws_s16_body(const ConvParams& p, int bid
 
   int nsub = (nb0 >> 4) + wid;
   nsub = nsub * 16 < n_pad ? nsub : (n_pad >> 4) - 1;   // tail subtile: clamp (never stored)
-  const unsigned char* wptr = static_cast<const unsigned char*>(sg.w_lane) + (size_t)nsub * (9 * CB) * 2048 + lane * 16;   // lane-order twin
+  const unsigned char* wptr = static_cast<const unsigned char*>(sg.w_lane) + (size_t)nsub * (9 * CB) * WB + lane * 16;   // lane-order twin
   const int n = nb0 + wid * 16 + lq * 4;                // slice-relative first channel of this lane's 4 outputs
   const bool n_ok = n < sg.n_count;
   const floatx4 bias = *reinterpret_cast<const floatx4*>(sg.bias + (n_ok ? n : 0));
@@ -1098,14 +1092,14 @@ __device__ __forceinline__ void conv3x3_ws_s16_body(const ConvParams& p, int bid
   const int src_bytes = p.H * p.W * p.src_ld * 2;
   const __amdgpu_buffer_rsrc_t srs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t srs_l =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(static_cast<const unsigned char*>(p.src) + p.src_lo), 0, src_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(static_cast<const unsigned char*>(p.src) + (SP ? p.src_lo : 0)), 0, src_bytes, 0x00020000);
   constexpr int nchx = CC * 2 / 16, nslots = R0H * R0W * nchx, PITER = (nslots + NT - 1) / NT;
 
   // destination planes: lanes outside the image / past the slice get an out-of-range offset and their stores are dropped
   const unsigned rowb = (unsigned)(p.Wo * sg.dst_ld * 2);
   const __amdgpu_buffer_rsrc_t drs_h = __builtin_amdgcn_make_buffer_rsrc(sg.dst, 0, (int)((unsigned)p.Ho * rowb), 0x00020000);
   const __amdgpu_buffer_rsrc_t drs_l =
-      __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned char*>(sg.dst) + sg.dst_lo, 0, (int)((unsigned)p.Ho * rowb), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned char*>(sg.dst) + (SP ? sg.dst_lo : 0), 0, (int)((unsigned)p.Ho * rowb), 0x00020000);
   const bool lane_ok = n_ok && tx0 + l15 < p.Wo;
   const unsigned voff0 = lane_ok ? (unsigned)(((ty0 * p.Wo + tx0 + l15) * sg.dst_ld + n) * 2) : 0x40000000u;
 
@@ -1121,32 +1115,33 @@ __device__ __forceinline__ void conv3x3_ws_s16_body(const ConvParams& p, int bid
       lv[e] = (half_t)(a - (float)hv[e]);
     }
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs_h, voff0 + (unsigned)r * rowb, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, lv), drs_l, voff0 + (unsigned)r * rowb, 0, 0);
+    if constexpr (SP) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, lv), drs_l, voff0 + (unsigned)r * rowb, 0, 0);
   };
 
   frag wA[KBC], wB[KBC];
-  uintx4 pvh[PITER], pvl[PITER];
+  uintx4 pvh[PITER], pvl[SP ? PITER : 1];
+  auto ldw = [&](const unsigned char* at) {
+    if constexpr (SP) return EltS::ldw(at);
+    else return *reinterpret_cast<const frag*>(at);
+  };
   // block g of chunk ch: tap g / CBC, channel block ch * CBC + g % CBC of the tap's CB blocks
   auto w_request = [&](frag (&w)[KBC], auto chc, auto g0c, auto g1c) {
     static_for<decltype(g0c)::value, decltype(g1c)::value>([&](auto gc) {
       constexpr int g = decltype(gc)::value, ch = decltype(chc)::value;
-      w[g] = EltS::ldw(wptr + (size_t)((g / CBC) * CB + ch * CBC + g % CBC) * 2048);
-      __builtin_amdgcn_sched_barrier(0);   // (issue order = order of first use: the counted waits are exact)
+      w[g] = ldw(wptr + (size_t)((g / CBC) * CB + ch * CBC + g % CBC) * WB);
+      __builtin_amdgcn_sched_barrier(0);   // (issue order = program order: the counted waits are exact)
     });
   };
-  auto patch_request = [&](auto chc) {
-    constexpr int ch = decltype(chc)::value;
-#pragma unroll
-    for (int it = 0; it < PITER; ++it) {
-      const int sl = it * NT + (int)threadIdx.x;
-      const int r = sl / nchx, cs = sl - r * nchx;
-      const int ry = r / R0W, rx = r - ry * R0W;
-      const int iy = ty0 - 1 + ry, ix = tx0 - 1 + rx;
-      const bool in = sl < nslots && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const unsigned off = in ? (unsigned)(((iy * p.W + ix) * p.src_ld + sg.src_coff + ch * CC) * 2 + (cs << 4)) : 0x40000000u;
-      pvh[it] = __builtin_amdgcn_raw_buffer_load_b128(srs_h, off, 0, 0);
-      pvl[it] = __builtin_amdgcn_raw_buffer_load_b128(srs_l, off, 0, 0);
-    }
+  auto patch_request_one = [&](auto chc, auto itc) {
+    constexpr int ch = decltype(chc)::value, it = decltype(itc)::value;
+    const int sl = it * NT + (int)threadIdx.x;
+    const int r = sl / nchx, cs = sl - r * nchx;
+    const int ry = r / R0W, rx = r - ry * R0W;
+    const int iy = ty0 - 1 + ry, ix = tx0 - 1 + rx;
+    const bool in = sl < nslots && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const unsigned off = in ? (unsigned)(((iy * p.W + ix) * p.src_ld + sg.src_coff + ch * CC) * 2 + (cs << 4)) : 0x40000000u;
+    pvh[it] = __builtin_amdgcn_raw_buffer_load_b128(srs_h, off, 0, 0);
+    if constexpr (SP) pvl[it] = __builtin_amdgcn_raw_buffer_load_b128(srs_l, off, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   };
   auto patch_commit = [&](int buf) {
@@ -1156,54 +1151,69 @@ __device__ __forceinline__ void conv3x3_ws_s16_body(const ConvParams& p, int bid
       const int r = sl / nchx, cs = sl - r * nchx;
       if (sl < nslots) {
         *reinterpret_cast<uintx4*>(conv_smem + buf * BUF + r * PITCH + cs * 16) = pvh[it];
-        *reinterpret_cast<uintx4*>(conv_smem + buf * BUF + PLANE + r * PITCH + cs * 16) = pvl[it];
+        if constexpr (SP) *reinterpret_cast<uintx4*>(conv_smem + buf * BUF + PLANE + r * PITCH + cs * 16) = pvl[it];
       }
     }
   };
   typedef std::integral_constant<int, 0> I0;
   // chunk 0 -- request order = order of first use: tap row ky = 0, the patch slice, tap rows ky = 1, 2
   w_request(wA, I0{}, I0{}, std::integral_constant<int, 3 * CBC>{});
-  patch_request(I0{});
+  static_for<0, PITER>([&](auto itc) { patch_request_one(I0{}, itc); });
   w_request(wA, I0{}, std::integral_constant<int, 3 * CBC>{}, std::integral_constant<int, KBC>{});
   if constexpr (STAMPS) stamp_b(p, 1, bid, nwg);
   patch_commit(0);
   lds_barrier();
   if constexpr (STAMPS) stamp_b(p, 2, bid, nwg);
 
+  // the next chunk's requests, one per K-loop step from step 0 on: its patch slice first (committed at the end of this
+  // chunk), then its weight blocks in the order of first use (all issued well before this chunk's last steps)
+  constexpr int NREQ = PITER + KBC;
+  constexpr int RSTRIDE = (STEPS * 3 / 4) / NREQ > 0 ? (STEPS * 3 / 4) / NREQ : 1;   // a request every RSTRIDE steps, all issued by ~3/4 of the loop
+  static_assert(NREQ * RSTRIDE <= STEPS, "the next chunk's requests fit this chunk's steps");
   static_for<0, NCHUNK>([&](auto chc) {
     constexpr int ch = decltype(chc)::value;
     auto& w = (ch & 1) ? wB : wA;
-    if constexpr (ch + 1 < NCHUNK) {   // the next chunk's operands are on their way during this chunk's K loop
-      w_request((ch & 1) ? wA : wB, std::integral_constant<int, ch + 1>{}, I0{}, std::integral_constant<int, KBC>{});
-      patch_request(std::integral_constant<int, ch + 1>{});
-    }
+    auto& wn = (ch & 1) ? wA : wB;
     const unsigned lo0 = (unsigned)((ch & 1) * BUF + l15 * PITCH + lq * 16);
     unsigned lo1 = lo0 + PLANE;                     // second base register: the lo plane (ds offsets are 16 bits)
     asm volatile("" : "+v"(lo1));
     auto bfrag = [&](auto sc) {
       constexpr int s = decltype(sc)::value, rho = s / (3 * CBC), kx = (s / CBC) % 3, cbl = s % CBC;
       constexpr int imm = (rho * R0W + kx) * PITCH + cbl * 64;
-      return frag{*reinterpret_cast<const half8*>(conv_smem + lo0 + imm), *reinterpret_cast<const half8*>(conv_smem + lo1 + imm)};
+      if constexpr (SP) return frag{*reinterpret_cast<const half8*>(conv_smem + lo0 + imm), *reinterpret_cast<const half8*>(conv_smem + lo1 + imm)};
+      else return *reinterpret_cast<const frag*>(conv_smem + lo0 + imm);
     };
     frag b[PF + 1];
     static_for<0, PF>([&](auto sc) { b[decltype(sc)::value] = bfrag(sc); });
     static_for<0, STEPS>([&](auto sc) {
       constexpr int s = decltype(sc)::value, rho = s / (3 * CBC), kx = (s / CBC) % 3, cbl = s % CBC;
+      if constexpr (ch + 1 < NCHUNK && s % RSTRIDE == 0 && s / RSTRIDE < NREQ) {
+        constexpr int q = s / RSTRIDE;
+        if constexpr (q < PITER) patch_request_one(std::integral_constant<int, ch + 1>{}, std::integral_constant<int, (q < PITER ? q : 0)>{});
+        else w_request(wn, std::integral_constant<int, ch + 1>{}, std::integral_constant<int, q - PITER>{}, std::integral_constant<int, q - PITER + 1>{});
+      }
       if constexpr (s + PF < STEPS) b[(s + PF) % (PF + 1)] = bfrag(std::integral_constant<int, s + PF>{});
-      if constexpr (ch == 0 && kx == 0 && cbl == 0 && rho < TH) acc[rho] = floatx4{0.f, 0.f, 0.f, 0.f};
-      // term-major: the three products of a split MFMA go to the same accumulator, so the rows' MFMAs are interleaved
-      // (lo*hi of rows rho, rho-1, rho-2, then hi*lo, then hi*hi): a dependent MFMA is three issues behind its predecessor
-      static_for<0, 3>([&](auto tc) {
-        constexpr int term = decltype(tc)::value;
+      if constexpr (ch == 0 && kx == 0 && cbl == 0 && rho < TH) acc[rho] = floatx4{0.f, 0.f, 0.f, 0.f};   // (every wave starts from zero)
+      if constexpr (SP) {
+        // term-major: the three products of a split MFMA go to the same accumulator, so the rows' MFMAs are interleaved
+        // (lo*hi of rows rho, rho-1, rho-2, then hi*lo, then hi*hi): a dependent MFMA is three issues behind its predecessor
+        static_for<0, 3>([&](auto tc) {
+          constexpr int term = decltype(tc)::value;
+          static_for<0, 3>([&](auto kyc) {
+            constexpr int ky = decltype(kyc)::value, r = rho - ky;
+            if constexpr (r >= 0 && r < TH) {
+              const auto& wv = w[(ky * 3 + kx) * CBC + cbl];
+              const auto& bv = b[s % (PF + 1)];
+              acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 0 ? wv.l : wv.h, term == 1 ? bv.l : bv.h, acc[r], 0, 0, 0);
+            }
+          });
+        });
+      } else {
         static_for<0, 3>([&](auto kyc) {
           constexpr int ky = decltype(kyc)::value, r = rho - ky;
-          if constexpr (r >= 0 && r < TH) {
-            const frag& wv = w[(ky * 3 + kx) * CBC + cbl];
-            const frag& bv = b[s % (PF + 1)];
-            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 0 ? wv.l : wv.h, term == 1 ? bv.l : bv.h, acc[r], 0, 0, 0);
-          }
+          if constexpr (r >= 0 && r < TH) acc[r] = E::mma(w[(ky * 3 + kx) * CBC + cbl], b[s % (PF + 1)], acc[r]);
         });
-      });
+      }
       // last chunk: row rho-3 was completed by the previous patch row: convert and store it in the shadow of this row's MFMAs
       if constexpr (ch == NCHUNK - 1 && kx == 1 && cbl == 0 && rho >= 3) store_row(std::integral_constant<int, rho - 3>{});
       __builtin_amdgcn_sched_barrier(0);
@@ -1218,18 +1228,30 @@ __device__ __forceinline__ void conv3x3_ws_s16_body(const ConvParams& p, int bid
   if constexpr (STAMPS) { stamp_b(p, 4, bid, nwg); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_wg(p, 1); }
 }
 
-template <int TH, int CIN, int NCHUNK, int NW>
-__global__ __launch_bounds__(NW * 64) void conv3x3_ws_s16(const ConvParams p) {
-  conv3x3_ws_s16_body<TH, CIN, NCHUNK, NW>(p, (int)blockIdx.x, (int)gridDim.x);
+template <typename T, int TH, int CIN, int NCHUNK, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_wsc(const ConvParams p) {
+  conv3x3_wsc_body<T, TH, CIN, NCHUNK, NW>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+// fp16 engines: the P3 | P4 head pair (P4's workgroups take the first block ids). P3: 16 x 16 pixel tiles, two chunks of 64
+// channels; P4: 8 x 16 tiles, four chunks. One wave per SIMD. (Two waves per SIMD -- 512-thread workgroups whose wave halves
+// split the chunks by parity and meet in LDS -- were built and measured: the K loop reaches the MFMA pipe's rate, the launch
+// does not get shorter: 14.3 against 13.4 us fp16, 30.7 against 28.5 us split; profiles/r03/head_pair_experiments.txt.)
+__global__ __launch_bounds__(256) void conv_dual_head3x3_ws(const ConvParams pa, const ConvParams pb, int nb) {
+  if ((int)blockIdx.x < nb) conv3x3_wsc_body<half_t, 8, 256, 4, 4>(pb, (int)blockIdx.x, nb);
+  else conv3x3_wsc_body<half_t, 16, 128, 2, 4>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
+}
+__global__ __launch_bounds__(256) void conv_dual_head3x3_ws_stamped(const ConvParams pa, const ConvParams pb, int nb) {
+  if ((int)blockIdx.x < nb) conv3x3_wsc_body<half_t, 8, 256, 4, 4, true>(pb, (int)blockIdx.x, nb);
+  else conv3x3_wsc_body<half_t, 16, 128, 2, 4, true>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
 }
 __global__ __launch_bounds__(256) void conv_dual_head3x3_ws_s16_stamped(const ConvParams pa, const ConvParams pb, int nb) {
-  if ((int)blockIdx.x < nb) conv3x3_ws_s16_body<8, 256, 4, 4, true>(pb, (int)blockIdx.x, nb);
-  else conv3x3_ws_s16_body<8, 128, 2, 4, true>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
+  if ((int)blockIdx.x < nb) conv3x3_wsc_body<s16_t, 8, 256, 4, 4, true>(pb, (int)blockIdx.x, nb);
+  else conv3x3_wsc_body<s16_t, 8, 128, 2, 4, true>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
 }
 // STRICT engines: the P3 | P4 head pair on it (P4's workgroups take the first block ids)
 __global__ __launch_bounds__(256) void conv_dual_head3x3_ws_s16(const ConvParams pa, const ConvParams pb, int nb) {
-  if ((int)blockIdx.x < nb) conv3x3_ws_s16_body<8, 256, 4, 4>(pb, (int)blockIdx.x, nb);
-  else conv3x3_ws_s16_body<8, 128, 2, 4>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
+  if ((int)blockIdx.x < nb) conv3x3_wsc_body<s16_t, 8, 256, 4, 4>(pb, (int)blockIdx.x, nb);
+  else conv3x3_wsc_body<s16_t, 8, 128, 2, 4>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
 }
 
 #ifndef UNINA_CONV_PROBE   // (ISA probe builds stop here: tools/isa_probe.sh compiles only the kernels above)
@@ -1273,7 +1295,7 @@ struct CfgInfo {
   int nthreads = 256;
   int stride = 1;      // register-queue kernel: conv stride it is instantiated for
   bool ws = false;     // weights-stationary 3x3 kernel: fp16 NHWC destination, ReLU, no residual / upsample / planar output
-  int chunks = 1;      // split-fp16 weights-stationary kernel: channel chunks the patch is staged in
+  int chunks = 0;      // chunked weights-stationary kernel (conv3x3_wsc_body): channel chunks; 0 = another kernel
 };
 
 constexpr size_t stage_bytes(int bm, int bn) { return (size_t)bm * (bn * 4 + 16); }  // epilogue staging tile (fp32 worst case)
@@ -1309,15 +1331,15 @@ constexpr size_t smem_of() {
 #define REGQS2(TH, TW, BN, CIN, NW, D)                                                               \
   {(TH) * (TW), BN, 32, 3, "conv3x3_regq<s16," #TH "x" #TW "," #BN "," #CIN "," #NW "w,s2>",             \
    conv3x3_regq<TH, TW, BN, CIN, NW, D, 2, 1, s16_t>, 0, TH, TW, CIN, (NW) * 64, 2}
-#define WS(TH, CIN, NW)                                                                              \
-  {(TH) * 16, (NW) * 16, 32, 3, "conv3x3_ws<f16," #TH "x16," #CIN "," #NW "w>",                          \
-   conv3x3_ws<TH, CIN, NW>, 0, TH, 16, CIN, (NW) * 64, 1, true}
+#define WS(TH, CIN, NCH, NW)                                                                         \
+  {(TH) * 16, (NW) * 16, 32, 3, "conv3x3_ws<f16," #TH "x16," #CIN "/" #NCH "," #NW "w>",                 \
+   conv3x3_wsc<half_t, TH, CIN, NCH, NW>, 0, TH, 16, CIN, (NW) * 64, 1, true, NCH}
 #define WSI(TH, CIN, NW)                                                                             \
   {(TH) * 16, (NW) * 16, 32, 3, "conv3x3_ws<i8," #TH "x16," #CIN "," #NW "w>",                           \
    conv3x3_ws<TH, CIN, NW, signed char>, 0, TH, 16, CIN, (NW) * 64, 1, true}
 #define WSS(TH, CIN, NCH, NW)                                                                        \
   {(TH) * 16, (NW) * 16, 32, 3, "conv3x3_ws<s16," #TH "x16," #CIN "/" #NCH "," #NW "w>",                 \
-   conv3x3_ws_s16<TH, CIN, NCH, NW>, 0, TH, 16, CIN, (NW) * 64, 1, true, NCH}
+   conv3x3_wsc<s16_t, TH, CIN, NCH, NW>, 0, TH, 16, CIN, (NW) * 64, 1, true, NCH}
 #define NOCFG {0, 0, 0, 0, "n/a", nullptr, 0, 0, 0, -1, 0, 0}
 
 // [dtype][config]; BK is in fp16-equivalent k (KSUB = BK/32 fragment blocks): a K-step covers BK channels in fp16
@@ -1356,8 +1378,8 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         REGQ2(4, 8, 64, 128, 8, 16),                  // kCfgRegqS2_4x8n64c128
         REGQ2(8, 16, 64, 32, 8, 8),                   // kCfgRegqS2_8x16n64c32    (stage1_conv)
         REGQ2(8, 8, 32, 128, 8, 16),                  // kCfgRegqS2_8x8n32c128
-        WS(16, 128, 4),                               // kCfgWs16x16n64c128    (P3 head layers, weights-stationary)
-        WS(8, 256, 4),                                // kCfgWs8x16n64c256     (P4 head layers, weights-stationary)
+        WS(16, 128, 2, 4),                            // kCfgWs16x16n64c128    (P3 head layers, weights-stationary, two chunks of 64 channels)
+        WS(8, 256, 4, 4),                             // kCfgWs8x16n64c256     (P4 head layers, weights-stationary, four chunks)
         NOCFG, NOCFG, NOCFG,                          // (split-fp16 weights-stationary kernels)
     },
     {
@@ -1475,7 +1497,8 @@ inline size_t smem_for(const ConvParams& p, const CfgInfo& c) {
   if (c.cin) {  // register-queue kernel: patch (+ < 1 KiB overrun of its last DMA instruction) or the epilogue staging tile
     const size_t ph = c.stride * (c.th - 1) + 3, pw = c.stride * (c.tw - 1) + 3;
     const size_t patch = ((ph * pw * c.cin * esize(p) + 1023) & ~(size_t)1023) + 1024;
-    if (c.ws && p.dtype == kS16) return (c.chunks > 1 ? 2 : 1) * 2 * ph * pw * ((c.cin / c.chunks) * 2 + 32);   // hi + lo image of a channel chunk, two buffers (conv3x3_ws_s16_body)
+    if (c.ws && c.chunks)   // image(s) of a channel chunk, two buffers (conv3x3_wsc_body)
+      return (c.chunks > 1 ? 2 : 1) * (p.dtype == kS16 ? 2 : 1) * ph * pw * ((c.cin / c.chunks) * 2 + 32);
     if (c.ws) return ph * pw * (c.cin * esize(p) + 32);   // padded pixel pitch, no swizzle (conv3x3_ws_body)
     if (p.dtype == kS16) return 2 * patch;                // hi and lo images; accumulators are stored straight from registers
     return max_sz(patch, stage_bytes((c.bm + 15) & ~15, c.bn));
@@ -1632,7 +1655,7 @@ const DualKind kDual[kDualKinds] = {
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3<regq 8x16,64,128 | regq 8x8,64,256>", conv_dual_head3x3},
     {kCfg128x16k64, kCfg128x16k64, 256, "conv_dual_head1x1<glds 128,16,64 x2>", conv_dual_head1x1},
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3_i8<regq i8,8x16,64,128 | regq i8,8x8,64,256>", conv_dual_head3x3_i8},
-    {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws<ws 16x16,64,128 | ws 8x16,64,256>", conv_dual_head3x3_ws},
+    {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws<ws 16x16,64,128/2 | ws 8x16,64,256/4>", conv_dual_head3x3_ws},
     {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws_i8<ws i8,16x16,64,128 | ws i8,8x16,64,256>", conv_dual_head3x3_ws_i8},
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3_s16<regq s16,8x16,64,128 | regq s16,8x8,64,256>", conv_dual_head3x3_s16},
     {kCfgWsS8x16n64c128, kCfgWsS8x16n64c256, 256, "conv_dual_head3x3_ws_s16<ws s16,8x16,64,128/2 | ws s16,8x16,64,256/4>", conv_dual_head3x3_ws_s16},
