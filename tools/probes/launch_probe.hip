@@ -57,5 +57,29 @@ int main() {
     }
     printf("hipGraphLaunch (15-kernel chain): first kernel's word p50 %.1f us, last kernel's word p50 %.1f us\n", stat(t1), stat(t2));
   }
+  // (d) the per-boundary floor of a dependent chain inside one graph: N launches of a kernel that does (almost) nothing, grids of
+  //     1 / 220 / 800 workgroups x 256 threads; span from the first kernel's word to the last kernel's word, divided by N
+  for (int wgs : {1, 220, 800}) {
+    for (int work : {0, 2000}) {
+      const int N = 32;
+      hipGraph_t g3; hipGraphExec_t ge3;
+      hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+      hipLaunchKernelGGL(mark, dim3(1), dim3(64), 0, s, flags, 1u);
+      for (int k = 0; k < N; ++k) hipLaunchKernelGGL(spin_work, dim3(wgs), dim3(256), 0, s, work, sink);
+      hipLaunchKernelGGL(mark, dim3(1), dim3(64), 0, s, flags + 16, 2u);
+      hipStreamEndCapture(s, &g3); hipGraphInstantiate(&ge3, g3, nullptr, nullptr, 0);
+      std::vector<double> t;
+      for (int i = 0; i < 200; ++i) {
+        flags[0] = 0; flags[16] = 0;
+        hipGraphLaunch(ge3, s);
+        while (flags[0] != 1u) {}
+        double b = now();
+        while (flags[16] != 2u) {}
+        t.push_back((now() - b) / (N + 1));
+      }
+      printf("chain of %d launches, %3d workgroups x 256 threads, %4d dependent FMAs per thread: %.2f us per launch\n", N, wgs, work, stat(t));
+      hipGraphExecDestroy(ge3); hipGraphDestroy(g3);
+    }
+  }
   return 0;
 }

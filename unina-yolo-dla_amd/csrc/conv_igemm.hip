@@ -1246,12 +1246,12 @@ __global__ __launch_bounds__(256) void conv_dual_head3x3_ws_stamped(const ConvPa
 }
 __global__ __launch_bounds__(256) void conv_dual_head3x3_ws_s16_stamped(const ConvParams pa, const ConvParams pb, int nb) {
   if ((int)blockIdx.x < nb) conv3x3_wsc_body<s16_t, 8, 256, 4, 4, true>(pb, (int)blockIdx.x, nb);
-  else conv3x3_wsc_body<s16_t, 8, 128, 2, 4, true>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
+  else conv3x3_wsc_body<s16_t, 16, 128, 4, 4, true>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
 }
 // STRICT engines: the P3 | P4 head pair on it (P4's workgroups take the first block ids)
 __global__ __launch_bounds__(256) void conv_dual_head3x3_ws_s16(const ConvParams pa, const ConvParams pb, int nb) {
   if ((int)blockIdx.x < nb) conv3x3_wsc_body<s16_t, 8, 256, 4, 4>(pb, (int)blockIdx.x, nb);
-  else conv3x3_wsc_body<s16_t, 8, 128, 2, 4>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
+  else conv3x3_wsc_body<s16_t, 16, 128, 4, 4>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
 }
 
 #ifndef UNINA_CONV_PROBE   // (ISA probe builds stop here: tools/isa_probe.sh compiles only the kernels above)
@@ -1470,7 +1470,9 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         REGQS2(4, 8, 64, 128, 8, 8),                // kCfgRegqS2_4x8n64c128
         REGQS2(8, 16, 64, 32, 8, 8),                // kCfgRegqS2_8x16n64c32    (stage1_conv)
         NOCFG,                                      // kCfgRegqS2_8x8n32c128
-        NOCFG, NOCFG,                               // (the fp16 / int8 weights-stationary kernels)
+        WSS(16, 128, 4, 4),                         // kCfgWs16x16n64c128    (P3 head layers in the pair: 16-row tiles, four chunks of 32 channels --
+                                                    //  100 + 120 workgroups run in ONE round; with 8-row tiles the pair's 320 needed two)
+        NOCFG,                                      // kCfgWs8x16n64c256     (fp16 / int8 only)
         WSS(8, 64, 1, 4),                           // kCfgWsS8x16n64c64     (P2 head layers)
         WSS(8, 128, 2, 4),                          // kCfgWsS8x16n64c128    (P3 head layers: two chunks of 64 channels)
         WSS(8, 256, 4, 4),                          // kCfgWsS8x16n64c256    (P4 head layers: four chunks. 4-row tiles -- 240 workgroups of the P3 conv's size -- ran 34 us per pair against 30.6)
@@ -1658,7 +1660,7 @@ const DualKind kDual[kDualKinds] = {
     {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws<ws 16x16,64,128/2 | ws 8x16,64,256/4>", conv_dual_head3x3_ws},
     {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws_i8<ws i8,16x16,64,128 | ws i8,8x16,64,256>", conv_dual_head3x3_ws_i8},
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3_s16<regq s16,8x16,64,128 | regq s16,8x8,64,256>", conv_dual_head3x3_s16},
-    {kCfgWsS8x16n64c128, kCfgWsS8x16n64c256, 256, "conv_dual_head3x3_ws_s16<ws s16,8x16,64,128/2 | ws s16,8x16,64,256/4>", conv_dual_head3x3_ws_s16},
+    {kCfgWs16x16n64c128, kCfgWsS8x16n64c256, 256, "conv_dual_head3x3_ws_s16<ws s16,16x16,64,128/4 | ws s16,8x16,64,256/4>", conv_dual_head3x3_ws_s16},
 };
 }  // namespace
 
