@@ -863,209 +863,44 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_regq(const ConvParams p) {
 }
 
 // ============================================================================================ 3x3 weights-stationary kernel
-// 3x3 / stride 1 / pad 1, fp16, ReLU, fp16 NHWC destination. The register-queue kernel above reads one activation
-// fragment from LDS per MFMA and is bound by exactly that (profiles/r02/pmc_mfma.json: LDS busy = the whole K loop), and
-// two of its waves fetch every weight block. Here a wave owns ONE 16-channel subtile and keeps ALL of its K/32 weight
-// blocks in registers (Cin 128: 144, Cin 256: 288 of the 512 a lone wave per SIMD may use), and walks DOWN the patch rows:
-// the fragment of patch row rho (shifted by kx, channel block cb) feeds the three output rows rho, rho-1, rho-2 (taps
-// ky = 0, 1, 2), so LDS is read once per ~3 MFMAs, every weight block is fetched once per workgroup, and only four
-// accumulators are live (a row is converted and stored while the next ones are being accumulated). Each output row still
-// receives its products in the order ky, kx, cb from a zero accumulator, i.e. the K order of every other conv kernel:
-// results are bit-identical.
-template <int TH, int CIN, int NW, bool STAMPS = false, typename T = half_t>
-__device__ __forceinline__ void conv3x3_ws_body(const ConvParams& p, int bid, int nwg) {
-  typedef Elem<T> E;     // half_t, or signed char (INT8 engines: int8 patch, 64-k weight blocks, exact int32 accumulators)
-  typedef typename E::frag frag;
-  constexpr int ESZ = (int)sizeof(T);
-  constexpr int TW = 16, R0W = TW + 2, R0H = TH + 2, NT = NW * 64, CB = CIN / E::kBlockK, KB = 9 * CB, BN = NW * 16;
-  constexpr int STEPS = R0H * 3 * CB, PF = 4;     // (rho, kx, cb) steps; LDS fragments are requested PF steps ahead
-  // LDS patch image: pixel pitch = Cin*2 + 32 bytes, NO xor swizzle. The pad makes the 16 pixels of a fragment read hit 16
-  // different bank groups, and the address of (rho, kx, cb) is lane_base + a compile-time constant: the ds_read takes it as
-  // its immediate offset. The K loop is ISSUE-bound (tools/probes/mix_probe.hip: an MFMA holds the SIMD's vector issue
-  // for 8 of its 16 cycles, a ds_read_b128 for ~16, every VALU op for 4): with the swizzled image's 2-3 address ops per
-  // fragment it ran at 28 cycles per MFMA; three MFMAs + one ds_read + one s_waitcnt fit the 48.
-  constexpr int PITCH = CIN * ESZ + 32, SPLIT = 60 * 1024;   // (+32, not +16: tools/probes/ldsbank_probe.hip -- 28.0 against 34.5 cycles per read)
-  if constexpr (STAMPS) { stamp_b(p, 0, bid, nwg); stamp_wg(p, 0); }
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int l15 = lane & 15, lq = lane >> 4;
-  int bx, by;
-  tile_of_block(p, bid, nwg, &bx, &by);
-  const int sidx = (p.nseg > 1 && by >= p.seg[1].tile0) ? 1 : 0;
-  const ConvSeg& sg = p.seg[sidx];
-  const int n_pad = (sg.n_count + 15) & ~15;
-  const int nb0 = (by - sg.tile0) * BN;
-  const int tiles_x = (p.Wo + TW - 1) / TW;
-  const int tyi = fast_div(bx, p.tx_magic), txi = bx - tyi * tiles_x;
-  const int ty0 = tyi * TH, tx0 = txi * TW;
-
-  int nsub = (nb0 >> 4) + wid;
-  nsub = nsub * 16 < n_pad ? nsub : (n_pad >> 4) - 1;   // tail subtile: clamp (never stored)
-  const unsigned char* wptr = static_cast<const unsigned char*>(sg.w_lane) + (size_t)nsub * KB * 1024 + lane * 16;   // lane-order twin
-  frag w[KB];
-  const int n = nb0 + wid * 16 + lq * 4;                // slice-relative first channel of this lane's 4 outputs
-  const bool n_ok = n < sg.n_count;
-  const floatx4 bias = *reinterpret_cast<const floatx4*>(sg.bias + (n_ok ? n : 0));
-  floatx4 mult = {1.f, 1.f, 1.f, 1.f};
-  if constexpr (ESZ == 1) mult = *reinterpret_cast<const floatx4*>(sg.mult + (n_ok ? n : 0));   // int8: s_in * s_w * bn_scale per channel
-  // tap row ky = 0 first: the patch (requested next) and these are all the first patch row needs
-  static_for<0, 3 * CB>([&](auto g) { w[decltype(g)::value] = *reinterpret_cast<const frag*>(wptr + decltype(g)::value * 1024); });
-  asm volatile("" ::: "memory");
-  // the patch through registers (plain loads, then ds_write): with LDS-DMA in the mix hipcc's wait-count pass sees two kinds
-  // of vector-memory events in flight and turns EVERY s_waitcnt into vmcnt(0) -- the first MFMA would wait for all K/32
-  // weight blocks. With plain loads only, its counted vmcnt lets the patch be committed while the weight rows ky = 1, 2 are
-  // still in flight and each block's first MFMA waits for exactly that block.
-  // (buffer loads: a slot outside the image -- the conv's zero padding -- or past the patch gets an out-of-range offset and the
-  // range check returns zeros: no branch around a load, no select on loaded data, nothing that makes the compiler wait early)
-  constexpr int nchx = CIN * ESZ / 16, nslots = R0H * R0W * nchx, PITER = (nslots + NT - 1) / NT;
-  typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
-  uintx4 pv[PITER];
-  __builtin_amdgcn_sched_barrier(0);   // request order = the order things are needed in: ky = 0 blocks, patch, ky = 1, 2 blocks
-  {
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.H * p.W * p.src_ld * ESZ, 0x00020000);
-#pragma unroll
-    for (int it = 0; it < PITER; ++it) {
-      const int sl = it * NT + (int)threadIdx.x;
-      const int r = sl / nchx, cs = sl - r * nchx;
-      const int ry = r / R0W, rx = r - ry * R0W;
-      const int iy = ty0 - 1 + ry, ix = tx0 - 1 + rx;
-      const bool in = sl < nslots && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const unsigned off = (unsigned)(((iy * p.W + ix) * p.src_ld + sg.src_coff) * ESZ + (cs << 4));
-      pv[it] = __builtin_amdgcn_raw_buffer_load_b128(srs, in ? off : 0x40000000u, 0, 0);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  static_for<3 * CB, KB>([&](auto g) {   // (pinned one by one: issue order = order of first use, so the counted waits are exact)
-    w[decltype(g)::value] = *reinterpret_cast<const frag*>(wptr + decltype(g)::value * 1024);
-    __builtin_amdgcn_sched_barrier(0);
-  });
-  if constexpr (STAMPS) stamp_b(p, 1, bid, nwg);
-#pragma unroll
-  for (int it = 0; it < PITER; ++it) {
-    const int sl = it * NT + (int)threadIdx.x;
-    const int r = sl / nchx, cs = sl - r * nchx;
-    if (sl < nslots) *reinterpret_cast<uintx4*>(conv_smem + r * PITCH + cs * 16) = pv[it];
-  }
-  lds_barrier();
-  if constexpr (STAMPS) stamp_b(p, 2, bid, nwg);
-
-  // destination through a buffer descriptor: lanes outside the image / past the slice get an out-of-range offset and
-  // the range check drops their store -- no exec masking, the whole K loop stays one basic block
-  const bool out16 = ESZ == 2 || sg.out_dtype == kF16;   // (int8 convs may feed an fp16 buffer: the layer in front of the heads' fp16 output convs)
-  const int DSZ = out16 ? 2 : 1;
-  const unsigned rowb = (unsigned)(p.Wo * sg.dst_ld * DSZ);
-  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(sg.dst, 0, (int)((unsigned)p.Ho * rowb), 0x00020000);
-  const bool lane_ok = n_ok && tx0 + l15 < p.Wo;
-  const unsigned voff0 = lane_ok ? (unsigned)(((ty0 * p.Wo + tx0 + l15) * sg.dst_ld + n) * DSZ) : 0x40000000u;
-
-  const unsigned lo0 = (unsigned)(l15 * PITCH + lq * 16);
-  unsigned lo1 = lo0 + SPLIT;                     // second base: ds offsets are 16 bits
-  asm volatile("" : "+v"(lo1));                   // (opaque, or the compiler folds it back into lo0 + a too-large constant)
-  auto bfrag = [&](auto sc) {
-    constexpr int s = decltype(sc)::value, rho = s / (3 * CB), kx = (s / CB) % 3, cb = s % CB;
-    constexpr int imm = (rho * R0W + kx) * PITCH + cb * 64;
-    if constexpr (imm < 65536 - 16) return *reinterpret_cast<const frag*>(conv_smem + lo0 + imm);
-    else return *reinterpret_cast<const frag*>(conv_smem + lo1 + (imm - SPLIT));
-  };
-  frag b[PF + 1];
-  static_for<0, PF>([&](auto sc) { b[decltype(sc)::value] = bfrag(sc); });
-  typename E::acc_t acc[4];
-  const float out_inv = sg.out_inv_scale;
-  auto store_row = [&](auto rc) {
-    constexpr int r = decltype(rc)::value;
-    if constexpr (ESZ == 2) {
-      floatx4 v = acc[r & 3] + bias;
-      half4 hv;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) hv[e] = (half_t)(v[e] > 0.f ? v[e] : 0.f);
-      typedef float floatx2 __attribute__((ext_vector_type(2)));
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs, voff0 + (unsigned)r * rowb, 0, 0);
-    } else {   // the per-op kernels' int8 epilogue operation for operation (conv_epilogue): fma, ReLU, then fp16 or rint(y / s_out), clamp
-      const floatx4 c = E::to_float(acc[r & 3]);
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = __builtin_fmaf(c[e], mult[e], bias[e]);
-        v[e] = v[e] > 0.f ? v[e] : 0.f;
-      }
-      if (out16) {   // (wave-uniform)
-        half4 hv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hv[e] = (half_t)v[e];
-        typedef float floatx2 __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs, voff0 + (unsigned)r * rowb, 0, 0);
-      } else {
-        unsigned q = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = __builtin_rintf(v[e] * out_inv);
-          t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
-          q |= ((unsigned)(int)t & 0xFFu) << (8 * e);
-        }
-        __builtin_amdgcn_raw_buffer_store_b32(q, drs, voff0 + (unsigned)r * rowb, 0, 0);
-      }
-    }
-  };
-  static_for<0, STEPS>([&](auto sc) {
-    constexpr int s = decltype(sc)::value, rho = s / (3 * CB), kx = (s / CB) % 3, cb = s % CB;
-    if constexpr (s + PF < STEPS) b[(s + PF) % (PF + 1)] = bfrag(std::integral_constant<int, s + PF>{});
-    if constexpr (kx == 0 && cb == 0 && rho < TH) acc[rho & 3] = typename E::acc_t{0, 0, 0, 0};
-    static_for<0, 3>([&](auto kyc) {
-      constexpr int ky = decltype(kyc)::value, r = rho - ky;
-      if constexpr (r >= 0 && r < TH) acc[r & 3] = E::mma(w[(ky * 3 + kx) * CB + cb], b[s % (PF + 1)], acc[r & 3]);
-    });
-    // row rho-3 was completed by the previous patch row: convert and store it in the shadow of this row's MFMAs
-    if constexpr (kx == 1 && cb == 0 && rho >= 3) store_row(std::integral_constant<int, rho - 3>{});
-    __builtin_amdgcn_sched_barrier(0);
-  });
-  if constexpr (STAMPS) stamp_b(p, 3, bid, nwg);
-  store_row(std::integral_constant<int, TH - 1>{});
-  if constexpr (STAMPS) { stamp_b(p, 4, bid, nwg); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_wg(p, 1); }
-}
-
-template <int TH, int CIN, int NW, typename T = half_t>
-__global__ __launch_bounds__(NW * 64) void conv3x3_ws(const ConvParams p) {
-  conv3x3_ws_body<TH, CIN, NW, false, T>(p, (int)blockIdx.x, (int)gridDim.x);
-}
-
-// INT8 engines: the same pair on int8 tensors (18 / 36 weight blocks of 64 k per wave: 72 / 144 registers)
-__global__ __launch_bounds__(256) void conv_dual_head3x3_ws_i8(const ConvParams pa, const ConvParams pb, int nb) {
-  if ((int)blockIdx.x < nb) conv3x3_ws_body<8, 256, 4, false, signed char>(pb, (int)blockIdx.x, nb);
-  else conv3x3_ws_body<16, 128, 4, false, signed char>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
-}
-
-
-// ============================================================================================ 3x3 weights-stationary, chunked
-// The row-walking / weights-stationary scheme of conv3x3_ws_body with the input channels run in NCHUNK chunks of CC channels,
-// for fp16 (the headline engine's P3 | P4 head pairs) and split fp16 (STRICT engines, kS16: (hi, lo) pairs, 3 MFMAs per product).
-// A wave owns ONE 16-channel subtile and a TH x 16 pixel tile; the fragment of patch row rho (kx, channel block) feeds the three
-// output rows rho, rho-1, rho-2. What the chunks buy: a wave's vector-memory requests cost it ~66 cycles of ISSUE each
-// (tools/probes/ingest_probe: one 1-KiB load per 66 cycles and wave, whatever is in flight), and an in-order wave issues no MFMA
-// behind a blocked request -- conv3x3_ws_body spends 7 700-8 700 cycles requesting its 72 + 24 KiB before the first MFMA of the
-// P4 conv. Here only chunk 0 (its weights and its slice of the patch: 24 requests at Cin 256) is requested up front; the
-// requests of chunk c + 1 -- weights into a SECOND register set, patch slice into staging registers -- are spread over the
-// steps of chunk c's K loop, ONE per step, so each finds the address path free and costs the wave its issue slot only. The
-// patch slices alternate between two LDS buffers (padded pixel pitch, no swizzle: immediate-offset reads); the TH accumulators
-// live across the chunks.
+// 3x3 / stride 1 / pad 1, ReLU, NHWC destination; fp16, int8 (INT8 engines: int8 patch, 64-k weight blocks, exact int32
+// accumulators, the per-op kernels' int8 epilogue) and split fp16 (STRICT engines, kS16: (hi, lo) pairs, 3 MFMAs per product).
+// The register-queue kernel above reads one activation fragment from LDS per MFMA and is bound by exactly that
+// (profiles/r02/pmc_mfma.json: LDS busy = the whole K loop), and two of its waves fetch every weight block. Here a wave owns
+// ONE 16-channel subtile and a TH x 16 pixel tile, keeps its weight blocks in registers and walks DOWN the patch rows: the
+// fragment of patch row rho (shifted by kx, channel block cb) feeds the three output rows rho, rho-1, rho-2 (taps ky = 0, 1, 2),
+// so LDS is read once per ~3 MFMAs (padded pixel pitch, no xor swizzle: the address of (rho, kx, cb) is lane base + an
+// immediate -- the K loop is issue-bound, tools/probes/mix_probe.hip) and every weight block is fetched once per workgroup.
+// The input channels run in NCHUNK chunks of CC channels. What the chunks buy: a wave's vector-memory requests cost it ~66
+// cycles of ISSUE each when they come back to back (tools/probes/ingest_probe: one 1-KiB load per 66 cycles and wave, whatever
+// is in flight; ~20-40 with MFMAs in between, tools/probes/vmem_mfma_probe), and an in-order wave issues no MFMA behind a blocked
+// request -- with ALL of a subtile's weights stationary (round 2's form: 288 VGPRs at Cin 256) the P4 conv spent 7 700-8 700
+// cycles requesting its 72 + 24 KiB before its first MFMA. Here only chunk 0 (its weights and its slice of the patch: 24
+// requests at Cin 256) is requested up front; the requests of chunk c + 1 -- weights into a SECOND register set, patch slice
+// into staging registers -- are spread over the steps of chunk c's K loop. The patch slices alternate between two LDS buffers;
+// the TH accumulators live across the chunks.
 // The sum order is chunk-major: (chunk, ky, kx, cb-in-chunk) instead of the (ky, kx, cb) of every other conv kernel, so this
-// kernel is NOT bit-identical to them (fp32 accumulation: the difference is the last bit of an fp16 output now and then; the
-// tests hold it to that against the register-queue pair, and to the fp32 oracle like everything else).
+// kernel is NOT bit-identical to them in fp16 / split fp16 (fp32 accumulation: the difference is the last bit of an fp16 output
+// now and then; the tests hold it to that against the register-queue pair, and to the fp32 oracle like everything else). int8
+// accumulates exactly: there the codes are the same as every other kernel's.
 template <typename T, int TH, int CIN, int NCHUNK, int NW, bool STAMPS = false>
 __device__ __forceinline__ void conv3x3_wsc_body(const ConvParams& p, int bid, int nwg) {
   typedef Elem<T> E;
   typedef typename E::frag frag;
   constexpr bool SP = E::kPlanes == 2;
+  constexpr bool I8 = sizeof(T) == 1;                       // INT8 engines: int8 patch, 64-k weight blocks, exact int32 accumulators
+  constexpr int ESZ = I8 ? 1 : 2, KBLK = E::kBlockK;
   constexpr int WB = 1024 * E::kPlanes;                     // bytes of a weight block (split: the (hi | lo) pair)
   if constexpr (STAMPS) { stamp_b(p, 0, bid, nwg); stamp_wg(p, 0); }
   typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
   typedef float floatx2 __attribute__((ext_vector_type(2)));
   constexpr int TW = 16, R0W = TW + 2, R0H = TH + 2, NT = NW * 64, BN = NW * 16;
-  constexpr int CB = CIN / 32, CC = CIN / NCHUNK, CBC = CC / 32, KBC = 9 * CBC;
+  constexpr int CB = CIN / KBLK, CC = CIN / NCHUNK, CBC = CC / KBLK, KBC = 9 * CBC;
   constexpr int STEPS = R0H * 3 * CBC, PF = 4;
-  constexpr int PITCH = CC * 2 + 32;
+  constexpr int PITCH = CC * ESZ + 32;
   constexpr int PLANE = R0H * R0W * PITCH;                   // one plane of a patch chunk; the lo image lies right behind the hi image
   constexpr int BUF = E::kPlanes * PLANE;                    // one LDS buffer; chunks alternate between two
-  static_assert(CIN % (32 * NCHUNK) == 0 && KBC * 4 * E::kPlanes <= 160 && PLANE % 16 == 0, "chunking: two weight sets must fit the registers");
+  static_assert(CIN % (KBLK * NCHUNK) == 0 && KBC * 4 * E::kPlanes <= 160 && PLANE % 16 == 0, "chunking: two weight sets must fit the registers");
   static_assert((R0H * R0W + 2) * PITCH < 65536, "ds_read immediate offsets");
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1089,33 +924,63 @@ __device__ __forceinline__ void conv3x3_wsc_body(const ConvParams& p, int bid, i
 
   // source planes through buffer descriptors: a slot outside the image (the conv's zero padding) or past the patch gets an
   // out-of-range offset and reads zeros -- no branch around a load
-  const int src_bytes = p.H * p.W * p.src_ld * 2;
+  const int src_bytes = p.H * p.W * p.src_ld * ESZ;
   const __amdgpu_buffer_rsrc_t srs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t srs_l =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(static_cast<const unsigned char*>(p.src) + (SP ? p.src_lo : 0)), 0, src_bytes, 0x00020000);
-  constexpr int nchx = CC * 2 / 16, nslots = R0H * R0W * nchx, PITER = (nslots + NT - 1) / NT;
+  constexpr int nchx = CC * ESZ / 16, nslots = R0H * R0W * nchx, PITER = (nslots + NT - 1) / NT;
 
   // destination planes: lanes outside the image / past the slice get an out-of-range offset and their stores are dropped
-  const unsigned rowb = (unsigned)(p.Wo * sg.dst_ld * 2);
+  const bool out16 = !I8 || sg.out_dtype == kF16;   // (int8 convs may feed an fp16 buffer: the layer in front of the heads' fp16 output convs)
+  const int DSZ = out16 ? 2 : 1;
+  const unsigned rowb = (unsigned)(p.Wo * sg.dst_ld * DSZ);
   const __amdgpu_buffer_rsrc_t drs_h = __builtin_amdgcn_make_buffer_rsrc(sg.dst, 0, (int)((unsigned)p.Ho * rowb), 0x00020000);
   const __amdgpu_buffer_rsrc_t drs_l =
       __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned char*>(sg.dst) + (SP ? sg.dst_lo : 0), 0, (int)((unsigned)p.Ho * rowb), 0x00020000);
   const bool lane_ok = n_ok && tx0 + l15 < p.Wo;
-  const unsigned voff0 = lane_ok ? (unsigned)(((ty0 * p.Wo + tx0 + l15) * sg.dst_ld + n) * 2) : 0x40000000u;
+  const unsigned voff0 = lane_ok ? (unsigned)(((ty0 * p.Wo + tx0 + l15) * sg.dst_ld + n) * DSZ) : 0x40000000u;
+  floatx4 mult = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (I8) mult = *reinterpret_cast<const floatx4*>(sg.mult + (n_ok ? n : 0));   // int8: s_in * s_w * bn_scale per channel
+  const float out_inv = sg.out_inv_scale;
 
-  floatx4 acc[TH];
+  typename E::acc_t acc[TH];
   auto store_row = [&](auto rc) {
     constexpr int r = decltype(rc)::value;
-    const floatx4 v = acc[r] + bias;
-    half4 hv, lv;
+    if constexpr (!I8) {
+      const floatx4 v = acc[r] + bias;
+      half4 hv, lv;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float a = v[e] > 0.f ? v[e] : 0.f;
-      hv[e] = (half_t)a;
-      lv[e] = (half_t)(a - (float)hv[e]);
+      for (int e = 0; e < 4; ++e) {
+        const float a = v[e] > 0.f ? v[e] : 0.f;
+        hv[e] = (half_t)a;
+        lv[e] = (half_t)(a - (float)hv[e]);
+      }
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs_h, voff0 + (unsigned)r * rowb, 0, 0);
+      if constexpr (SP) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, lv), drs_l, voff0 + (unsigned)r * rowb, 0, 0);
+    } else {   // the per-op kernels' int8 epilogue operation for operation (conv_epilogue): fma, ReLU, then fp16 or rint(y / s_out), clamp
+      const floatx4 c = E::to_float(acc[r]);
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = __builtin_fmaf(c[e], mult[e], bias[e]);
+        v[e] = v[e] > 0.f ? v[e] : 0.f;
+      }
+      if (out16) {   // (wave-uniform)
+        half4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = (half_t)v[e];
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs_h, voff0 + (unsigned)r * rowb, 0, 0);
+      } else {
+        unsigned q = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = __builtin_rintf(v[e] * out_inv);
+          t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
+          q |= ((unsigned)(int)t & 0xFFu) << (8 * e);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(q, drs_h, voff0 + (unsigned)r * rowb, 0, 0);
+      }
     }
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, hv), drs_h, voff0 + (unsigned)r * rowb, 0, 0);
-    if constexpr (SP) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(floatx2, lv), drs_l, voff0 + (unsigned)r * rowb, 0, 0);
   };
 
   frag wA[KBC], wB[KBC];
@@ -1139,7 +1004,7 @@ __device__ __forceinline__ void conv3x3_wsc_body(const ConvParams& p, int bid, i
     const int ry = r / R0W, rx = r - ry * R0W;
     const int iy = ty0 - 1 + ry, ix = tx0 - 1 + rx;
     const bool in = sl < nslots && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    const unsigned off = in ? (unsigned)(((iy * p.W + ix) * p.src_ld + sg.src_coff + ch * CC) * 2 + (cs << 4)) : 0x40000000u;
+    const unsigned off = in ? (unsigned)(((iy * p.W + ix) * p.src_ld + sg.src_coff + ch * CC) * ESZ + (cs << 4)) : 0x40000000u;
     pvh[it] = __builtin_amdgcn_raw_buffer_load_b128(srs_h, off, 0, 0);
     if constexpr (SP) pvl[it] = __builtin_amdgcn_raw_buffer_load_b128(srs_l, off, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -1193,7 +1058,7 @@ __device__ __forceinline__ void conv3x3_wsc_body(const ConvParams& p, int bid, i
         else w_request(wn, std::integral_constant<int, ch + 1>{}, std::integral_constant<int, q - PITER>{}, std::integral_constant<int, q - PITER + 1>{});
       }
       if constexpr (s + PF < STEPS) b[(s + PF) % (PF + 1)] = bfrag(std::integral_constant<int, s + PF>{});
-      if constexpr (ch == 0 && kx == 0 && cbl == 0 && rho < TH) acc[rho] = floatx4{0.f, 0.f, 0.f, 0.f};   // (every wave starts from zero)
+      if constexpr (ch == 0 && kx == 0 && cbl == 0 && rho < TH) acc[rho] = typename E::acc_t{0, 0, 0, 0};
       if constexpr (SP) {
         // term-major: the three products of a split MFMA go to the same accumulator, so the rows' MFMAs are interleaved
         // (lo*hi of rows rho, rho-1, rho-2, then hi*lo, then hi*hi): a dependent MFMA is three issues behind its predecessor
@@ -1252,6 +1117,12 @@ __global__ __launch_bounds__(256) void conv_dual_head3x3_ws_s16_stamped(const Co
 __global__ __launch_bounds__(256) void conv_dual_head3x3_ws_s16(const ConvParams pa, const ConvParams pb, int nb) {
   if ((int)blockIdx.x < nb) conv3x3_wsc_body<s16_t, 8, 256, 4, 4>(pb, (int)blockIdx.x, nb);
   else conv3x3_wsc_body<s16_t, 16, 128, 4, 4>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
+}
+
+// INT8 engines: the same pair on int8 tensors (18 / 36 weight blocks of 64 k per wave: 72 / 144 registers)
+__global__ __launch_bounds__(256) void conv_dual_head3x3_ws_i8(const ConvParams pa, const ConvParams pb, int nb) {
+  if ((int)blockIdx.x < nb) conv3x3_wsc_body<signed char, 8, 256, 4, 4>(pb, (int)blockIdx.x, nb);
+  else conv3x3_wsc_body<signed char, 16, 128, 2, 4>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
 }
 
 #ifndef UNINA_CONV_PROBE   // (ISA probe builds stop here: tools/isa_probe.sh compiles only the kernels above)
@@ -1334,9 +1205,9 @@ constexpr size_t smem_of() {
 #define WS(TH, CIN, NCH, NW)                                                                         \
   {(TH) * 16, (NW) * 16, 32, 3, "conv3x3_ws<f16," #TH "x16," #CIN "/" #NCH "," #NW "w>",                 \
    conv3x3_wsc<half_t, TH, CIN, NCH, NW>, 0, TH, 16, CIN, (NW) * 64, 1, true, NCH}
-#define WSI(TH, CIN, NW)                                                                             \
-  {(TH) * 16, (NW) * 16, 32, 3, "conv3x3_ws<i8," #TH "x16," #CIN "," #NW "w>",                           \
-   conv3x3_ws<TH, CIN, NW, signed char>, 0, TH, 16, CIN, (NW) * 64, 1, true}
+#define WSI(TH, CIN, NCH, NW)                                                                        \
+  {(TH) * 16, (NW) * 16, 32, 3, "conv3x3_ws<i8," #TH "x16," #CIN "/" #NCH "," #NW "w>",                  \
+   conv3x3_wsc<signed char, TH, CIN, NCH, NW>, 0, TH, 16, CIN, (NW) * 64, 1, true, NCH}
 #define WSS(TH, CIN, NCH, NW)                                                                        \
   {(TH) * 16, (NW) * 16, 32, 3, "conv3x3_ws<s16," #TH "x16," #CIN "/" #NCH "," #NW "w>",                 \
    conv3x3_wsc<s16_t, TH, CIN, NCH, NW>, 0, TH, 16, CIN, (NW) * 64, 1, true, NCH}
@@ -1439,8 +1310,8 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         REGQI2(4, 8, 64, 128, 8, 16),                 // kCfgRegqS2_4x8n64c128
         NOCFG,                                        // kCfgRegqS2_8x16n64c32    (Cin 32 < one int8 block)
         REGQI2(8, 8, 32, 128, 8, 16),                 // kCfgRegqS2_8x8n32c128
-        WSI(16, 128, 4),                              // kCfgWs16x16n64c128
-        WSI(8, 256, 4),                               // kCfgWs8x16n64c256
+        WSI(16, 128, 2, 4),                           // kCfgWs16x16n64c128
+        WSI(8, 256, 4, 4),                            // kCfgWs8x16n64c256
         NOCFG, NOCFG, NOCFG,
     },
     {   // split fp16 (kS16): a K-step stages (hi, lo) block pairs -- twice the LDS per stage, hence shallower rings on the wide tiles
@@ -1500,8 +1371,7 @@ inline size_t smem_for(const ConvParams& p, const CfgInfo& c) {
     const size_t ph = c.stride * (c.th - 1) + 3, pw = c.stride * (c.tw - 1) + 3;
     const size_t patch = ((ph * pw * c.cin * esize(p) + 1023) & ~(size_t)1023) + 1024;
     if (c.ws && c.chunks)   // image(s) of a channel chunk, two buffers (conv3x3_wsc_body)
-      return (c.chunks > 1 ? 2 : 1) * (p.dtype == kS16 ? 2 : 1) * ph * pw * ((c.cin / c.chunks) * 2 + 32);
-    if (c.ws) return ph * pw * (c.cin * esize(p) + 32);   // padded pixel pitch, no swizzle (conv3x3_ws_body)
+      return (c.chunks > 1 ? 2 : 1) * (p.dtype == kS16 ? 2 : 1) * ph * pw * ((c.cin / c.chunks) * (p.dtype == kI8 ? 1 : 2) + 32);
     if (p.dtype == kS16) return 2 * patch;                // hi and lo images; accumulators are stored straight from registers
     return max_sz(patch, stage_bytes((c.bm + 15) & ~15, c.bn));
   }
@@ -1658,7 +1528,7 @@ const DualKind kDual[kDualKinds] = {
     {kCfg128x16k64, kCfg128x16k64, 256, "conv_dual_head1x1<glds 128,16,64 x2>", conv_dual_head1x1},
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3_i8<regq i8,8x16,64,128 | regq i8,8x8,64,256>", conv_dual_head3x3_i8},
     {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws<ws 16x16,64,128/2 | ws 8x16,64,256/4>", conv_dual_head3x3_ws},
-    {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws_i8<ws i8,16x16,64,128 | ws i8,8x16,64,256>", conv_dual_head3x3_ws_i8},
+    {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws_i8<ws i8,16x16,64,128/2 | ws i8,8x16,64,256/4>", conv_dual_head3x3_ws_i8},
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3_s16<regq s16,8x16,64,128 | regq s16,8x8,64,256>", conv_dual_head3x3_s16},
     {kCfgWs16x16n64c128, kCfgWsS8x16n64c256, 256, "conv_dual_head3x3_ws_s16<ws s16,16x16,64,128/4 | ws s16,8x16,64,256/4>", conv_dual_head3x3_ws_s16},
 };
