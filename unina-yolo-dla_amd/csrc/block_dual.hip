@@ -35,13 +35,13 @@ __global__ __launch_bounds__(512, 4) void block_dual_s2c3k2i8_128x384_head64(con
   else head_fused_body<64, 8, 16, 8, 4>(ph, (int)blockIdx.x - nc, bd_smem);
 }
 
-// The head as the row-streaming / weights-stationary body (head_ws_body: 16 x 14 output pixels per workgroup, 120 workgroups at
+// The head as the row-streaming / weights-stationary body (head_ws_body: kHeadWsTH x 14 output pixels per workgroup, 156 workgroups at
 // 640^2) next to the block's 100: ONE 512-thread workgroup per CU (234 VGPRs), so the block's weight queue can be as deep as
 // the stand-alone kernel's. 30.5 -> 23.5 us for the launch, -7 us serial latency, frames/s unchanged (same-box A/B).
 #define BLOCK_DUAL_WS(NAME, ...)                                                                                     \
   __global__ __launch_bounds__(512) void NAME(const C3k2Params pc, const HeadParams ph, int nc) {                    \
     if ((int)blockIdx.x < nc) c3k2_fused_body<__VA_ARGS__>(pc, (int)blockIdx.x, bd_smem);                           \
-    else head_ws_body<64, 16, 8>(ph, (int)blockIdx.x - nc, bd_smem);                                                 \
+    else head_ws_body<64, kHeadWsTH, 8>(ph, (int)blockIdx.x - nc, bd_smem);                                                 \
   }
 BLOCK_DUAL_WS(block_dual_s2c3k2_128x384_head64ws, 128, 4, 4, 1, 384, 8, 16, 0, EltH, 128, 128)
 BLOCK_DUAL_WS(block_dual_s2c3k2i8_128x384_head64ws, 128, 4, 4, 1, 384, 8, 8, 0, EltI8, 128, 128)
@@ -65,7 +65,7 @@ hipError_t block_dual_init() {
 }
 
 bool block_dual_match(const C3k2Params& pc, const HeadParams& ph) {
-  if (head_tile_is(ph, 16, 14))   // the row-streaming head: next to either block form, fp16 or int8
+  if (head_tile_is(ph, kHeadWsTH, 14))   // the row-streaming head: next to either block form, fp16 or int8
     return (pc.dtype == kF16 || pc.dtype == kI8) && pc.hid == 128 && pc.nb == 1 && pc.Cin == 384 && pc.tail == 0 && ph.C == 64 &&
            (pc.cpre == 0 || (pc.cpre == 128 && pc.cx == 128)) && c3k2_tile_is(pc, 4, 4);
   const bool pre_ok = pc.cpre == 0 || (pc.cpre == 128 && pc.cx == 128 && head_tile_is(ph, 8, 16));
@@ -75,10 +75,10 @@ bool block_dual_match(const C3k2Params& pc, const HeadParams& ph) {
 
 const char* block_dual_name(int dtype, int cpre) {
   if (head_is_ws(64)) {
-    if (cpre) return dtype == kI8 ? "block_dual_s2c3k2i8_128x384_head64ws<s2conv 128 + c3k2 i8,128,4x4,1,384 | head_ws 64,16x14>"
-                                  : "block_dual_s2c3k2_128x384_head64ws<s2conv 128 + c3k2 128,4x4,1,384 | head_ws 64,16x14>";
-    return dtype == kI8 ? "block_dual_c3k2i8_128x384_head64ws<c3k2 i8,128,4x4,1,384 | head_ws 64,16x14>"
-                        : "block_dual_c3k2_128x384_head64ws<c3k2 128,4x4,1,384 | head_ws 64,16x14>";
+    if (cpre) return dtype == kI8 ? "block_dual_s2c3k2i8_128x384_head64ws<s2conv 128 + c3k2 i8,128,4x4,1,384 | head_ws 64,13x14>"
+                                  : "block_dual_s2c3k2_128x384_head64ws<s2conv 128 + c3k2 128,4x4,1,384 | head_ws 64,13x14>";
+    return dtype == kI8 ? "block_dual_c3k2i8_128x384_head64ws<c3k2 i8,128,4x4,1,384 | head_ws 64,13x14>"
+                        : "block_dual_c3k2_128x384_head64ws<c3k2 128,4x4,1,384 | head_ws 64,13x14>";
   }
   if (cpre) return dtype == kI8 ? "block_dual_s2c3k2i8_128x384_head64<s2conv 128 + c3k2 i8,128,4x4,1,384 | head 64,8x16>"
                                 : "block_dual_s2c3k2_128x384_head64<s2conv 128 + c3k2 128,4x4,1,384 | head 64,8x16>";
@@ -90,7 +90,7 @@ hipError_t block_dual_launch(const C3k2Params& pc, const HeadParams& ph, hipStre
   const int nc = pc.tiles_x * pc.tiles_y, nh = ph.tiles_x * ph.tiles_y;
   const int smem = pc.smem_bytes > ph.smem_bytes ? pc.smem_bytes : ph.smem_bytes;
   if (grid_out) *grid_out = nc + nh;
-  if (head_tile_is(ph, 16, 14)) {
+  if (head_tile_is(ph, kHeadWsTH, 14)) {
     auto fn = pc.cpre ? (pc.dtype == kI8 ? block_dual_s2c3k2i8_128x384_head64ws : block_dual_s2c3k2_128x384_head64ws)
                       : (pc.dtype == kI8 ? block_dual_c3k2i8_128x384_head64ws : block_dual_c3k2_128x384_head64ws);
     hipLaunchKernelGGL(fn, dim3(nc + nh, 1, 1), dim3(512, 1, 1), smem, stream, pc, ph, nc);

@@ -45,7 +45,7 @@ struct HClass {
 const HClass kHeadClasses[] = {
     {64, 8, 16, 8, "head_fused<64,8x16,8w>", head_fused_kernel<64, 8, 16, 8, 16>},   // UNINA_HEAD_ALT=0: the tile form (round 1's), kept as the
                                                                                      // independent implementation the row-streaming form is tested against
-    {64, 16, 14, 8, "head_ws<64,16x14,8w>", head_ws_kernel<64, 16, 8>, true},        // default
+    {64, kHeadWsTH, 14, 8, "head_ws<64,13x14,8w>", head_ws_kernel<64, kHeadWsTH, 8>, true},   // default
 };
 const HClass* find_hclass(int c) {
   // default: the row-streaming class (same-box A/B against the 8x16 tile class: the block dual 30.5 -> 23.5 us, -7 us serial

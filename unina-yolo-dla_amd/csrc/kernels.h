@@ -230,6 +230,10 @@ const char* block_dual_name(int dtype = kF16, int cpre = 0);
 hipError_t block_dual_launch(const C3k2Params& pc, const HeadParams& ph, hipStream_t stream, int* grid_out = nullptr);
 bool c3k2_tile_is(const C3k2Params& p, int th, int tw);    // the tile the layout of `p` was computed for
 bool head_tile_is(const HeadParams& p, int th, int tw);
+// Rows of the row-streaming head's (head_ws_body) th x 14 pixel strips. 13: at 640^2 the P2 map's 160 rows x 12 strips give 156
+// workgroups, which with pan_c3k2_2's 100 (block_dual.hip) fill the 256 CUs in ONE round, and a strip's 18 row iterations take
+// about as long as a block workgroup (16 rows: 120 + 100 workgroups, the head's the long pole: 22.2 us for the launch).
+constexpr int kHeadWsTH = 13;
 
 // ------------------------------------------------------------------------------------------------
 // Stem: fp32 NCHW image -> 3x3/s2 conv (Cin=3) + bias + ReLU -> NHWC fp16
