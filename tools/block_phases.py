@@ -30,5 +30,7 @@ for i, o in enumerate(e.op_infos()):
             continue
         print(f"   {NAMES[k]:16s} +{(st[k] - prev):9.0f} ticks   (t = {(st[k] - st[0]):9.0f})")
         prev = st[k]
+    if st[12] and st[13]:     # sub-stamps of the b0.cv1 step (wave 0): its K loop done, its epilogue's LDS stores landed; the rest is the barrier
+        print(f"   inside b0.cv1: K loop {st[12] - st[3]:.0f}, epilogue {st[13] - st[12]:.0f}, barrier (waiting for the slowest wave) {st[4] - st[13]:.0f} ticks")
     print(f"   (ticks per us of wall clock: {(st[11] - st[0]) / max((st[14] - st[15]) * 0.01, 1e-9):.0f})")
 e.close()

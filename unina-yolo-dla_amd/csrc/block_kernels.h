@@ -148,11 +148,13 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
   const Img U2 = make_img(p.off_u2, H_ / E::CH);     // last bottleneck's output on the tile
   auto in_image = [&](int iy, int ix) { return (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W; };
 
-  auto run_step = [&](auto sc, auto pc, auto baddr, auto epi) {
-    dev::run_step<ST, D, decltype(sc)::value, decltype(pc)::value, E>(q, wbase, smem, wid, lane, baddr, epi, lds_lo);
+  auto run_step = [&](auto sc, auto pc, auto nc, const float* cst, auto baddr, auto epi) {
+    dev::run_step<ST, D, decltype(sc)::value, decltype(pc)::value, E, decltype(nc)::value>(q, wbase, smem, wid, lane, baddr, epi, lds_lo, cst);
   };
-#define STEP(S, P) std::integral_constant<int, (S) + PRE>{}, std::integral_constant<int, (P)>{}
+  // (step, pixels, channels of the step's constant arrays, the arrays)
+#define STEP(S, P, NCH) std::integral_constant<int, (S) + PRE>{}, std::integral_constant<int, (P)>{}, std::integral_constant<int, (NCH)>{}, CST(S)
   typedef typename E::acc_t acc_t;
+  typedef StepConsts<E> KC;
 
   if constexpr (PRE) {
     // ---- pre-step: x = ReLU(3x3/s2 conv of the patch + b) on R0 -> the block's input image ----
@@ -160,7 +162,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
     const Img PI = Img{p.off_p, PI0.nch, PI0.sh, PI0.mask};
     constexpr int CBP = (CPRE ? CPRE : E::KBLK) / E::KBLK;
     const float* c0 = bias_lds;
-    dev::run_step<ST, D, 0, P0, E>(q, wbase, smem, wid, lane,
+    dev::run_step<ST, D, 0, P0, E, CX>(q, wbase, smem, wid, lane,
         [&](int sub, auto kc) {
           constexpr int kb = decltype(kc)::value, tap = kb / CBP, cb = kb - tap * CBP, th3 = tap / 3;
           int r = sub * 16 + l15;
@@ -168,46 +170,48 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           const int ry = r / R0W, rx = r - ry * R0W;
           return PI.addr((2 * ry + th3) * PW + 2 * rx + (tap - th3 * 3), cb * 4 + lq);
         },
-        [&](int sub, int n, const acc_t& acc) {
+        [&](int sub, int n, const acc_t& acc, const KC& k) {
           const int r = sub * 16 + l15;
-          if (r < P0) store4<E, CX>(smem + img_at<E>(Xi, r, n), act_relu<E, CX>(acc, c0, n), c0, n, lds_lo);
-        }, lds_lo);
+          if (r < P0) store4<E>(smem + img_at<E>(Xi, r, n), act_relu<E>(acc, k), k, lds_lo);
+        }, lds_lo, c0);
     stamp(2);
   }
 
   // ---- step 0: a | b = ReLU(W12 x + b12) on R0 --------------------------------------------------------------------
-  run_step(STEP(0, P0),
+  run_step(STEP(0, P0, 2 * H_),
       [&](int sub, auto kc) {
         constexpr int kb = decltype(kc)::value;
         const int r = sub * 16 + l15;
         if constexpr (kb < CX / E::KBLK) return Xi.addr(r < P0 ? r : P0 - 1, kb * 4 + lq);
         else return XRi.addr(r < P0 ? r : P0 - 1, (kb - CX / E::KBLK) * 4 + lq);
       },
-      [&](int sub, int n, const acc_t& acc) {
+      [&](int sub, int n, const acc_t& acc, const KC& k) {
         const int r = sub * 16 + l15;
-        if (r < P0) store4<E, 2 * H_>(smem + img_at<E>(Y, r, n), act_relu<E, 2 * H_>(acc, CST(0), n), CST(0), n, lds_lo);
+        if (r < P0) store4<E>(smem + img_at<E>(Y, r, n), act_relu<E>(acc, k), k, lds_lo);
       });
 
   stamp(3);
   // ---- bottleneck 0 -----------------------------------------------------------------------------------------------
   // t = ReLU(Wb1 a + b) on R0, forced to 0 outside the image (zero padding of the 3x3 that follows)
-  run_step(STEP(1, P0),
+  run_step(STEP(1, P0, H_),
       [&](int sub, auto kc) {
         const int r = sub * 16 + l15;
         return Y.addr(r < P0 ? r : P0 - 1, decltype(kc)::value * 4 + lq);
       },
-      [&](int sub, int n, const acc_t& acc) {
+      [&](int sub, int n, const acc_t& acc, const KC& k) {
+        if constexpr (STAMPS) { if (sub == 0) stamp(12); }      // (debug twin: this step's K loop is done, its epilogue starts)
         const int r = sub * 16 + l15;
         if (r >= P0) return;
         const int ry = r / R0W, rx = r - ry * R0W;
-        floatx4 v = act_relu<E, H_>(acc, CST(1), n);
+        floatx4 v = act_relu<E>(acc, k);
         if (!in_image(ty0 - NB + ry, tx0 - NB + rx)) v = floatx4{0.f, 0.f, 0.f, 0.f};
-        store4<E, H_>(smem + img_at<E>(T, r, n), v, CST(1), n, lds_lo);
+        store4<E>(smem + img_at<E>(T, r, n), v, k, lds_lo);
+        if constexpr (STAMPS) { if (sub == (P0 + 15) / 16 - 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(13); } }   // (... and its LDS stores have landed)
       });
   stamp(4);
   if constexpr (NB == 1) {
     // u = ReLU(3x3(t) + b) + a on the tile
-    run_step(STEP(2, PT),
+    run_step(STEP(2, PT, H_),
         [&](int sub, auto kc) {
           constexpr int kb = decltype(kc)::value, tap = kb / HB, cb = kb - tap * HB, th3 = tap / 3;
           int pp = sub * 16 + l15;
@@ -215,16 +219,16 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           const int py = pp / TW, px = pp - py * TW;
           return T.addr((py + th3) * R0W + px + (tap - th3 * 3), cb * 4 + lq);
         },
-        [&](int sub, int n, const acc_t& acc) {
+        [&](int sub, int n, const acc_t& acc, const KC& k) {
           const int pp = sub * 16 + l15;
           if (pp >= PT) return;
           const int py = pp / TW, px = pp - py * TW;
-          const floatx4 v = add_res<E>(act_relu<E, H_>(acc, CST(2), n), smem, Y, (py + 1) * R0W + px + 1, n, p.res_scale[0], lds_lo);
-          store4<E, H_>(smem + img_at<E>(U2, pp, n), v, CST(2), n, lds_lo);
+          const floatx4 v = add_res<E>(act_relu<E>(acc, k), smem, Y, (py + 1) * R0W + px + 1, n, p.res_scale[0], lds_lo);
+          store4<E>(smem + img_at<E>(U2, pp, n), v, k, lds_lo);
         });
   } else {
     // u1 = ReLU(3x3(t1) + b) + a on R1
-    run_step(STEP(2, P1),
+    run_step(STEP(2, P1, H_),
         [&](int sub, auto kc) {
           constexpr int kb = decltype(kc)::value, tap = kb / HB, cb = kb - tap * HB, th3 = tap / 3;
           int pp = sub * 16 + l15;
@@ -232,32 +236,32 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           const int py = pp / R1W, px = pp - py * R1W;
           return T.addr((py + th3) * R0W + px + (tap - th3 * 3), cb * 4 + lq);
         },
-        [&](int sub, int n, const acc_t& acc) {
+        [&](int sub, int n, const acc_t& acc, const KC& k) {
           const int pp = sub * 16 + l15;
           if (pp >= P1) return;
           const int py = pp / R1W, px = pp - py * R1W;
-          const floatx4 v = add_res<E>(act_relu<E, H_>(acc, CST(2), n), smem, Y, (py + 1) * R0W + px + 1, n, p.res_scale[0], lds_lo);
-          store4<E, H_>(smem + img_at<E>(U1, pp, n), v, CST(2), n, lds_lo);
+          const floatx4 v = add_res<E>(act_relu<E>(acc, k), smem, Y, (py + 1) * R0W + px + 1, n, p.res_scale[0], lds_lo);
+          store4<E>(smem + img_at<E>(U1, pp, n), v, k, lds_lo);
         });
     stamp(5);
     // ---- bottleneck 1 ---------------------------------------------------------------------------------------------
     // t2 = ReLU(Wb1' u1 + b) on R1, 0 outside the image
-    run_step(STEP(3, P1),
+    run_step(STEP(3, P1, H_),
         [&](int sub, auto kc) {
           const int r = sub * 16 + l15;
           return U1.addr(r < P1 ? r : P1 - 1, decltype(kc)::value * 4 + lq);
         },
-        [&](int sub, int n, const acc_t& acc) {
+        [&](int sub, int n, const acc_t& acc, const KC& k) {
           const int r = sub * 16 + l15;
           if (r >= P1) return;
           const int ry = r / R1W, rx = r - ry * R1W;
-          floatx4 v = act_relu<E, H_>(acc, CST(3), n);
+          floatx4 v = act_relu<E>(acc, k);
           if (!in_image(ty0 - 1 + ry, tx0 - 1 + rx)) v = floatx4{0.f, 0.f, 0.f, 0.f};
-          store4<E, H_>(smem + img_at<E>(T, r, n), v, CST(3), n, lds_lo);
+          store4<E>(smem + img_at<E>(T, r, n), v, k, lds_lo);
         });
     stamp(6);
     // u2 = ReLU(3x3(t2) + b) + u1 on the tile
-    run_step(STEP(4, PT),
+    run_step(STEP(4, PT, H_),
         [&](int sub, auto kc) {
           constexpr int kb = decltype(kc)::value, tap = kb / HB, cb = kb - tap * HB, th3 = tap / 3;
           int pp = sub * 16 + l15;
@@ -265,12 +269,12 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           const int py = pp / TW, px = pp - py * TW;
           return T.addr((py + th3) * R1W + px + (tap - th3 * 3), cb * 4 + lq);
         },
-        [&](int sub, int n, const acc_t& acc) {
+        [&](int sub, int n, const acc_t& acc, const KC& k) {
           const int pp = sub * 16 + l15;
           if (pp >= PT) return;
           const int py = pp / TW, px = pp - py * TW;
-          const floatx4 v = add_res<E>(act_relu<E, H_>(acc, CST(4), n), smem, U1, (py + 1) * R1W + px + 1, n, p.res_scale[1], lds_lo);
-          store4<E, H_>(smem + img_at<E>(U2, pp, n), v, CST(4), n, lds_lo);
+          const floatx4 v = add_res<E>(act_relu<E>(acc, k), smem, U1, (py + 1) * R1W + px + 1, n, p.res_scale[1], lds_lo);
+          store4<E>(smem + img_at<E>(U2, pp, n), v, k, lds_lo);
         });
   }
 
@@ -279,7 +283,7 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
   constexpr int ROWB = 2 * H_ * ESZ + 16;  // staged output row: 2h elements + 16 bytes of padding (bank spread)
   unsigned char* stage = smem + p.off_stage;
   constexpr int S3 = 1 + 2 * NB;
-  run_step(STEP(S3, PT),
+  run_step(STEP(S3, PT, 2 * H_),
       [&](int sub, auto kc) {
         constexpr int kb = decltype(kc)::value;
         int pp = sub * 16 + l15;
@@ -291,10 +295,10 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
           return Y.addr((py + NB) * R0W + px + NB, H_ / E::CH + (kb - HB) * 4 + lq);
         }
       },
-      [&](int sub, int n, const acc_t& acc) {
+      [&](int sub, int n, const acc_t& acc, const KC& k) {
         const int pp = sub * 16 + l15;
         if (pp >= PT) return;
-        store4<E, 2 * H_>(stage + pp * ROWB + n * ESZ, act_relu<E, 2 * H_>(acc, CST(S3), n), CST(S3), n, lds_lo);
+        store4<E>(stage + pp * ROWB + n * ESZ, act_relu<E>(acc, k), k, lds_lo);
       });
   stamp(8);
   typedef float vec16 __attribute__((ext_vector_type(4)));  // 16 opaque bytes
@@ -333,16 +337,16 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
     constexpr int ROWT = H_ * TSZ + 16;
     constexpr int S4 = 2 + 2 * NB;
     unsigned char* tout = smem + p.off_tail;
-    run_step(STEP(S4, PT),
+    run_step(STEP(S4, PT, H_),
         [&](int sub, auto kc) {
           int pp = sub * 16 + l15;
           pp = pp < PT ? pp : PT - 1;
           return YS.addr(pp, decltype(kc)::value * 4 + lq);
         },
-        [&](int sub, int n, const acc_t& acc) {
+        [&](int sub, int n, const acc_t& acc, const KC& k) {
           const int pp = sub * 16 + l15;
           if (pp >= PT) return;
-          store4<TE, H_>(tout + pp * ROWT + n * TSZ, act_relu<E, H_>(acc, CST(S4), n), CST(S4), n, lds_lo);
+          store4<TE>(tout + pp * ROWT + n * TSZ, act_relu<E>(acc, k), k, lds_lo);
         });
     stamp(10);
     constexpr int CPT = H_ * TSZ / 16;

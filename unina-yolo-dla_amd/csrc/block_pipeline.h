@@ -129,15 +129,35 @@ __device__ __forceinline__ void lds_barrier() {  // publishes this wave's LDS wr
   asm volatile("" ::: "memory");
 }
 
+// A step's per-channel constants for ONE channel quad of a wave (channels n..n+3), in registers: bias (| multiplier | 1 / s_out
+// for int8). run_step reads them from LDS BEFORE its K loop, so the epilogue starts from registers: read inside the epilogue
+// (one LDS round trip per accumulator, each waited for) they were half of a short step -- the 1x1 steps of the stage-3 block:
+// K loop 880 cycles, epilogue 1 110 (profiles/r03/block_phases_epilogue.txt).
+template <typename E>
+struct StepConsts {
+  floatx4 bias, mult, inv;
+};
+template <typename E, int NCH>
+__device__ __forceinline__ StepConsts<E> load_consts(const float* c, int n) {
+  StepConsts<E> k;
+  k.bias = *reinterpret_cast<const floatx4*>(c + n);
+  if constexpr (E::I8) {
+    k.mult = *reinterpret_cast<const floatx4*>(c + NCH + n);
+    k.inv = *reinterpret_cast<const floatx4*>(c + 2 * NCH + n);
+  }
+  return k;
+}
+
 // One GEMM step S over P pixels.
 //   baddr(sub, kc) : LDS byte address of this lane's 16-byte B fragment of pixel subtile `sub`, k-block kc (an
 //                    std::integral_constant) -- the same for all of the wave's channel subtiles
-//   epi(sub, n, acc): consumes channels n..n+3 of pixel sub*16 + (lane & 15)
+//   epi(sub, n, acc [, k]): consumes channels n..n+3 of pixel sub*16 + (lane & 15); k = the step's constants for those channels
+//                    (StepConsts, preloaded from `cst` = the step's [bias | ...] arrays of NCH channels in LDS) when NCH != 0
 // Ends with the barrier that publishes the epilogue's LDS writes.
 // lds_lo (EltS): byte distance from an LDS image to its lo twin.
-template <typename ST, int D, int S, int P, typename E = EltH, typename BAddr, typename Epi>
+template <typename ST, int D, int S, int P, typename E = EltH, int NCH = 0, typename BAddr, typename Epi>
 __device__ __forceinline__ void run_step(typename E::frag (&q)[D], const unsigned char* wbase, const unsigned char* smem,
-                                         int wid, int lane, BAddr baddr, Epi epi, int lds_lo = 0) {
+                                         int wid, int lane, BAddr baddr, Epi epi, int lds_lo = 0, const float* cst = nullptr) {
   typedef typename E::frag frag;
   typedef typename E::acc_t acc_t;
   constexpr int KB = ST::kb(S), G0 = ST::first(S), WN_T = ST::wnt(S), WVN = ST::waves_n(S), WVM = ST::waves_m(S);
@@ -147,6 +167,11 @@ __device__ __forceinline__ void run_step(typename E::frag (&q)[D], const unsigne
   acc_t acc[WN_T][WM_T];
   frag b[2][WM_T];
   auto& baddr_t = baddr;
+  StepConsts<E> kc[WN_T];
+  if constexpr (NCH != 0) {
+#pragma unroll
+    for (int j = 0; j < WN_T; ++j) kc[j] = load_consts<E, NCH>(cst, (wn * WN_T + j) * 16 + lq * 4);
+  }
 #pragma unroll
   for (int i = 0; i < WM_T; ++i) {
 #pragma unroll
@@ -173,12 +198,19 @@ __device__ __forceinline__ void run_step(typename E::frag (&q)[D], const unsigne
     for (int j = 0; j < WN_T; ++j)
 #pragma unroll
       for (int i = 0; i < WM_T; ++i) acc[j][i] = E::mma(a[j], b[kb & 1][i], acc[j][i]);
+    // pin the iteration: left free, the scheduler sinks a step's weight requests behind its last MFMAs (cv1|cv2 of the stage-3
+    // block: all 16 in one burst at the end, each costing the wave ~70 cycles of issue, and the next step then waits for data
+    // that was only just requested -- the prefetch distance D was lost exactly where the steps are shortest)
+    __builtin_amdgcn_sched_barrier(0);
   });
 #pragma unroll
   for (int j = 0; j < WN_T; ++j)
 #pragma unroll
     for (int i = 0; i < WM_T; ++i)
-      if (wm * WM_T + i < MS) epi(wm * WM_T + i, (wn * WN_T + j) * 16 + lq * 4, acc[j][i]);
+      if (wm * WM_T + i < MS) {
+        if constexpr (NCH != 0) epi(wm * WM_T + i, (wn * WN_T + j) * 16 + lq * 4, acc[j][i], kc[j]);
+        else epi(wm * WM_T + i, (wn * WN_T + j) * 16 + lq * 4, acc[j][i]);
+      }
   lds_barrier();
 }
 
@@ -218,6 +250,19 @@ __device__ __forceinline__ floatx4 act_relu(const typename E::acc_t& acc, const 
   for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
   return v;
 }
+template <typename E>
+__device__ __forceinline__ floatx4 act_relu(const typename E::acc_t& acc, const StepConsts<E>& k) {   // (constants in registers)
+  floatx4 v;
+  if constexpr (E::I8) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf((float)acc[r], k.mult[r], k.bias[r]);
+  } else {
+    v = acc + k.bias;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+  return v;
+}
 // v + residual (channels n..n+3 of image row `row`); int8: fma(code, s_res, v)
 template <typename E>
 __device__ __forceinline__ floatx4 add_res(floatx4 v, const unsigned char* smem, const Img& im, int row, int n, float res_scale, int lds_lo = 0) {
@@ -251,6 +296,33 @@ __device__ __forceinline__ void store4(unsigned char* at, const floatx4& v, cons
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float t = __builtin_rintf(v[r] * inv[r]);  // round half to even
+      t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
+      q |= ((unsigned int)(int)t & 0xFFu) << (8 * r);
+    }
+    *reinterpret_cast<unsigned int*>(at) = q;
+  } else {
+    half4 hv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hv[r] = (_Float16)v[r];
+    *reinterpret_cast<half4*>(at) = hv;
+  }
+}
+template <typename E, typename KE>
+__device__ __forceinline__ void store4(unsigned char* at, const floatx4& v, const StepConsts<KE>& k, long long lo = 0) {   // (constants in registers)
+  if constexpr (E::SPLIT) {
+    half4 hv, lv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      hv[r] = (_Float16)v[r];
+      lv[r] = (_Float16)(v[r] - (float)hv[r]);
+    }
+    *reinterpret_cast<half4*>(at) = hv;
+    *reinterpret_cast<half4*>(at + lo) = lv;
+  } else if constexpr (E::I8) {
+    unsigned int q = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t = __builtin_rintf(v[r] * k.inv[r]);  // round half to even
       t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
       q |= ((unsigned int)(int)t & 0xFFu) << (8 * r);
     }

@@ -146,12 +146,12 @@ __global__ __launch_bounds__(NW * 64) void conv_pair_kernel(const PairParams p) 
   constexpr int ROWB = C1 * ESZ + 16;
   unsigned char* stage = smem + p.off_stage;
   const float* c0 = cst;
-  run_step<ST, D, 0, PT, E>(q, wbase, smem, wid, lane,
+  run_step<ST, D, 0, PT, E, C1>(q, wbase, smem, wid, lane,
       [&](int sub, auto kc) { return Xi.addr(pixel(sub), decltype(kc)::value * 4 + lq); },
-      [&](int sub, int n, const acc_t& acc) {
+      [&](int sub, int n, const acc_t& acc, const StepConsts<E>& k) {
         const int pp = sub * 16 + l15;
-        if (pp < PT) store4<E, C1>(stage + pp * ROWB + n * ESZ, act_relu<E, C1>(acc, c0, n), c0, n, lds_lo);
-      }, lds_lo);
+        if (pp < PT) store4<E>(stage + pp * ROWB + n * ESZ, act_relu<E>(acc, k), k, lds_lo);
+      }, lds_lo, c0);
   constexpr int CPR = C1 * ESZ / 16;
   unsigned char* dst = static_cast<unsigned char*>(p.dst);
   for (int c = threadIdx.x; c < NPL * PT * CPR; c += NT) {
@@ -168,12 +168,12 @@ __global__ __launch_bounds__(NW * 64) void conv_pair_kernel(const PairParams p) 
   constexpr int ROWT = C2 * ESZ + 16;
   unsigned char* tout = smem + p.off_out;
   const float* c1 = cst + E::CM * PL::cfirst(1);
-  run_step<ST, D, 1, PT, E>(q, wbase, smem, wid, lane,
+  run_step<ST, D, 1, PT, E, C2>(q, wbase, smem, wid, lane,
       [&](int sub, auto kc) { return YS.addr(pixel(sub), decltype(kc)::value * 4 + lq); },
-      [&](int sub, int n, const acc_t& acc) {
+      [&](int sub, int n, const acc_t& acc, const StepConsts<E>& k) {
         const int pp = sub * 16 + l15;
-        if (pp < PT) store4<E, C2>(tout + pp * ROWT + n * ESZ, act_relu<E, C2>(acc, c1, n), c1, n, lds_lo);
-      }, lds_lo);
+        if (pp < PT) store4<E>(tout + pp * ROWT + n * ESZ, act_relu<E>(acc, k), k, lds_lo);
+      }, lds_lo, c1);
   constexpr int CPT = C2 * ESZ / 16;
   unsigned char* dst2b = static_cast<unsigned char*>(p.dst2);
   const size_t px = (size_t)p.dst2_ld * ESZ, row = (size_t)(2 * p.W) * px;
