@@ -147,6 +147,28 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
   const Img U1 = make_img(p.off_u1, H_ / E::CH);     // NB == 2: first bottleneck's output on R1
   const Img U2 = make_img(p.off_u2, H_ / E::CH);     // last bottleneck's output on the tile
   auto in_image = [&](int iy, int ix) { return (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W; };
+  // per-lane "inside the image" bits of the two halo'd regions, one bit per 16-pixel subtile (bit i: pixel 16 i + l15), computed
+  // ONCE: the epilogues of the 1x1 steps in front of a 3x3 zero their output outside the image (the 3x3's zero padding) and
+  // used to redo the row / column division and the range test per accumulator, behind an exec-masked branch
+  unsigned inm0 = 0u, inm1 = 0u;
+#pragma unroll
+  for (int i = 0; i < (P0 + 15) / 16; ++i) {
+    const int r = i * 16 + l15, ry = r / R0W, rx = r - ry * R0W;
+    inm0 |= (r < P0 && in_image(ty0 - NB + ry, tx0 - NB + rx)) ? (1u << i) : 0u;
+  }
+  if constexpr (NB == 2) {
+#pragma unroll
+    for (int i = 0; i < (P1 + 15) / 16; ++i) {
+      const int r = i * 16 + l15, ry = r / R1W, rx = r - ry * R1W;
+      inm1 |= (r < P1 && in_image(ty0 - 1 + ry, tx0 - 1 + rx)) ? (1u << i) : 0u;
+    }
+  }
+  auto masked = [](floatx4 v, unsigned bits, int sub) {   // v, or +0 where the lane's bit `sub` is clear: branch-free, exact
+    const int m = -(int)((bits >> sub) & 1u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = __int_as_float(__float_as_int(v[r]) & m);
+    return v;
+  };
 
   auto run_step = [&](auto sc, auto pc, auto nc, const float* cst, auto baddr, auto epi) {
     dev::run_step<ST, D, decltype(sc)::value, decltype(pc)::value, E, decltype(nc)::value>(q, wbase, smem, wid, lane, baddr, epi, lds_lo, cst);
@@ -201,11 +223,8 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
       [&](int sub, int n, const acc_t& acc, const KC& k) {
         if constexpr (STAMPS) { if (sub == 0) stamp(12); }      // (debug twin: this step's K loop is done, its epilogue starts)
         const int r = sub * 16 + l15;
-        if (r >= P0) return;
-        const int ry = r / R0W, rx = r - ry * R0W;
-        floatx4 v = act_relu<E>(acc, k);
-        if (!in_image(ty0 - NB + ry, tx0 - NB + rx)) v = floatx4{0.f, 0.f, 0.f, 0.f};
-        store4<E>(smem + img_at<E>(T, r, n), v, k, lds_lo);
+        const floatx4 v = masked(act_relu<E>(acc, k), inm0, sub);
+        if (r < P0) store4<E>(smem + img_at<E>(T, r, n), v, k, lds_lo);
         if constexpr (STAMPS) { if (sub == (P0 + 15) / 16 - 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(13); } }   // (... and its LDS stores have landed)
       });
   stamp(4);
@@ -253,11 +272,8 @@ __device__ __forceinline__ void c3k2_fused_body(const C3k2Params& p, int bid, un
         },
         [&](int sub, int n, const acc_t& acc, const KC& k) {
           const int r = sub * 16 + l15;
-          if (r >= P1) return;
-          const int ry = r / R1W, rx = r - ry * R1W;
-          floatx4 v = act_relu<E>(acc, k);
-          if (!in_image(ty0 - 1 + ry, tx0 - 1 + rx)) v = floatx4{0.f, 0.f, 0.f, 0.f};
-          store4<E>(smem + img_at<E>(T, r, n), v, k, lds_lo);
+          const floatx4 v = masked(act_relu<E>(acc, k), inm1, sub);
+          if (r < P1) store4<E>(smem + img_at<E>(T, r, n), v, k, lds_lo);
         });
     stamp(6);
     // u2 = ReLU(3x3(t2) + b) + u1 on the tile
