@@ -228,6 +228,28 @@ int unina_debug_block_stamps(unina_engine_t *e, int op_index, long long *out16, 
 /* Library/build identification: "unina_mi355 <version> gfx950". */
 const char *unina_version(void);
 
+/* ------------------------------------------------------------------ multi-GPU: the gather of detection slots, over RCCL
+ * SURVEY.md section 8e. The path shards by frame: one process per GPU, the engine file loaded by each, NO data-path collective;
+ * the only exchange is an all-gather of fixed-size detection records (e.g. k slots of 8 + 8 * MAX_DETECTIONS int32 words, as
+ * bench.py / gather.py use) so that one rank -- the node that publishes -- sees every GPU's detections. The reference has no
+ * counterpart (one GPU, one stream: perception_node.cpp:472,802); these entry points are what its node would call with
+ * several MI355X (INTEGRATION.md "Several GPUs"). RCCL is loaded on first use: single-GPU consumers never touch it, and
+ * unina_comm_* return UNINA_ERR_UNSUPPORTED (message in unina_comm_last_error) where librccl is absent.
+ * Issue the gather on a stream of its own behind an event of the frames it carries, as gather.SlotRing does: the call only
+ * enqueues (RCCL semantics), inference streams need not wait for it. */
+#define UNINA_COMM_ID_BYTES 128
+typedef struct unina_comm unina_comm;
+/* rank 0: 128 opaque bytes to hand to every rank out of band (file, socket, MPI, ROS parameter ...) */
+int unina_comm_unique_id(void *id128);
+/* every rank, collectively: joins the communicator `id128` as `rank` of `world` on HIP device `device_id` */
+int unina_comm_init(unina_comm **out, const void *id128, int rank, int world, int device_id);
+/* d_send: bytes_per_rank bytes on this rank's device; d_recv: world * bytes_per_rank bytes, rank-major. Enqueued on `stream`. */
+int unina_comm_all_gather(unina_comm *c, const void *d_send, void *d_recv, size_t bytes_per_rank, hipStream_t stream);
+int unina_comm_rank(const unina_comm *c);
+int unina_comm_world(const unina_comm *c);
+void unina_comm_destroy(unina_comm *c);
+const char *unina_comm_last_error(void);
+
 /* ------------------------------------------------------------------ post-process C API (gpu_postprocess.h:42-80)
  * Same seven symbols, same argument meaning, hipError_t/hipStream_t in place of cudaError_t/cudaStream_t
  * (ABI-identical: int + pointer), so perception_node.cpp:627-656 recompiles unchanged under HIP.

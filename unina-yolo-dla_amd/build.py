@@ -28,6 +28,7 @@ UNITS = {
     "postprocess.hip": ["-ffp-contract=off"],   # box arithmetic must round like the reference's scalar code
     "preprocess.hip": ["-ffp-contract=off"],    # normalisation arithmetic rounds as written (oracle/preprocess_oracle.c)
     "engine.hip": [],
+    "comm.hip": [],                             # host code only: RCCL all-gather of detection slots, librccl loaded on first use
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result"]
 

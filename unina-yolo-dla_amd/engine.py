@@ -50,6 +50,8 @@ ABI_SYMBOLS = [
     "unina_last_error", "unina_op_count", "unina_get_op_info", "unina_profile_ops", "unina_profile_post", "unina_debug_read_buffer",
     "unina_version", "unina_conv_config_count", "unina_conv_config_name", "unina_set_op_config", "unina_autotune", "unina_debug_post_stamps", "unina_debug_conv_stamps", "unina_debug_dual_stamps", "unina_debug_dual_timeline", "unina_debug_block_stamps", "unina_serial_latency",
     "unina_set_fusion", "unina_fusion_groups", "unina_debug_fusable_groups",
+    "unina_comm_unique_id", "unina_comm_init", "unina_comm_all_gather", "unina_comm_rank", "unina_comm_world", "unina_comm_destroy",
+    "unina_comm_last_error",
     "create_norm_params_imagenet", "create_norm_params", "preprocess_bgra_resize", "preprocess_bgra", "preprocess_nv12",
     "allocate_preprocess_buffer", "free_preprocess_buffer", "create_preprocess_stream", "destroy_preprocess_stream",
     "init_postprocess_resources", "cleanup_postprocess_resources", "reset_detection_counter", "get_detection_count",
@@ -99,6 +101,15 @@ def load_library() -> C.CDLL:
     L.unina_debug_dual_timeline.argtypes = [vp, ci, C.POINTER(C.c_longlong), ci, vp]
     L.unina_debug_block_stamps.argtypes = [vp, ci, C.POINTER(C.c_longlong), vp]
     L.unina_serial_latency.argtypes = [vp, C.POINTER(vp), ci, ci, cf, cf, cf, C.POINTER(C.c_double), vp]
+    # multi-GPU: RCCL gather of detection slots behind the C ABI (csrc/comm.hip)
+    L.unina_comm_unique_id.argtypes = [vp]
+    L.unina_comm_init.argtypes = [C.POINTER(vp), vp, ci, ci, ci]
+    L.unina_comm_all_gather.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.unina_comm_rank.argtypes = [vp]
+    L.unina_comm_world.argtypes = [vp]
+    L.unina_comm_destroy.argtypes = [vp]
+    L.unina_comm_destroy.restype = None
+    L.unina_comm_last_error.restype = C.c_char_p
     # cuda_preprocess.h drop-in symbols
     L.create_norm_params_imagenet.restype = NormParams
     L.create_norm_params.restype = NormParams
