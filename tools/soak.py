@@ -17,6 +17,8 @@ sd = u.synth.make_state_dict(7, g)
 if a.precision == "int8":
     amax = calibrate_amax(sd, g, [u.rng.frame(5000 + i, 640, 640) for i in range(8)])
     e = Engine.from_state_dict(sd, g, precision=export.INT8, amax=amax)
+elif a.precision == "strict":
+    e = Engine.from_state_dict(sd, g, precision=export.STRICT)
 else:
     e = Engine.from_state_dict(sd, g)
 xs = [torch.from_numpy(u.rng.frame(1234 + i, 640, 640)).cuda() for i in range(8)]

@@ -1033,7 +1033,7 @@ __device__ __forceinline__ void conv3x3_wsc_body(const ConvParams& p, int bid, i
   // the next chunk's requests, one per K-loop step from step 0 on: its patch slice first (committed at the end of this
   // chunk), then its weight blocks in the order of first use (all issued well before this chunk's last steps)
   constexpr int NREQ = PITER + KBC;
-  constexpr int RSTRIDE = (STEPS * 3 / 4) / NREQ > 0 ? (STEPS * 3 / 4) / NREQ : 1;   // a request every RSTRIDE steps, all issued by ~3/4 of the loop
+  constexpr int RSTRIDE = (STEPS * 7 / 8) / NREQ > 0 ? (STEPS * 7 / 8) / NREQ : 1;   // a request every RSTRIDE steps, all issued by ~7/8 of the loop
   static_assert(NREQ * RSTRIDE <= STEPS, "the next chunk's requests fit this chunk's steps");
   static_for<0, NCHUNK>([&](auto chc) {
     constexpr int ch = decltype(chc)::value;
