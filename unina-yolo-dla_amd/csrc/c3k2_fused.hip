@@ -86,8 +86,8 @@ const Class kClasses[] = {
     // lost 4-6 % throughput; deeper weight queues (D x2, x1.5) changed nothing.
     C3K2(32, 8, 8, 1, 64, 8, 4),       // backbone.stage1_block        160^2 at 640: 400 workgroups
     C3K2S(32, 8, 8, 1, 64, 8, 4, 32, 64),     // backbone.stage1_conv (3x3/s2, 32 -> 64) + backbone.stage1_block
-    // (stage2_conv + stage2_c3k2, n = 2: the 2-pixel halo recomputes the conv 3x -- 18.3 vs 9.8 + 12.5 us as launches, but
-    //  no latency gain in the frame and -2 % frames/s: not instantiated)
+    // (stage2_conv + stage2_c3k2, n = 2: the 2-pixel halo recomputes the conv 3x -- round 2: 18.3 vs 9.8 + 12.5 us as launches,
+    //  round 3 with lane-order weights: 17.0 vs 8.4 + 11.7 us; both times the serial frame and frames/s did not move: not instantiated)
     C3K2S(64, 4, 8, 1, 192, 8, 8, 64, 64),    // neck.down1 (3x3/s2, 64 -> 64 = the first half of [p2_down | p3_fused]) + neck.pan_c3k2_1
     C3K2S(128, 4, 4, 1, 384, 8, 16, 128, 128),  // neck.down2 + neck.pan_c3k2_2
     C3K2(32, 8, 8, 1, 128, 8, 4),      // neck.fpn_c3k2_2
