@@ -146,6 +146,43 @@ __device__ __forceinline__ bool arrive_and_check_last(unsigned int* ticket, int*
   return true;
 }
 
+// The same hand-off WITHOUT the two fences (buffer_wbl2 / buffer_inv: ~1.7 us each on this part, MI355X_MICROARCH.md "Workgroup
+// dispatch ... visibility"): valid when EVERY handed-off byte is stored with sc1 (st_sc1 below, or an agent-scope atomic) and
+// EVERY load of them by the last arriver is an sc1 load (ld_sc1 / an agent-scope atomic load) -- the guide's measured form "one
+// lane of each storing workgroup adds to ONE counter after every storing wave's vmcnt(0) wait and the workgroup barrier; the
+// workgroup whose add came last loads after its add has returned, its other waves after a barrier". One workgroup per CU.
+__device__ __forceinline__ bool arrive_and_check_last_sc1(unsigned int* ticket, int* is_last /*LDS*/, int arrivals) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's sc1 stores and atomics have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *is_last = (t == (unsigned)arrivals - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  return *is_last != 0;
+}
+__device__ __forceinline__ void st_sc1(unsigned long long* at, unsigned long long v) {
+  __hip_atomic_store(at, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_sc1(const unsigned long long* at) {
+  return __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(float2* at, float2 v) {
+  st_sc1(reinterpret_cast<unsigned long long*>(at), ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x));
+}
+__device__ __forceinline__ float2 ld_sc1(const float2* at) {
+  const unsigned long long u = ld_sc1(reinterpret_cast<const unsigned long long*>(at));
+  return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+}
+__device__ __forceinline__ void st_sc1(float4* at, float4 v) {
+  st_sc1(reinterpret_cast<float2*>(at), make_float2(v.x, v.y));
+  st_sc1(reinterpret_cast<float2*>(at) + 1, make_float2(v.z, v.w));
+}
+__device__ __forceinline__ float4 ld_sc1(const float4* at) {
+  const float2 a = ld_sc1(reinterpret_cast<const float2*>(at)), b = ld_sc1(reinterpret_cast<const float2*>(at) + 1);
+  return make_float4(a.x, a.y, b.x, b.y);
+}
+
 // exclusive prefix of block_count[0..nblocks) into s.scan[0..nblocks]; returns the total. nblocks <= kT.
 __device__ __forceinline__ int scan_block_counts(const int* block_count, int nblocks, Smem& s) {
   const int tid = threadIdx.x;
@@ -409,7 +446,9 @@ __device__ void sort_and_nms(Smem& s, int n, float iou_thr, long long* stamps = 
 // them at system scope and then stores the caller's sequence number; the host spins on that word (engine.hip unina_infer).
 __device__ __forceinline__ void signal_done(const PostParams& p, int tid) {
   if (!p.done_flag) return;
-  __threadfence_system();
+  // every storing wave waits for its own stores, the barrier collects the waves, ONE lane does the system-scope release in
+  // front of the completion word (all 512 threads fencing cost 2-4x one lane's: MI355X_MICROARCH.md, fence prices)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) __hip_atomic_store(p.done_flag, p.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -950,8 +989,8 @@ __global__ __launch_bounds__(kTN) void post_nms_kernel(const PostParams p) {
     __syncthreads();
     if (p.stamps && tid == 0 && t == 0) p.stamps[2] = wall_clock64();
     if (c == w && tid < 64) {   // the diagonal tile publishes its chunk of the candidate list (output stage)
-      p.ws_box[c * 64 + tid] = s.rbox[tid];
-      p.ws_cc[c * 64 + tid] = s.rcc[tid];
+      st_sc1(p.ws_box + c * 64 + tid, s.rbox[tid]);     // (everything the last arriver reads is stored sc1: arrive_and_check_last_sc1)
+      st_sc1(p.ws_cc + c * 64 + tid, s.rcc[tid]);
     }
     const int gi = c * 64 + lane;
     const float4 a = s.rbox[lane];
@@ -993,7 +1032,7 @@ __global__ __launch_bounds__(kTN) void post_nms_kernel(const PostParams p) {
     if (w != c) {   // (the diagonal tile visits every ordered pair itself)
       if (lane < kColsPerWave) {
         const int gj = w * 64 + wv * kColsPerWave + lane;
-        p.ws_full[(size_t)gj * kWords + c] = colword;
+        st_sc1(p.ws_full + (size_t)gj * kWords + c, colword);
         atomicAdd(&p.ws_rank[gj], colcnt);
       }
       if (lane == 0 && colnz) atomicOr(&p.ws_rownz[w], colnz << (kColsPerWave * wv));
@@ -1007,12 +1046,12 @@ __global__ __launch_bounds__(kTN) void post_nms_kernel(const PostParams p) {
         word |= (unsigned long long)s.piece[tid][v] << (kColsPerWave * v);
         cnt += s.rcnt[tid][v];
       }
-      p.ws_full[(size_t)gi * kWords + w] = word;
+      st_sc1(p.ws_full + (size_t)gi * kWords + w, word);
       atomicAdd(&p.ws_rank[gi], cnt);
       const unsigned long long nz = __ballot(word != 0ull);
       if (tid == 0 && nz) atomicOr(&p.ws_rownz[c], nz);
     }
-    if (!arrive_and_check_last(p.ticket2, &s.is_last, ntiles)) return;
+    if (!arrive_and_check_last_sc1(p.ticket2, &s.is_last, ntiles)) return;
   }
   if (p.stamps && tid == 0) p.stamps[4] = wall_clock64();
 
@@ -1028,8 +1067,8 @@ __global__ __launch_bounds__(kTN) void post_nms_kernel(const PostParams p) {
     for (int q = 0; q < 2; ++q) {
       const int e = tid + q * kTN;
       rk[q] = e < n ? __hip_atomic_load(p.ws_rank + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-      cc2[q] = e < n ? p.ws_cc[e] : make_float2(0.f, 0.f);
-      bx2[q] = e < n ? p.ws_box[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+      cc2[q] = e < n ? ld_sc1(p.ws_cc + e) : make_float2(0.f, 0.f);
+      bx2[q] = e < n ? ld_sc1(p.ws_box + e) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     unsigned long long rz = tid < kWords ? __hip_atomic_load(p.ws_rownz + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     for (int k0 = tid; k0 < total; k0 += kTN * B) {
@@ -1038,7 +1077,7 @@ __global__ __launch_bounds__(kTN) void post_nms_kernel(const PostParams p) {
       for (int q = 0; q < B; ++q) {
         const int k = k0 + q * kTN;
         const int row = k / nw, wd = k - row * nw;
-        v[q] = k < total ? p.ws_full[(size_t)row * kWords + wd] : 0ull;
+        v[q] = k < total ? ld_sc1(p.ws_full + (size_t)row * kWords + wd) : 0ull;
       }
 #pragma unroll
       for (int q = 0; q < B; ++q) {
