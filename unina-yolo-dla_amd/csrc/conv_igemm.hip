@@ -1105,6 +1105,14 @@ __global__ __launch_bounds__(256) void conv_dual_head3x3_ws(const ConvParams pa,
   if ((int)blockIdx.x < nb) conv3x3_wsc_body<half_t, 8, 256, 4, 4>(pb, (int)blockIdx.x, nb);
   else conv3x3_wsc_body<half_t, 16, 128, 2, 4>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
 }
+// The same pair on LARGE frames (more workgroups than CUs even with the tiles above: 1280^2, or several such launches in flight):
+// half-height tiles and at most 256 registers, so that TWO workgroups share a CU -- a SIMD's two waves together run at ~19 cycles
+// per MFMA against 25 for a lone wave. At 640^2 (220 workgroups: one round either way) this form starts 440 workgroups that each
+// load the same weights for half the pixels: launch 14.2 against 13.2 us; at 1280^2 38.2 -> 32.3 us, 0.32 -> 0.37 of the peak.
+__global__ __launch_bounds__(256, 2) void conv_dual_head3x3_ws_small(const ConvParams pa, const ConvParams pb, int nb) {
+  if ((int)blockIdx.x < nb) conv3x3_wsc_body<half_t, 4, 256, 4, 4>(pb, (int)blockIdx.x, nb);
+  else conv3x3_wsc_body<half_t, 8, 128, 2, 4>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
+}
 __global__ __launch_bounds__(256) void conv_dual_head3x3_ws_stamped(const ConvParams pa, const ConvParams pb, int nb) {
   if ((int)blockIdx.x < nb) conv3x3_wsc_body<half_t, 8, 256, 4, 4, true>(pb, (int)blockIdx.x, nb);
   else conv3x3_wsc_body<half_t, 16, 128, 2, 4, true>(pa, (int)blockIdx.x - nb, (int)gridDim.x - nb);
@@ -1252,6 +1260,8 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         WS(16, 128, 2, 4),                            // kCfgWs16x16n64c128    (P3 head layers, weights-stationary, two chunks of 64 channels)
         WS(8, 256, 4, 4),                             // kCfgWs8x16n64c256     (P4 head layers, weights-stationary, four chunks)
         NOCFG, NOCFG, NOCFG,                          // (split-fp16 weights-stationary kernels)
+        WS(8, 128, 2, 4),                             // kCfgWs8x16n64c128     (the pair on large frames: half-height tiles, 230 VGPRs, two workgroups per CU)
+        WS(4, 256, 4, 4),                             // kCfgWs4x16n64c256
     },
     {
         CFG(float, "f32", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
@@ -1277,6 +1287,7 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         NOCFG, NOCFG, NOCFG, NOCFG, NOCFG, NOCFG,
         NOCFG, NOCFG,
         NOCFG, NOCFG, NOCFG,
+        NOCFG, NOCFG,                                 // (fp16 half-height weights-stationary tiles)
     },
     {
         CFG(signed char, "i8", 64, 64, 64, 2, 2, 4),    // kCfg64x64k64
@@ -1313,6 +1324,7 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         WSI(16, 128, 2, 4),                           // kCfgWs16x16n64c128
         WSI(8, 256, 4, 4),                            // kCfgWs8x16n64c256
         NOCFG, NOCFG, NOCFG,
+        NOCFG, NOCFG,                                 // (fp16 half-height weights-stationary tiles)
     },
     {   // split fp16 (kS16): a K-step stages (hi, lo) block pairs -- twice the LDS per stage, hence shallower rings on the wide tiles
         CFG(s16_t, "s16", 64, 64, 64, 2, 2, 3),     // kCfg64x64k64
@@ -1347,6 +1359,7 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         WSS(8, 64, 1, 4),                           // kCfgWsS8x16n64c64     (P2 head layers)
         WSS(8, 128, 2, 4),                          // kCfgWsS8x16n64c128    (P3 head layers: two chunks of 64 channels)
         WSS(8, 256, 4, 4),                          // kCfgWsS8x16n64c256    (P4 head layers: four chunks. 4-row tiles -- 240 workgroups of the P3 conv's size -- ran 34 us per pair against 30.6)
+        NOCFG, NOCFG,                               // (fp16 half-height weights-stationary tiles)
     },
 };
 #undef CFG
@@ -1522,7 +1535,7 @@ struct DualKind {
   const char* name;
   void (*fn)(const ConvParams, const ConvParams, int);
 };
-enum { kDualRegq = 0, kDual1x1, kDualRegqI8, kDualWs, kDualWsI8, kDualRegqS16, kDualWsS16, kDualKinds };
+enum { kDualRegq = 0, kDual1x1, kDualRegqI8, kDualWs, kDualWsI8, kDualRegqS16, kDualWsS16, kDualWsSmall, kDualKinds };
 const DualKind kDual[kDualKinds] = {
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3<regq 8x16,64,128 | regq 8x8,64,256>", conv_dual_head3x3},
     {kCfg128x16k64, kCfg128x16k64, 256, "conv_dual_head1x1<glds 128,16,64 x2>", conv_dual_head1x1},
@@ -1531,6 +1544,7 @@ const DualKind kDual[kDualKinds] = {
     {kCfgWs16x16n64c128, kCfgWs8x16n64c256, 256, "conv_dual_head3x3_ws_i8<ws i8,16x16,64,128/2 | ws i8,8x16,64,256/4>", conv_dual_head3x3_ws_i8},
     {kCfgRegq8x16n64c128, kCfgRegq8x8n64c256, 512, "conv_dual_head3x3_s16<regq s16,8x16,64,128 | regq s16,8x8,64,256>", conv_dual_head3x3_s16},
     {kCfgWs16x16n64c128, kCfgWsS8x16n64c256, 256, "conv_dual_head3x3_ws_s16<ws s16,16x16,64,128/4 | ws s16,8x16,64,256/4>", conv_dual_head3x3_ws_s16},
+    {kCfgWs8x16n64c128, kCfgWs4x16n64c256, 256, "conv_dual_head3x3_ws_small<ws 8x16,64,128/2 | ws 4x16,64,256/4, 2 per CU>", conv_dual_head3x3_ws_small},
 };
 }  // namespace
 
@@ -1552,7 +1566,11 @@ int conv_dual_match(const ConvParams& a, const ConvParams& b) {
   if (a.dtype != kF16 || b.dtype != kF16) return -1;
   // the weights-stationary pair: default for fp16 (same-box A/B against the register-queue pair: +2-3 % frames/s at 2 frames in
   // flight, serial latency equal within noise; workgroup lives 9-11 us against 12-15). UNINA_DUAL_WS=0 falls back.
-  if (ws && fits(kDualWs)) return kDualWs;
+  if (ws && fits(kDualWs)) {
+    // more workgroups than CUs with the full-height tiles: the half-height form, two workgroups per CU
+    if (fits(kDualWsSmall) && conv_dual_grid(kDualWs, a, b) > 256) return kDualWsSmall;
+    return kDualWs;
+  }
   if (fits(kDualRegq)) return kDualRegq;
   auto tiny = [](const ConvParams& p) {
     for (int s = 0; s < p.nseg; ++s)
@@ -1585,7 +1603,7 @@ hipError_t conv_dual_launch(int kind, const ConvParams& pa_in, const ConvParams&
     if (kind != kDualWs && kind != kDualWsS16) return hipErrorInvalidValue;
     fn = kind == kDualWs ? conv_dual_head3x3_ws_stamped : conv_dual_head3x3_ws_s16_stamped;
   }
-  hipLaunchKernelGGL(fn, dim3(na + nb, 1, 1), dim3(k.threads, 1, 1), max_sz(sa, sb), stream, pa, pb, (kind == kDualWs || kind == kDualWsI8 || kind == kDualWsS16) ? nb : na);   // (the weights-stationary pairs put conv B first)
+  hipLaunchKernelGGL(fn, dim3(na + nb, 1, 1), dim3(k.threads, 1, 1), max_sz(sa, sb), stream, pa, pb, (kind == kDualWs || kind == kDualWsI8 || kind == kDualWsS16 || kind == kDualWsSmall) ? nb : na);   // (the weights-stationary pairs put conv B first)
   return hipGetLastError();
 }
 

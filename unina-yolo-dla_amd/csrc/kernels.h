@@ -78,6 +78,7 @@ enum ConvConfig : int {
   kCfgRegqS2_8x8n64c64, kCfgRegqS2_8x16n64c64, kCfgRegqS2_8x8n64c128, kCfgRegqS2_4x8n64c128, kCfgRegqS2_8x16n64c32, kCfgRegqS2_8x8n32c128,
   kCfgWs16x16n64c128, kCfgWs8x16n64c256,
   kCfgWsS8x16n64c64, kCfgWsS8x16n64c128, kCfgWsS8x16n64c256,   // split fp16 (STRICT engines): weights-stationary, row-walking, channel-chunked
+  kCfgWs8x16n64c128, kCfgWs4x16n64c256,                        // fp16: the half-height tiles of the head pair on large frames (two workgroups per CU)
   kCfgCount
 };
 struct ConvLaunch {
