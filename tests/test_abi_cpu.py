@@ -173,3 +173,18 @@ def test_node_harness_builds_and_links_against_the_library(pkg):
     for sym in ("unina_load_engine", "unina_enqueue", "unina_infer", "unina_infer_bgra", "decode_yolo_head", "run_gpu_nms",
                 "copy_valid_detections_to_host", "preprocess_bgra_resize", "reset_detection_counter", "get_detection_count"):
         assert sym in nm, sym
+
+
+def test_comm_entry_points_reject_bad_arguments_without_touching_a_gpu(lib):
+    """include/unina_mi355.h "multi-GPU": argument errors of the RCCL gather entry points are reported through the return
+    code and unina_comm_last_error before any HIP / RCCL call is made (so this runs on the CPU-only container too)."""
+    import ctypes as C
+    comm = C.c_void_p()
+    ident = (C.c_char * 128)()
+    assert lib.unina_comm_init(C.byref(comm), ident, 2, 1, 0) != 0 and not comm.value          # rank outside the world
+    assert b"bad arguments" in lib.unina_comm_last_error()
+    assert lib.unina_comm_init(None, ident, 0, 1, 0) != 0
+    assert lib.unina_comm_all_gather(None, None, None, 0, None) != 0
+    assert lib.unina_comm_unique_id(None) != 0
+    assert lib.unina_comm_rank(None) == -1 and lib.unina_comm_world(None) == -1
+    lib.unina_comm_destroy(None)                                                                 # a no-op
