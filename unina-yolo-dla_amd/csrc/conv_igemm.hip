@@ -1356,7 +1356,8 @@ const CfgInfo kCfg[kNumDTypes][kCfgCount] = {
         WSS(16, 128, 4, 4),                         // kCfgWs16x16n64c128    (P3 head layers in the pair: 16-row tiles, four chunks of 32 channels --
                                                     //  100 + 120 workgroups run in ONE round; with 8-row tiles the pair's 320 needed two)
         NOCFG,                                      // kCfgWs8x16n64c256     (fp16 / int8 only)
-        WSS(8, 64, 1, 4),                           // kCfgWsS8x16n64c64     (P2 head layers)
+        WSS(16, 64, 2, 4),                          // kCfgWsS8x16n64c64     (P2 head layers: 16-row tiles, two chunks of 32 channels -- 200 workgroups, ONE round; the 8-row
+                                                    //  single-chunk form ran 400 workgroups at one per CU in two rounds: 18 us per layer)
         WSS(8, 128, 2, 4),                          // kCfgWsS8x16n64c128    (P3 head layers: two chunks of 64 channels)
         WSS(8, 256, 4, 4),                          // kCfgWsS8x16n64c256    (P4 head layers: four chunks. 4-row tiles -- 240 workgroups of the P3 conv's size -- ran 34 us per pair against 30.6)
         NOCFG, NOCFG,                               // (fp16 half-height weights-stationary tiles)
