@@ -530,7 +530,7 @@ __device__ __forceinline__ void head_fused_body(const HeadParams& p, int bid, un
 //   layer 1: one iteration later (a barrier in between) the h0 row feeds output rows i, i-1, i-2 the same way; a finished h1
 //            row goes to the LDS h1 tile;
 //   layer 2: after the last row, the 1x1 output convs read h1 from LDS and store the fp32 planes.
-// LDS is read once per three MFMAs, with immediate offsets (padded pixel pitch, no xor swizzle: conv3x3_ws_body explains
+// LDS is read once per three MFMAs, with immediate offsets (padded pixel pitch, no xor swizzle: conv3x3_wsc_body explains
 // why), every weight block is fetched once per workgroup, and each output receives its products in the order (ky, kx, cb)
 // from a zero accumulator with the same fp16 rounding points as head_fused_body: bit-identical results.
 template <int C, int TH, int NW>

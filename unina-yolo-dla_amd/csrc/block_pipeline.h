@@ -402,7 +402,7 @@ struct PatchRegs {
   static constexpr int nchx = CIN / E::CH, nslots = RH * RW * nchx, ITER = (nslots + NT - 1) / NT;
   floatx4 v[ITER];
 };
-// The form in use: a branch around each load (out-of-image pixels are not fetched). Same-box A/B (tools/ab_run.sh, regq head
+// The form in use: a branch around each load (out-of-image pixels are not fetched). Same-box A/B (round 2, regq head
 // pairs): LDS-DMA 19.8 us, this 18.9 us, the branch-free clamped form above 20.5 us per pair.
 template <int RH, int RW, int CIN, int NT, typename E = EltH>
 __device__ __forceinline__ void patch_issue(PatchRegs<RH, RW, CIN, NT, E>& pr, const void* src_, int src_ld, int H, int W, int y0,

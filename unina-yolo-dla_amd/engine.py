@@ -18,7 +18,7 @@ from . import export as _export
 from .graph import Graph, OUTPUT_NAMES
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("UNINA_LIB") or os.path.join(_PKG, "libunina_mi355.so")   # (UNINA_LIB: A/B builds, tools/ab_build.sh)
+LIB_PATH = os.environ.get("UNINA_LIB") or os.path.join(_PKG, "libunina_mi355.so")   # (UNINA_LIB: another build of the library, for same-box A/B runs)
 MAX_DETECTIONS = 1024
 
 DET_DTYPE = np.dtype([("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4"), ("confidence", "<f4"),
